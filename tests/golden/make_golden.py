@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING the reference.
+
+Run in the build container only (it needs /root/reference, which does not exist on the GPU box):
+
+    python tests/golden/make_golden.py
+
+The reference (`/root/reference/spectre.py`) ships no tests and no fixtures, so the
+spectral-mix hot path (`spectre.py:506`, `:542-553`) is pinned here by importing the reference
+module, driving `SpectreHead.forward` on seeded inputs and recording, per case,
+
+    x            module input                         (B, N, d) f32
+    sd/<name>    the module's state_dict              (so the drop-in module can load it)
+    V            W_v(x), captured by a forward hook   (B, N, d) f32      -> kernel input
+    gate         the filter that reaches `:542`       (B, G, F) c64      -> kernel input
+                 (= modrelu output times pos_phase, `:531-536`)
+    mem          memory_fft or absent                 (F, d) c64         -> kernel input
+    out          SpectreHead.forward(x, ...)          (B, min(N,n_fft), d) f32
+
+Every case is self-checked before it is written: `irfft(gate_bc * rfft(V) [+ mem])[:, :N]`
+recomputed from the captured tensors must equal `out` bit for bit (SURVEY.md §4 identity 1).
+
+Adversarial-gate cases (G6) and the bf16 case (G8) still run the reference's own forward: the
+module's `modrelu` is swapped for a stub that returns a chosen gate and `W_v` is set to the
+identity, so lines `:542-553` execute unmodified on inputs we control.
+
+The files are data only: inputs and the outputs the reference produced for them.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, "/root/reference")
+import spectre as ref  # noqa: E402  (the reference; never shipped)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+torch.set_num_threads(4)
+
+
+class _FixedGate(torch.nn.Module):
+    """Stub for `modrelu`: ignores its input and returns a preset (B, G*F) complex gate."""
+
+    def __init__(self, gate_flat):
+        super().__init__()
+        self.g = gate_flat
+
+    def forward(self, z):
+        return self.g.reshape(z.shape)
+
+
+def _capture(head, x, pos_phase=None, memory_fft=None):
+    cap = {}
+    h1 = head.W_v.register_forward_hook(lambda m, i, o: cap.__setitem__("V", o.detach().clone()))
+    h2 = head.modrelu.register_forward_hook(lambda m, i, o: cap.__setitem__("g", o.detach().clone()))
+    with torch.no_grad():
+        out = head(x, pos_phase=pos_phase, memory_fft=memory_fft)
+    h1.remove()
+    h2.remove()
+    B = x.shape[0]
+    gate = cap["g"].reshape(B, head.G, head.F_half)
+    if pos_phase is not None:  # spectre.py:534-536
+        gate = gate * pos_phase.unsqueeze(1 if pos_phase.dim() == 2 else 0)
+    return cap["V"], gate, out
+
+
+def _selfcheck(V, gate, mem, n_fft, d_g, out):
+    N = V.shape[1]
+    vf = torch.fft.rfft(V, n=n_fft, dim=1)
+    gb = gate.permute(0, 2, 1).repeat_interleave(d_g, dim=-1)
+    mixed = gb * vf
+    if mem is not None:
+        mixed = mixed + mem.unsqueeze(0)
+    y = torch.fft.irfft(mixed, n=n_fft, dim=1)[:, :N]
+    assert y.shape == out.shape, (y.shape, out.shape)
+    assert torch.equal(y, out), float((y - out).abs().max())
+
+
+def _save(name, *, x, head, V, gate, out, mem=None, pos_phase=None, extra=None, with_sd=True):
+    d = {"V": V.numpy(), "gate": gate.numpy().astype(np.complex64), "out": out.numpy(),
+         "n_fft": np.int64(head.n_fft), "G": np.int64(head.G)}
+    if with_sd:
+        d["x"] = x.numpy()   # module-level cases only; fixed-gate cases have x == V (W_v = identity)
+    if mem is not None:
+        d["mem"] = mem.numpy().astype(np.complex64)
+    if pos_phase is not None:
+        d["pos_phase"] = pos_phase.numpy().astype(np.complex64)
+    if with_sd:
+        for k, v in head.state_dict().items():
+            d["sd/" + k] = v.numpy()
+    if extra:
+        d.update(extra)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **d)
+    print(f"{name:28s} x{tuple(x.shape)} gate{tuple(gate.shape)} out{tuple(out.shape)}  {os.path.getsize(path) / 1e3:.0f} kB")
+
+
+def _head(d, n_fft, G, seed, pooling="mean"):
+    torch.manual_seed(seed)
+    h = ref.SpectreHead(d, n_fft, num_groups=G, pooling_type=pooling).eval()
+    return h
+
+
+def case_module(name, B, N, d, n_fft, G, seed, *, pooling="mean", with_mem=False, phase_shape=None, with_sd=True):
+    head = _head(d, n_fft, G, seed, pooling)
+    g = torch.Generator().manual_seed(seed + 1000)
+    x = torch.randn(B, N, d, generator=g)
+    F = head.F_half
+    mem = None
+    if with_mem:
+        mem = torch.complex(torch.randn(F, d, generator=g), torch.randn(F, d, generator=g)) * 0.5
+    pp = None
+    if phase_shape is not None:
+        k = torch.arange(F, dtype=torch.float32)
+        if phase_shape == "F":
+            pp = torch.exp(1j * 2 * np.pi * k * 3.0 / n_fft)
+        elif phase_shape == "1F":
+            pp = torch.exp(1j * 2 * np.pi * k * 5.0 / n_fft).unsqueeze(0)
+        elif phase_shape == "BF":
+            shifts = torch.arange(B, dtype=torch.float32).unsqueeze(1) + 1.0
+            pp = torch.exp(1j * 2 * np.pi * k.unsqueeze(0) * shifts / n_fft)
+        pp = pp.to(torch.complex64)
+    V, gate, out = _capture(head, x, pos_phase=pp, memory_fft=mem)
+    _selfcheck(V, gate, mem, n_fft, head.d_g, out)
+    _save(name, x=x, head=head, V=V, gate=gate, out=out, mem=mem, pos_phase=pp, with_sd=with_sd)
+
+
+def case_fixed_gate(name, B, N, d, n_fft, G, seed, gate_fn, *, bf16=False, with_mem=False):
+    """Run reference lines :542-553 on a gate we choose (W_v = identity so V == x)."""
+    head = _head(d, n_fft, G, seed)
+    with torch.no_grad():
+        head.W_v.weight.copy_(torch.eye(d))
+    g = torch.Generator().manual_seed(seed + 2000)
+    x = torch.randn(B, N, d, generator=g)
+    extra = {}
+    if bf16:
+        x = x.bfloat16().float()  # values exactly representable in bf16
+    F = head.F_half
+    gate = gate_fn(B, G, F, g).to(torch.complex64)
+    head.modrelu = _FixedGate(gate.reshape(B, G * F))
+    mem = None
+    if with_mem:
+        mem = torch.complex(torch.randn(F, d, generator=g), torch.randn(F, d, generator=g)) * 0.25
+    V, gate_c, out = _capture(head, x, memory_fft=mem)
+    assert torch.equal(V, x)  # identity projection is exact
+    assert torch.equal(gate_c, gate)
+    _selfcheck(V, gate, mem, n_fft, head.d_g, out)
+    if bf16:
+        extra["out_bf16_bits"] = out.bfloat16().view(torch.int16).numpy()
+    _save(name, x=x, head=head, V=V, gate=gate, out=out, mem=mem, extra=extra, with_sd=False)
+
+
+def g_random(scale=0.3, zero_frac=0.18):
+    def f(B, G, F, gen):
+        z = torch.complex(torch.randn(B, G, F, generator=gen), torch.randn(B, G, F, generator=gen)) * scale
+        keep = torch.rand(B, G, F, generator=gen) >= zero_frac  # modReLU zeroes ~18 % at init
+        return z * keep
+    return f
+
+
+def g_unit(B, G, F, gen):
+    return torch.ones(B, G, F, dtype=torch.complex64)
+
+
+def g_single_bin(B, G, F, gen):
+    z = torch.zeros(B, G, F, dtype=torch.complex64)
+    for b in range(B):
+        for gg in range(G):
+            z[b, gg, (3 + 5 * b + 7 * gg) % F] = complex(0.5 + b, -0.25 * (gg + 1))
+    return z
+
+
+def g_imag_edges(B, G, F, gen):
+    """Large imaginary parts at DC and Nyquist: irfft must ignore them."""
+    z = g_random(0.3, 0.0)(B, G, F, gen)
+    z[..., 0] = torch.complex(z[..., 0].real, torch.full_like(z[..., 0].real, 7.0))
+    z[..., -1] = torch.complex(z[..., -1].real, torch.full_like(z[..., -1].real, -9.0))
+    return z
+
+
+def main():
+    # G1 — config 0 of BASELINE.json: (B=4, N=256, D=64, G=4)
+    case_module("g1_b4_n256_d64", 4, 256, 64, 256, 4, seed=0)
+    # G2 — memory_fft + pos_phase in each accepted shape (spectre.py:534-536, :548-549)
+    case_module("g2_mem_phaseF", 2, 64, 32, 64, 4, seed=1, with_mem=True, phase_shape="F")
+    case_module("g2_mem_phase1F", 2, 64, 32, 64, 4, seed=2, with_mem=True, phase_shape="1F")
+    case_module("g2_mem_phaseBF", 2, 64, 32, 64, 4, seed=3, with_mem=True, phase_shape="BF")
+    case_module("g2_attnpool", 2, 64, 32, 64, 2, seed=4, pooling="attention")
+    # G3 — N < n_fft (zero pad) and N > n_fft (truncate; output shrinks to n_fft rows)
+    case_module("g3_pad_n20_fft32", 2, 20, 8, 32, 2, seed=5)
+    case_module("g3_trunc_n48_fft32", 2, 48, 8, 32, 2, seed=6)
+    # G4 — non-power-of-two even n_fft sharing N=3000's factor set (2,3,5), and 3000 itself
+    case_module("g4_n60", 2, 60, 8, 60, 2, seed=7)
+    case_module("g4_n24", 2, 24, 8, 24, 4, seed=8)
+    case_module("g4_n3000", 1, 3000, 8, 3000, 2, seed=9, with_sd=False)
+    # G5 — odd n_fft (only Im(DC) is ignored), plus a prime and a 7-smooth length
+    case_module("g5_n15", 2, 15, 8, 15, 2, seed=10)
+    case_fixed_gate("g5_n97_prime", 2, 97, 4, 97, 2, 11, g_random())
+    case_fixed_gate("g5_n210", 1, 210, 4, 210, 1, 12, g_random())
+    case_fixed_gate("g5_n31_oddG", 2, 31, 6, 31, 2, 13, g_imag_edges)   # d_g = 3 (odd): no channel pairing
+    # G6 — adversarial gates through the reference's own lines :542-553
+    case_fixed_gate("g6_unit_gate", 2, 64, 8, 64, 2, 14, g_unit)
+    case_fixed_gate("g6_single_bin", 2, 64, 8, 64, 2, 15, g_single_bin)
+    case_fixed_gate("g6_imag_edges", 2, 64, 8, 64, 4, 16, g_imag_edges)
+    case_fixed_gate("g6_zeros_mem", 2, 128, 8, 128, 2, 17, g_random(0.3, 0.5), with_mem=True)
+    case_fixed_gate("g6_pad_mem", 2, 50, 8, 128, 2, 18, g_random(), with_mem=True)
+    # G7 — full-length columns at the benchmark sizes
+    case_fixed_gate("g7_n1024", 1, 1024, 16, 1024, 4, 19, g_random())
+    case_fixed_gate("g7_n4096", 1, 4096, 16, 4096, 4, 20, g_random())
+    case_fixed_gate("g7_n2048_mem", 1, 2048, 16, 2048, 2, 21, g_random(), with_mem=True)
+    # G8 — bf16 input values; oracle = reference on x_bf16.float(); bf16 rounding of the result stored
+    case_fixed_gate("g8_bf16_n1024", 1, 1024, 16, 1024, 4, 22, g_random(), bf16=True)
+    case_fixed_gate("g8_bf16_n4096", 1, 4096, 16, 4096, 4, 23, g_random(), bf16=True)
+
+
+if __name__ == "__main__":
+    main()
