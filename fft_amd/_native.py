@@ -1,0 +1,87 @@
+"""ctypes binding of libspectre_hip.so (C ABI: include/spectre_hip.h).
+
+There is no CPU or PyTorch fallback behind this module: if the shared object is missing or does not export
+the ABI the header declares, importing `fft_amd.functional` works but every call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+
+import torch  # noqa: F401  — must be imported first: the library binds to the HIP runtime torch already loaded
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libspectre_hip.so")
+
+ABI_VERSION = 1
+F32, BF16 = 0, 1
+ALGO = {"auto": 0, "stockham": 1, "regtile": 2}
+
+# every symbol include/spectre_hip.h declares
+EXPORTS = ("spectre_version", "spectre_last_error", "spectre_mix_fwd", "spectre_mix_describe",
+           "spectre_plan_create", "spectre_plan_destroy", "spectre_mix_time")
+
+
+class SpectreMixArgs(ctypes.Structure):
+    _fields_ = [
+        ("v", ctypes.c_void_p), ("gate", ctypes.c_void_p), ("mem", ctypes.c_void_p), ("out", ctypes.c_void_p),
+        ("B", ctypes.c_int64), ("N_in", ctypes.c_int64), ("n_fft", ctypes.c_int64), ("D", ctypes.c_int64),
+        ("G_tot", ctypes.c_int64),
+        ("v_sb", ctypes.c_int64), ("v_sn", ctypes.c_int64), ("out_sb", ctypes.c_int64), ("out_sn", ctypes.c_int64),
+        ("in_dtype", ctypes.c_int32), ("out_dtype", ctypes.c_int32), ("algo", ctypes.c_int32), ("device", ctypes.c_int32),
+        ("stream", ctypes.c_void_p),
+    ]
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the shared library; raises NativeLibraryError if it cannot be used."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise NativeLibraryError(
+                f"{LIB_PATH} not found — build it with `python -m fft_amd.build` (hipcc, gfx950). "
+                "There is no fallback implementation.")
+        lib = ctypes.CDLL(LIB_PATH)
+        missing = [s for s in EXPORTS if not hasattr(lib, s)]
+        if missing:
+            raise NativeLibraryError(f"{LIB_PATH} lacks symbols {missing}")
+        lib.spectre_version.restype = ctypes.c_int
+        lib.spectre_last_error.restype = ctypes.c_char_p
+        lib.spectre_mix_fwd.argtypes = [ctypes.POINTER(SpectreMixArgs)]
+        lib.spectre_mix_fwd.restype = ctypes.c_int
+        lib.spectre_mix_describe.argtypes = [ctypes.POINTER(SpectreMixArgs), ctypes.c_char_p, ctypes.c_size_t]
+        lib.spectre_mix_describe.restype = ctypes.c_int
+        lib.spectre_plan_create.argtypes = [ctypes.c_int, ctypes.c_int64]
+        lib.spectre_plan_create.restype = ctypes.c_int
+        lib.spectre_plan_destroy.argtypes = [ctypes.c_int, ctypes.c_int64]
+        lib.spectre_plan_destroy.restype = ctypes.c_int
+        lib.spectre_mix_time.argtypes = [ctypes.POINTER(SpectreMixArgs), ctypes.c_int, ctypes.c_int,
+                                         ctypes.POINTER(ctypes.c_float)]
+        lib.spectre_mix_time.restype = ctypes.c_int
+        ver = lib.spectre_version()
+        if ver != ABI_VERSION:
+            raise NativeLibraryError(f"ABI mismatch: library {ver}, binding {ABI_VERSION}")
+        _lib = lib
+    return _lib
+
+
+_ERR = {1: ValueError, 2: NotImplementedError, 3: RuntimeError, 4: ValueError}
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().spectre_last_error().decode("utf-8", "replace")
+        raise _ERR.get(rc, RuntimeError)(f"{what}: {msg} (code {rc})")

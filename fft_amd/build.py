@@ -1,0 +1,79 @@
+"""Build libspectre_hip.so (gfx950) in-tree with hipcc.
+
+    python -m fft_amd.build [--force]
+
+The heavy register-resident kernels live in one translation unit per R so they compile in parallel.
+The shared object lands in fft_amd/lib/ (git-ignored, but it travels to the GPU box with the snapshot).
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+OBJDIR = os.path.join(LIBDIR, "obj")
+LIB = os.path.join(LIBDIR, "libspectre_hip.so")
+
+SOURCES = ["spectre_hip.hip", "regtile_r16.hip", "regtile_r32.hip", "regtile_r64.hip"]
+HEADERS = ["fft_regs.h", "kernel_regtile.h", "kernel_stockham.h", os.path.join("..", "..", "include", "spectre_hip.h")]
+
+# -fno-slp-vectorize: SLP packs the butterflies into v_pk_*_f32 (no faster than two scalar ops on gfx950)
+# plus register-pair shuffles, which pushes the 64-point kernel past 256 VGPRs into scratch.
+CXXFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-Wall",
+            "-Wno-unused-function"]
+
+
+def hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC or install ROCm under /opt/rocm)")
+
+
+def _newest(paths):
+    return max(os.path.getmtime(p) for p in paths)
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
+    return _newest(deps) > os.path.getmtime(LIB)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not needs_build():
+        return LIB
+    os.makedirs(OBJDIR, exist_ok=True)
+    cc = hipcc()
+
+    def compile_one(src: str) -> str:
+        obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
+        cmd = [cc, *CXXFLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+        if verbose and r.stderr.strip():
+            print(r.stderr, file=sys.stderr)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB + ".tmp", *objs]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    path = build(force="--force" in sys.argv, verbose=True)
+    print(path)

@@ -1,0 +1,388 @@
+// spectre_hip.hip — C ABI (include/spectre_hip.h), plan cache and kernel dispatch of libspectre_hip.so.
+//
+// Host side of the MI355X spectral mix: picks the register-resident R x R kernel when the shape and the
+// buffers allow it, the LDS Stockham / Bluestein kernel otherwise, and fails loudly for anything else.
+// No computation happens on the host beyond twiddle/chirp tables (double precision, once per plan).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/spectre_hip.h"
+#include "kernel_regtile.h"
+#include "kernel_stockham.h"
+
+namespace sfft {
+// defined in regtile_r16.hip / regtile_r32.hip / regtile_r64.hip
+template <> hipError_t launch_regtile<16>(const RegtileArgs&, bool, bool, bool, hipStream_t);
+template <> hipError_t launch_regtile<32>(const RegtileArgs&, bool, bool, bool, hipStream_t);
+template <> hipError_t launch_regtile<64>(const RegtileArgs&, bool, bool, bool, hipStream_t);
+}  // namespace sfft
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+constexpr size_t kLdsBytes = 160 * 1024;   // gfx950: 160 KiB per CU, one workgroup may take all of it
+
+struct Plan {
+  int device = 0;
+  int64_t n = 0;
+  // length-n table exp(-2 pi i m / n): regtile twiddle bases and smooth-n Stockham passes
+  float2* tw_n = nullptr;
+  // Stockham factorisation of n (empty if n has a prime factor > 13)
+  std::vector<int> radix_n;
+  // Bluestein
+  bool bluestein = false;
+  int64_t m = 0;
+  std::vector<int> radix_m;
+  float2* tw_m = nullptr;
+  float2* chirp = nullptr;
+  float2* bhat = nullptr;
+
+  ~Plan() {
+    // best effort: the owning device must be current for hipFree
+    int cur = 0;
+    if (hipGetDevice(&cur) == hipSuccess) {
+      (void)hipSetDevice(device);
+      if (tw_n) (void)hipFree(tw_n);
+      if (tw_m) (void)hipFree(tw_m);
+      if (chirp) (void)hipFree(chirp);
+      if (bhat) (void)hipFree(bhat);
+      (void)hipSetDevice(cur);
+    }
+  }
+};
+
+std::mutex g_mu;
+std::map<std::pair<int, int64_t>, std::unique_ptr<Plan>> g_plans;
+
+bool factorize(int64_t n, std::vector<int>& out) {
+  out.clear();
+  static const int radices[] = {8, 4, 2, 3, 5, 7, 11, 13};
+  for (int r : radices)
+    while (n % r == 0 && n > 1) { out.push_back(r); n /= r; }
+  return n == 1;
+}
+
+std::vector<float2> unit_table(int64_t n) {   // exp(-2 pi i m / n)
+  std::vector<float2> t((size_t)n);
+  const long double two_pi = 6.283185307179586476925286766559L;
+  for (int64_t m = 0; m < n; ++m) {
+    const long double a = two_pi * (long double)m / (long double)n;
+    t[(size_t)m] = make_float2((float)cosl(a), (float)(-sinl(a)));
+  }
+  return t;
+}
+
+hipError_t upload(const std::vector<float2>& h, float2** d) {
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(d), h.size() * sizeof(float2));
+  if (e != hipSuccess) return e;
+  return hipMemcpy(*d, h.data(), h.size() * sizeof(float2), hipMemcpyHostToDevice);
+}
+
+// naive-free host FFT is not needed: the Bluestein filter spectrum is computed by an O(M log M) radix-2
+// recursion in double precision (M is a power of two)
+void fft_pow2(std::vector<std::pair<double, double>>& a) {
+  const size_t n = a.size();
+  for (size_t i = 1, j = 0; i < n; ++i) {
+    size_t bit = n >> 1;
+    for (; j & bit; bit >>= 1) j ^= bit;
+    j ^= bit;
+    if (i < j) std::swap(a[i], a[j]);
+  }
+  for (size_t len = 2; len <= n; len <<= 1) {
+    for (size_t i = 0; i < n; i += len) {
+      for (size_t k = 0; k < len / 2; ++k) {
+        const double ang = -2.0 * M_PI * (double)k / (double)len;
+        const double wr = cos(ang), wi = sin(ang);
+        auto& u = a[i + k];
+        auto& v = a[i + k + len / 2];
+        const double tr = v.first * wr - v.second * wi, ti = v.first * wi + v.second * wr;
+        v = {u.first - tr, u.second - ti};
+        u = {u.first + tr, u.second + ti};
+      }
+    }
+  }
+}
+
+int build_plan(int device, int64_t n, Plan** out) {
+  auto plan = std::make_unique<Plan>();
+  plan->device = device;
+  plan->n = n;
+  hipError_t e = upload(unit_table(n), &plan->tw_n);
+  if (e != hipSuccess) return fail(SPECTRE_E_HIP, "plan(n_fft=%lld): %s", (long long)n, hipGetErrorString(e));
+  if (!factorize(n, plan->radix_n)) {
+    plan->radix_n.clear();
+    plan->bluestein = true;
+    int64_t m = 1;
+    while (m < 2 * n - 1) m <<= 1;
+    plan->m = m;
+    factorize(m, plan->radix_m);
+    if ((e = upload(unit_table(m), &plan->tw_m)) != hipSuccess)
+      return fail(SPECTRE_E_HIP, "plan(bluestein M=%lld): %s", (long long)m, hipGetErrorString(e));
+    // chirp w[j] = exp(-i pi j^2 / n), angle reduced exactly through j^2 mod 2n
+    std::vector<float2> w((size_t)n);
+    std::vector<std::pair<double, double>> bt((size_t)m, {0.0, 0.0});
+    for (int64_t j = 0; j < n; ++j) {
+      const int64_t q = (j * j) % (2 * n);
+      const double ang = M_PI * (double)q / (double)n;
+      w[(size_t)j] = make_float2((float)cos(ang), (float)(-sin(ang)));
+      bt[(size_t)j] = {cos(ang), sin(ang)};                 // conj(w[j])
+      if (j > 0) bt[(size_t)(m - j)] = {cos(ang), sin(ang)};
+    }
+    fft_pow2(bt);
+    std::vector<float2> bh((size_t)m);
+    for (int64_t j = 0; j < m; ++j) bh[(size_t)j] = make_float2((float)bt[(size_t)j].first, (float)bt[(size_t)j].second);
+    if ((e = upload(w, &plan->chirp)) != hipSuccess || (e = upload(bh, &plan->bhat)) != hipSuccess)
+      return fail(SPECTRE_E_HIP, "plan(bluestein tables): %s", hipGetErrorString(e));
+  }
+  *out = plan.get();
+  g_plans[{device, n}] = std::move(plan);
+  return SPECTRE_OK;
+}
+
+int get_plan(int device, int64_t n, Plan** out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_plans.find({device, n});
+  if (it != g_plans.end()) { *out = it->second.get(); return SPECTRE_OK; }
+  return build_plan(device, n, out);
+}
+
+struct Choice {
+  bool regtile = false;
+  int R = 0;
+  bool general = false;
+  // stockham
+  int P = 0, S = 0, solo = 0;
+  const char* why_not_regtile = "";
+};
+
+int validate(const SpectreMixArgs* a) {
+  if (!a) return fail(SPECTRE_E_INVALID, "args is NULL");
+  if (!a->v || !a->gate || !a->out) return fail(SPECTRE_E_INVALID, "v, gate and out must be non-NULL device pointers");
+  if (a->B < 0 || a->N_in < 1 || a->n_fft < 1 || a->D < 1 || a->G_tot < 1)
+    return fail(SPECTRE_E_INVALID, "bad sizes B=%lld N_in=%lld n_fft=%lld D=%lld G_tot=%lld", (long long)a->B,
+                (long long)a->N_in, (long long)a->n_fft, (long long)a->D, (long long)a->G_tot);
+  if (a->D % a->G_tot) return fail(SPECTRE_E_INVALID, "D=%lld not divisible by G_tot=%lld (spectre.py:422)", (long long)a->D, (long long)a->G_tot);
+  if ((a->in_dtype != SPECTRE_F32 && a->in_dtype != SPECTRE_BF16) || (a->out_dtype != SPECTRE_F32 && a->out_dtype != SPECTRE_BF16))
+    return fail(SPECTRE_E_UNSUPPORTED, "dtype must be SPECTRE_F32 or SPECTRE_BF16");
+  if (a->algo < SPECTRE_ALGO_AUTO || a->algo > SPECTRE_ALGO_REGTILE) return fail(SPECTRE_E_INVALID, "bad algo %d", a->algo);
+  const int64_t n_out = a->N_in < a->n_fft ? a->N_in : a->n_fft;
+  if (a->v_sn < a->D || a->out_sn < a->D || a->v_sb < 0 || a->out_sb < 0)
+    return fail(SPECTRE_E_INVALID, "row strides must be >= D and batch strides >= 0");
+  (void)n_out;
+  if (a->B > 0 && (a->B * a->D > (int64_t)1 << 40)) return fail(SPECTRE_E_INVALID, "B*D too large");
+  return SPECTRE_OK;
+}
+
+int choose(const SpectreMixArgs* a, const Plan* plan, Choice* c) {
+  const int64_t n = a->n_fft, D = a->D, d_g = D / a->G_tot;
+  const int es_in = a->in_dtype == SPECTRE_BF16 ? 2 : 4, es_out = a->out_dtype == SPECTRE_BF16 ? 2 : 4;
+  int R = 0;
+  if (n == 256) R = 16; else if (n == 1024) R = 32; else if (n == 4096) R = 64;
+  const char* why = "";
+  if (!R) why = "n_fft is not 256/1024/4096";
+  else if (D % 16) why = "D % 16 != 0";
+  else if (d_g % 2) why = "odd group width";
+  else if ((reinterpret_cast<uintptr_t>(a->v) % (2 * es_in)) || (a->v_sn % 2) || (a->v_sb % 2)) why = "v not pair-aligned";
+  else if ((reinterpret_cast<uintptr_t>(a->out) % (2 * es_out)) || (a->out_sn % 2) || (a->out_sb % 2)) why = "out not pair-aligned";
+  else if (a->mem && (reinterpret_cast<uintptr_t>(a->mem) % 16)) why = "mem not 16-byte aligned";
+  else if (reinterpret_cast<uintptr_t>(a->gate) % 8) why = "gate not 8-byte aligned";
+  else if (a->v_sn * 63 * 4 + 64 >= ((int64_t)1 << 31) || a->out_sn * 63 * 4 + 64 >= ((int64_t)1 << 31)) why = "row stride too large";
+  else if (a->B * (D / 16) >= ((int64_t)1 << 31)) why = "too many tiles";
+  c->why_not_regtile = why;
+  const bool can_regtile = why[0] == 0;
+  if (a->algo == SPECTRE_ALGO_REGTILE && !can_regtile)
+    return fail(why[0] == 'v' || why[0] == 'o' || why[0] == 'm' || why[0] == 'g' ? SPECTRE_E_ALIGN : SPECTRE_E_UNSUPPORTED,
+                "register-tile kernel not applicable: %s", why);
+  if (can_regtile && a->algo != SPECTRE_ALGO_STOCKHAM) {
+    c->regtile = true;
+    c->R = R;
+    c->general = (a->mem != nullptr) || (a->N_in < a->n_fft);
+    return SPECTRE_OK;
+  }
+  // Stockham / Bluestein in LDS
+  const int64_t L = plan->bluestein ? plan->m : n;
+  c->solo = (d_g % 2) ? 1 : 0;
+  c->S = (int)(c->solo ? D : D / 2);
+  int64_t P = (int64_t)kLdsBytes / (16 * L);
+  if (P > 8) P = 8;
+  if (P > c->S) P = c->S;
+  if (P < 1)
+    return fail(SPECTRE_E_UNSUPPORTED,
+                "n_fft=%lld needs %lld bytes of LDS per sequence (transform length %lld%s); the CU has %zu",
+                (long long)n, (long long)(16 * L), (long long)L, plan->bluestein ? ", Bluestein" : "", kLdsBytes);
+  c->P = (int)P;
+  const int64_t groups = (c->S + P - 1) / P;
+  if (a->B * groups >= ((int64_t)1 << 31)) return fail(SPECTRE_E_UNSUPPORTED, "grid too large");
+  return SPECTRE_OK;
+}
+
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+    if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
+  }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+int launch(const SpectreMixArgs* a, const Plan* plan, const Choice& c) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(a->stream);
+  if (a->B == 0) return SPECTRE_OK;
+  hipError_t e;
+  if (c.regtile) {
+    sfft::RegtileArgs k{};
+    k.v = a->v; k.gate = reinterpret_cast<const float2*>(a->gate); k.mem = reinterpret_cast<const float*>(a->mem);
+    k.out = a->out; k.tw = plan->tw_n;
+    k.B = (int)a->B; k.N_in = (int)std::min<int64_t>(a->N_in, (int64_t)1 << 30); k.D = (int)a->D; k.G = (int)a->G_tot;
+    k.d_g = (int)(a->D / a->G_tot); k.F = (int)(a->n_fft / 2 + 1);
+    k.tiles_per_row = (int)(a->D / 16); k.n_tiles = (int)(a->B * (a->D / 16));
+    k.v_sb = a->v_sb; k.v_sn = a->v_sn; k.out_sb = a->out_sb; k.out_sn = a->out_sn;
+    const bool ib = a->in_dtype == SPECTRE_BF16, ob = a->out_dtype == SPECTRE_BF16;
+    if (c.R == 16) e = sfft::launch_regtile<16>(k, ib, ob, c.general, stream);
+    else if (c.R == 32) e = sfft::launch_regtile<32>(k, ib, ob, c.general, stream);
+    else e = sfft::launch_regtile<64>(k, ib, ob, c.general, stream);
+  } else {
+    sfft::StockhamArgs k{};
+    k.v = a->v; k.gate = reinterpret_cast<const float2*>(a->gate); k.mem = reinterpret_cast<const float*>(a->mem); k.out = a->out;
+    k.B = (int)a->B; k.N_in = (int)std::min<int64_t>(a->N_in, (int64_t)1 << 30); k.N = (int)a->n_fft; k.D = (int)a->D;
+    k.G = (int)a->G_tot; k.d_g = (int)(a->D / a->G_tot); k.F = (int)(a->n_fft / 2 + 1);
+    k.P = c.P; k.S = c.S; k.solo = c.solo; k.groups_per_batch = (c.S + c.P - 1) / c.P;
+    k.in_bf16 = a->in_dtype == SPECTRE_BF16; k.out_bf16 = a->out_dtype == SPECTRE_BF16;
+    k.v_sb = a->v_sb; k.v_sn = a->v_sn; k.out_sb = a->out_sb; k.out_sn = a->out_sn;
+    const std::vector<int>& rad = plan->bluestein ? plan->radix_m : plan->radix_n;
+    k.L = (int)(plan->bluestein ? plan->m : a->n_fft);
+    k.n_pass = (int)rad.size();
+    if (k.n_pass > sfft::kMaxPasses) return fail(SPECTRE_E_UNSUPPORTED, "too many Stockham passes (%d)", k.n_pass);
+    for (int i = 0; i < k.n_pass; ++i) k.radix[i] = rad[(size_t)i];
+    k.tw = plan->bluestein ? plan->tw_m : plan->tw_n;
+    k.bluestein = plan->bluestein ? 1 : 0;
+    k.chirp = plan->chirp; k.bhat = plan->bhat;
+    const size_t lds = (size_t)2 * k.L * k.P * sizeof(float2);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(sfft::spectre_mix_stockham),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(sfft::spectre_mix_stockham, dim3((unsigned)(a->B * k.groups_per_batch)), dim3(sfft::kStockhamThreads),
+                         lds, stream, k);
+      e = hipGetLastError();
+    }
+  }
+  if (e != hipSuccess) return fail(SPECTRE_E_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+  return SPECTRE_OK;
+}
+
+int prepare(const SpectreMixArgs* a, Plan** plan, Choice* c) {
+  int rc = validate(a);
+  if (rc) return rc;
+  rc = get_plan(a->device, a->n_fft, plan);
+  if (rc) return rc;
+  return choose(a, *plan, c);
+}
+
+}  // namespace
+
+extern "C" {
+
+int spectre_version(void) { return SPECTRE_ABI_VERSION; }
+
+const char* spectre_last_error(void) { return g_err.c_str(); }
+
+int spectre_plan_create(int device, int64_t n_fft) {
+  if (n_fft < 1) return fail(SPECTRE_E_INVALID, "n_fft must be >= 1");
+  DeviceGuard g(device);
+  if (!g.ok) return fail(SPECTRE_E_HIP, "cannot select device %d", device);
+  Plan* p = nullptr;
+  return get_plan(device, n_fft, &p);
+}
+
+int spectre_plan_destroy(int device, int64_t n_fft) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_plans.find({device, n_fft});
+  if (it == g_plans.end()) return fail(SPECTRE_E_INVALID, "no plan for device %d n_fft %lld", device, (long long)n_fft);
+  g_plans.erase(it);
+  return SPECTRE_OK;
+}
+
+int spectre_mix_fwd(const SpectreMixArgs* a) {
+  if (!a) return fail(SPECTRE_E_INVALID, "args is NULL");
+  DeviceGuard g(a->device);
+  if (!g.ok) return fail(SPECTRE_E_HIP, "cannot select device %d", a->device);
+  Plan* plan = nullptr;
+  Choice c;
+  int rc = prepare(a, &plan, &c);
+  if (rc) return rc;
+  return launch(a, plan, c);
+}
+
+int spectre_mix_describe(const SpectreMixArgs* a, char* buf, size_t cap) {
+  if (!a || !buf || cap == 0) return fail(SPECTRE_E_INVALID, "bad describe arguments");
+  DeviceGuard g(a->device);
+  if (!g.ok) return fail(SPECTRE_E_HIP, "cannot select device %d", a->device);
+  Plan* plan = nullptr;
+  Choice c;
+  int rc = prepare(a, &plan, &c);
+  if (rc) return rc;
+  const char* in = a->in_dtype == SPECTRE_BF16 ? "bf16" : "f32";
+  const char* out = a->out_dtype == SPECTRE_BF16 ? "bf16" : "f32";
+  if (c.regtile) {
+    snprintf(buf, cap, "regtile R=%d in=%s out=%s general=%d tiles=%lld", c.R, in, out, c.general ? 1 : 0,
+             (long long)(a->B * (a->D / 16)));
+  } else {
+    std::string r;
+    const std::vector<int>& rad = plan->bluestein ? plan->radix_m : plan->radix_n;
+    for (size_t i = 0; i < rad.size(); ++i) r += (i ? "," : "") + std::to_string(rad[i]);
+    snprintf(buf, cap, "stockham P=%d solo=%d L=%lld radices=%s bluestein=%d in=%s out=%s (regtile: %s)", c.P, c.solo,
+             (long long)(plan->bluestein ? plan->m : a->n_fft), r.c_str(), plan->bluestein ? 1 : 0, in, out,
+             c.why_not_regtile[0] ? c.why_not_regtile : "not selected");
+  }
+  return SPECTRE_OK;
+}
+
+int spectre_mix_time(const SpectreMixArgs* a, int warmup, int iters, float* ms_per_launch) {
+  if (!a || !ms_per_launch || iters < 1 || warmup < 0) return fail(SPECTRE_E_INVALID, "bad timing arguments");
+  DeviceGuard g(a->device);
+  if (!g.ok) return fail(SPECTRE_E_HIP, "cannot select device %d", a->device);
+  Plan* plan = nullptr;
+  Choice c;
+  int rc = prepare(a, &plan, &c);
+  if (rc) return rc;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(a->stream);
+  for (int i = 0; i < warmup; ++i)
+    if ((rc = launch(a, plan, c))) return rc;
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(SPECTRE_E_HIP, "hipEventCreate failed");
+  hipError_t e = hipEventRecord(e0, stream);
+  for (int i = 0; i < iters && e == hipSuccess; ++i)
+    if ((rc = launch(a, plan, c))) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
+  if (e == hipSuccess) e = hipEventRecord(e1, stream);
+  if (e == hipSuccess) e = hipEventSynchronize(e1);
+  float ms = 0.f;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (e != hipSuccess) return fail(SPECTRE_E_HIP, "timing failed: %s", hipGetErrorString(e));
+  *ms_per_launch = ms / (float)iters;
+  return SPECTRE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,119 @@
+"""spectral_mix — the fused rfft -> gate -> (+memory) -> irfft forward on MI355X.
+
+Python face of the C ABI in include/spectre_hip.h; replaces these statements of the reference layer
+(`/root/reference/spectre.py`):
+
+    V_fft  = torch.fft.rfft(V, n=n_fft, dim=1)                                   # :506
+    mixed  = gate.permute(0,2,1).repeat_interleave(d_g, -1) * V_fft              # :542-545
+    mixed  = mixed + memory_fft.unsqueeze(0)                                     # :548-549 (optional)
+    out    = torch.fft.irfft(mixed, n=n_fft, dim=1)[:, :N]                       # :551-553
+
+PyTorch is used for device memory and streams only.  There is no eager/CPU fallback: CPU tensors,
+unsupported dtypes or a missing shared library raise.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _native
+
+_DT = {torch.float32: _native.F32, torch.bfloat16: _native.BF16}
+
+
+def _args(V, gate, mem, n_fft, out, algo):
+    if V.dim() != 3:
+        raise ValueError(f"V must be (B, N, D), got {tuple(V.shape)}")
+    if not V.is_cuda:
+        raise RuntimeError("spectral_mix runs on a HIP device only (no CPU path): move V to cuda")
+    if V.dtype not in _DT:
+        raise TypeError(f"V dtype {V.dtype} unsupported (float32 or bfloat16)")
+    B, N, D = V.shape
+    F = n_fft // 2 + 1
+    if gate.dim() != 3 or gate.shape[0] != B or gate.shape[2] != F:
+        raise ValueError(f"gate must be (B={B}, G, F={F}) complex64, got {tuple(gate.shape)}")
+    if gate.dtype != torch.complex64:
+        raise TypeError(f"gate dtype {gate.dtype} unsupported (complex64)")
+    G = gate.shape[1]
+    if D % G:
+        raise ValueError(f"D={D} not divisible by the number of gate channels G={G}")
+    if gate.device != V.device or (mem is not None and mem.device != V.device):
+        raise RuntimeError("V, gate and memory_fft must be on the same device")
+    if V.stride(2) != 1:
+        V = V.contiguous()
+    gate = gate.contiguous()
+    if mem is not None:
+        if mem.dtype != torch.complex64 or tuple(mem.shape) != (F, D):
+            raise ValueError(f"memory_fft must be (F={F}, D={D}) complex64, got {tuple(mem.shape)} {mem.dtype}")
+        mem = mem.contiguous()
+    a = _native.SpectreMixArgs()
+    a.v = V.data_ptr()
+    a.gate = gate.data_ptr()
+    a.mem = mem.data_ptr() if mem is not None else None
+    a.out = out.data_ptr()
+    a.B, a.N_in, a.n_fft, a.D, a.G_tot = B, N, n_fft, D, G
+    a.v_sb, a.v_sn = V.stride(0), V.stride(1)
+    a.out_sb, a.out_sn = out.stride(0), out.stride(1)
+    a.in_dtype, a.out_dtype = _DT[V.dtype], _DT[out.dtype]
+    a.algo = _native.ALGO[algo]
+    a.device = V.device.index if V.device.index is not None else torch.cuda.current_device()
+    a.stream = torch.cuda.current_stream(V.device).cuda_stream
+    return a, (V, gate, mem, out)   # keep the (possibly re-laid-out) tensors alive until the launch is enqueued
+
+
+def _empty_out(V, n_fft, out_dtype):
+    B, N, D = V.shape
+    return torch.empty((B, min(N, n_fft), D), dtype=out_dtype or V.dtype, device=V.device)
+
+
+def spectral_mix(V: torch.Tensor, gate: torch.Tensor, memory_fft: Optional[torch.Tensor] = None,
+                 n_fft: Optional[int] = None, *, out_dtype: Optional[torch.dtype] = None,
+                 out: Optional[torch.Tensor] = None, algo: str = "auto") -> torch.Tensor:
+    """out[b, n, c] = irfft(gate[b, c // d_g, :] * rfft(V[b, :, c], n_fft) + memory_fft[:, c], n_fft)[n].
+
+    V (B, N, D) float32|bfloat16 (last dim unit stride; channel-chunk views with a larger row stride are
+    fine), gate (B, G, n_fft//2+1) complex64, memory_fft (n_fft//2+1, D) complex64 or None.
+    Returns (B, min(N, n_fft), D) in `out_dtype` (default: V.dtype).  Arithmetic is fp32.
+    Asynchronous on the current stream.
+    """
+    lib = _native.load()
+    if n_fft is None:
+        n_fft = V.shape[1]
+    if out is None:
+        out = _empty_out(V, n_fft, out_dtype)
+    elif out.stride(2) != 1 or tuple(out.shape) != (V.shape[0], min(V.shape[1], n_fft), V.shape[2]):
+        raise ValueError("out has the wrong shape or a non-unit channel stride")
+    a, keep = _args(V, gate, memory_fft, n_fft, out, algo)
+    _native.check(lib.spectre_mix_fwd(ctypes.byref(a)), "spectre_mix_fwd")
+    del keep
+    return out
+
+
+def describe(V, gate, memory_fft=None, n_fft=None, *, out_dtype=None, algo="auto") -> str:
+    """Name of the kernel `spectral_mix` would launch for these arguments."""
+    lib = _native.load()
+    if n_fft is None:
+        n_fft = V.shape[1]
+    out = _empty_out(V, n_fft, out_dtype)
+    a, keep = _args(V, gate, memory_fft, n_fft, out, algo)
+    buf = ctypes.create_string_buffer(512)
+    _native.check(lib.spectre_mix_describe(ctypes.byref(a), buf, 512), "spectre_mix_describe")
+    del keep
+    return buf.value.decode()
+
+
+def time_kernel(V, gate, memory_fft=None, n_fft=None, *, out_dtype=None, out=None, algo="auto",
+                warmup: int = 3, iters: int = 10) -> float:
+    """Average milliseconds per launch, measured with HIP events on the launch stream (bench.py)."""
+    lib = _native.load()
+    if n_fft is None:
+        n_fft = V.shape[1]
+    if out is None:
+        out = _empty_out(V, n_fft, out_dtype)
+    a, keep = _args(V, gate, memory_fft, n_fft, out, algo)
+    ms = ctypes.c_float(0.0)
+    _native.check(lib.spectre_mix_time(ctypes.byref(a), warmup, iters, ctypes.byref(ms)), "spectre_mix_time")
+    del keep
+    return float(ms.value)

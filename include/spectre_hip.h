@@ -1,0 +1,101 @@
+/* spectre_hip.h — C ABI of libspectre_hip.so: the MI355X (gfx950) spectral-mix forward.
+ *
+ * The reference has no FFI/plugin layer for this path: the hot path is four inline statements of
+ * `SpectreHead.forward` calling ATen (/root/reference/spectre.py:506, :542-545, :548-549, :551-553).
+ * This header is the seam a maintainer binds instead of those statements (ctypes stub: INTEGRATION.md):
+ *
+ *     out[b, n, c] = irfft( gate[b, c / d_g, :] * rfft(v[b, :, c], n_fft) + mem[:, c], n_fft )[n],
+ *                    n < min(N_in, n_fft)
+ *
+ * Contract
+ *  - plain pointers and sizes only; all data pointers are DEVICE pointers on `device`
+ *  - the library never allocates, frees or retains user buffers; it owns only its per-(device, n_fft)
+ *    plans (twiddle tables) — cached internally behind a mutex, or created explicitly below
+ *  - launches are asynchronous on the caller's stream, no device synchronisation, re-entrant across
+ *    streams and devices
+ *  - every entry point returns 0 on success and a non-zero SPECTRE_E_* code on failure, with a message
+ *    retrievable (per thread) through spectre_last_error(); unsupported shapes FAIL — there is no
+ *    fallback to another backend and no host computation.
+ */
+#ifndef SPECTRE_HIP_H
+#define SPECTRE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPECTRE_ABI_VERSION 1
+
+enum {
+  SPECTRE_OK = 0,
+  SPECTRE_E_INVALID = 1,     /* bad argument (null pointer, negative size, D % G != 0, ...)          */
+  SPECTRE_E_UNSUPPORTED = 2, /* shape/dtype has no kernel (e.g. n_fft too large for on-chip memory)   */
+  SPECTRE_E_HIP = 3,         /* a HIP runtime call failed                                             */
+  SPECTRE_E_ALIGN = 4        /* forced fast path on buffers that do not meet its alignment rules      */
+};
+
+enum { SPECTRE_F32 = 0, SPECTRE_BF16 = 1 }; /* storage dtype of v / out; arithmetic is always fp32 */
+
+enum {
+  SPECTRE_ALGO_AUTO = 0,    /* register-resident kernel when the shape allows, else LDS Stockham     */
+  SPECTRE_ALGO_STOCKHAM = 1,/* force the general mixed-radix LDS Stockham (+ Bluestein) kernel        */
+  SPECTRE_ALGO_REGTILE = 2  /* force the register-resident R x R kernel; fails if not applicable      */
+};
+
+/* Replaces spectre.py:506 + :542-553 (one call = those statements for a whole (B, N, D) tensor).
+ *   v     (B, N_in, D)      f32|bf16  last dim unit stride; element strides v_sb, v_sn
+ *                                     (spectre.py:703 hands the layer channel-chunk views, so D-contiguous
+ *                                      rows with a larger row stride must work)
+ *   gate  (B, G_tot, F)     complex64 (re, im) interleaved, contiguous, F = n_fft/2 + 1
+ *                                     — the tensor spectre.py:542 consumes (after modReLU / pos_phase)
+ *   mem   (F, D)            complex64 contiguous, or NULL (spectre.py:548-549)
+ *   out   (B, N_out, D)     f32|bf16  N_out = min(N_in, n_fft) (spectre.py:553), strides out_sb, out_sn
+ * G_tot gate channels cover D (= G for one head, = H*G for a fused multi-head call); D % G_tot == 0.
+ */
+typedef struct SpectreMixArgs {
+  const void* v;
+  const void* gate;
+  const void* mem;   /* nullable */
+  void* out;
+  int64_t B, N_in, n_fft, D, G_tot;
+  int64_t v_sb, v_sn;     /* element strides of v   */
+  int64_t out_sb, out_sn; /* element strides of out */
+  int32_t in_dtype;       /* SPECTRE_F32 | SPECTRE_BF16 */
+  int32_t out_dtype;
+  int32_t algo;           /* SPECTRE_ALGO_*  */
+  int32_t device;         /* HIP device ordinal the pointers live on */
+  void* stream;           /* hipStream_t (0 = default stream) */
+} SpectreMixArgs;
+
+/* ABI version of the loaded library (== SPECTRE_ABI_VERSION of the header it was built from). */
+int spectre_version(void);
+
+/* Message of the last failure on the calling thread ("" if none). Never NULL. */
+const char* spectre_last_error(void);
+
+/* Enqueue the spectral mix on args->stream. */
+int spectre_mix_fwd(const SpectreMixArgs* args);
+
+/* Which kernel spectre_mix_fwd would run for these arguments, e.g.
+ * "regtile R=64 in=f32 out=f32 mem=0 full=1" or "stockham P=2 radices=16,16,16 bluestein=0".
+ * Writes a NUL-terminated string of at most `cap` bytes. */
+int spectre_mix_describe(const SpectreMixArgs* args, char* buf, size_t cap);
+
+/* Plans: twiddle tables (and Bluestein chirps) for one (device, n_fft).  spectre_mix_fwd creates and
+ * caches them on demand; explicit creation lets a caller pay the one-time upload outside a timed or
+ * graph-captured region.  Destroying a cached plan is allowed only when no launch using it is in flight. */
+int spectre_plan_create(int device, int64_t n_fft);
+int spectre_plan_destroy(int device, int64_t n_fft);
+
+/* Measurement helper used by bench.py: runs `warmup` untimed + `iters` timed launches of the same
+ * arguments on args->stream, bracketed by HIP events recorded on that stream, and returns the average
+ * per-launch time in milliseconds.  (Synchronises the stream; not part of the data path.) */
+int spectre_mix_time(const SpectreMixArgs* args, int warmup, int iters, float* ms_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPECTRE_HIP_H */
