@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py — spectral-mix tokens/s at (B=256, N=4096, D=768) per GPU, batch-sharded over N GPUs.
+
+    python bench.py [--gpus N --steps K --warmup W] [--io f32|bf16] [--shape B,N,D] [--groups G]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path (fused rfft -> gate -> irfft, spectre.py:506,:542-553) over one
+synthetic batch already resident in HBM.  Weak scaling: every rank owns B=256 batch elements (the 8-GPU
+configuration is BASELINE.json's B=2048 batch shard); there is no collective in the data path, only the
+barrier + MAX-over-ranks timing reduction the contract asks for.
+
+Prints ONE JSON line on rank 0 with
+  value        whole-job tokens/s (B_total * N * K / wall time of the K timed steps, max over ranks)
+  roofline     dominant kernel vs the HBM roofline: algorithmic bytes per launch / average launch duration,
+               the duration measured live with HIP events on the launch stream over the timed region
+  cpu_baseline the oracle's torch.fft restatement of the same statements timed on this box's host cores
+               on a bounded sample (rank 0, single-GPU runs only)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); a plain copy reaches ~5.4 TB/s here
+
+
+def algorithmic_bytes(B, N_in, n_fft, D, G, es_in, es_out, mem=False):
+    """one read of V, one write of out, the gate once (+ memory_fft once)."""
+    F = n_fft // 2 + 1
+    n_out = min(N_in, n_fft)
+    return B * N_in * D * es_in + B * n_out * D * es_out + B * G * F * 8 + (F * D * 8 if mem else 0)
+
+
+def cpu_baseline(N, D, G, seconds_budget=20.0):
+    """torch.fft on the host cores: the reference's own statements (oracle.spectral_mix_torch), bounded sample."""
+    import torch
+    from oracle.spectral_mix_oracle import spectral_mix_torch
+    cores = os.cpu_count() or 1
+    try:
+        torch.set_num_threads(cores)
+    except Exception:
+        pass
+    Bc = 32
+    g = torch.Generator().manual_seed(0)
+    V = torch.randn(Bc, N, D, generator=g)
+    F = N // 2 + 1
+    gate = (torch.complex(torch.randn(Bc, G, F, generator=g), torch.randn(Bc, G, F, generator=g)) * 0.3)
+    spectral_mix_torch(V, gate, None, N)                     # warm-up (MKL plan, allocator)
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        spectral_mix_torch(V, gate, None, N)
+        reps += 1
+        el = time.perf_counter() - t0
+        if reps >= 3 and (el > seconds_budget * 0.5 or reps >= 20):
+            break
+        if el > seconds_budget:
+            break
+    return {"value": Bc * N * reps / el, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle.spectral_mix_torch (torch.fft restatement of spectre.py:506,:542-553), fp32, "
+                      f"B={Bc} N={N} D={D} G={G}, {reps} reps in {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--io", choices=["f32", "bf16"], default="f32",
+                    help="storage dtype of V and out (arithmetic is always fp32; the reference is fp32-only)")
+    ap.add_argument("--shape", default="256,4096,768", help="per-GPU B,N,D")
+    ap.add_argument("--groups", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from fft_amd import describe, spectral_mix
+    from fft_amd import _native
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    dev = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(dev)
+    _native.load()                                            # fail loudly if the HIP library is missing
+
+    B, N, D = (int(x) for x in a.shape.split(","))
+    G = a.groups
+    dt = torch.float32 if a.io == "f32" else torch.bfloat16
+    F = N // 2 + 1
+    # synthetic inputs, SURVEY.md §8(d): V ~ N(0,1); gate ~ 0.3 CN(0,1) with ~18 % exact zeros (modReLU)
+    torch.manual_seed(rank)
+    V = torch.randn(B, N, D, device=dev).to(dt)
+    gate = torch.randn(B, G, F, dtype=torch.complex64, device=dev) * 0.3
+    gate = gate * (torch.rand(B, G, F, device=dev) >= 0.18)
+    out = torch.empty_like(V)
+    kernel = describe(V, gate, None, N)
+
+    def step():
+        spectral_mix(V, gate, None, N, out=out)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()                                              # same stream the kernels are launched on
+    for _ in range(a.steps):
+        step()
+    ev1.record()
+    barrier()
+    wall = time.perf_counter() - t0
+    kern_ms = ev0.elapsed_time(ev1) / a.steps                 # average launch duration over the timed region
+    tw = torch.tensor([wall, kern_ms], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+    wall, kern_ms = float(tw[0]), float(tw[1])
+
+    if rank == 0:
+        es = V.element_size()
+        alg = algorithmic_bytes(B, N, N, D, G, es, es)
+        achieved = alg / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")  # written by tools/collect_pmc.py on the GPU box
+        if os.path.exists(pmc):
+            try:
+                rec = json.load(open(pmc))
+                if rec.get("io") == a.io and rec.get("shape") == [B, N, D]:
+                    traffic = rec.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "spectral-mix tokens/sec at (B=256, N=4096, D=768) per GPU, batch-sharded",
+            "value": world * B * N * a.steps / wall,
+            "unit": "tokens/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": wall / a.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"spectral-mix forward (rfft->gate->irfft), per-GPU (B={B}, N={N}, D={D}), G={G}, "
+                                   f"n_fft={N}, {a.io} in/out, fp32 arithmetic; global batch {world * B}",
+                       "io_dtype": a.io, "global_batch": world * B, "seq_len": N, "d_model": D,
+                       "parallelism": f"batch-shard x{world} (no collective)", "kernel": kernel},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg, "kernel_ms": kern_ms},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(N, D, G)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -177,6 +177,8 @@ struct Choice {
 
 int validate(const SpectreMixArgs* a) {
   if (!a) return fail(SPECTRE_E_INVALID, "args is NULL");
+  if (a->B == 0 && a->N_in >= 1 && a->n_fft >= 1 && a->D >= 1 && a->G_tot >= 1 && a->D % a->G_tot == 0)
+    return SPECTRE_OK;   // empty batch: nothing to read or write, pointers may be NULL
   if (!a->v || !a->gate || !a->out) return fail(SPECTRE_E_INVALID, "v, gate and out must be non-NULL device pointers");
   if (a->B < 0 || a->N_in < 1 || a->n_fft < 1 || a->D < 1 || a->G_tot < 1)
     return fail(SPECTRE_E_INVALID, "bad sizes B=%lld N_in=%lld n_fft=%lld D=%lld G_tot=%lld", (long long)a->B,

@@ -1,0 +1,195 @@
+"""SpectreHead — drop-in for the reference layer with the spectral mix running as one HIP kernel.
+
+Mirrors the `nn.Module` surface of `SpectreHead` in `/root/reference/spectre.py:400-557` (constructor
+keywords, attribute / parameter / buffer names, `forward` signature and return convention), so a reference
+`state_dict()` loads unchanged and callers (`SpectreMultiHead.forward`, spectre.py:712) need no edits.
+
+What runs where
+---------------
+* projections `W_q`, `W_v` (spectre.py:502-503) and the gate producer (pool -> LayerNorm -> MLP -> cubic
+  resample -> modReLU -> positional phase, spectre.py:511-536): stock PyTorch-ROCm ops — O(B*G*F) work,
+  <1 % of the layer's memory traffic.  Exposed as `spectral_gate()`.
+* rfft -> gate multiply -> (+memory) -> irfft -> slice (spectre.py:506, :542-553): `fft_amd.functional.
+  spectral_mix`, one fused gfx950 kernel through the C ABI.  HIP device only; CPU tensors raise.
+
+Forward only for now: the spectral mix is wrapped in an autograd.Function whose backward raises
+(SURVEY.md section 8(f), row N1).
+"""
+from __future__ import annotations
+
+import math
+import warnings
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .functional import spectral_mix
+
+try:  # optional, exactly as the reference treats it (spectre.py:10-14)
+    import torch_dct as _dct
+except ImportError:  # pragma: no cover - not installed in the build image
+    _dct = None
+
+
+# --------------------------------------------------------------------------------------------------
+# gate-producer pieces (host logic, plain torch)
+# --------------------------------------------------------------------------------------------------
+def resample_complex(anchors: torch.Tensor, size: int, mode: str = "cubic") -> torch.Tensor:
+    """(B, G, K) complex anchors -> (B, G, size) complex, endpoints aligned.
+
+    "cubic" follows spectre.py:38-61: the real/imag planes form a 2-channel image of height 1 that
+    `grid_sample(mode='bicubic', padding_mode='border', align_corners=True)` samples on an even grid.
+    "linear"/"nearest" follow spectre.py:75-92 (`F.interpolate`).
+    """
+    B, G, K = anchors.shape
+    if mode == "cubic":
+        planes = torch.stack((anchors.real, anchors.imag), dim=1).reshape(B * G, 2, 1, K)
+        xs = torch.linspace(-1, 1, size, device=anchors.device)
+        grid = torch.stack((xs, torch.zeros_like(xs)), dim=-1).view(1, 1, size, 2).expand(B * G, 1, size, 2)
+        up = F.grid_sample(planes, grid, mode="bicubic", padding_mode="border", align_corners=True)
+        return torch.complex(up[:, 0, 0, :], up[:, 1, 0, :]).view(B, G, size)
+    if mode not in ("linear", "nearest"):
+        raise AssertionError(f"Unsupported interpolation mode: {mode}")
+    kw = {"align_corners": True} if mode == "linear" else {}
+    re = F.interpolate(anchors.real.reshape(B * G, 1, K), size=size, mode=mode, **kw)
+    im = F.interpolate(anchors.imag.reshape(B * G, 1, K), size=size, mode=mode, **kw)
+    return torch.complex(re.squeeze(1), im.squeeze(1)).view(B, G, size)
+
+
+class ComplexModReLU(nn.Module):
+    """z -> z * relu(|z| + b) / sqrt(|z|^2 + eps^2), one real bias per element (spectre.py:95-121)."""
+
+    def __init__(self, num_features: int):
+        super().__init__()
+        self.bias = nn.Parameter(torch.full((num_features,), -0.1))
+        self.register_buffer("eps", torch.tensor(1e-4))
+
+    def forward(self, z: torch.Tensor) -> torch.Tensor:
+        mag = torch.abs(z)
+        denom = torch.sqrt(mag.square() + self.eps.square())
+        return z * (F.relu(mag + self.bias) / denom)
+
+
+class DCTPooling(nn.Module):
+    """Mean of the first `dct_components` DCT coefficients along the sequence (spectre.py:136-156).
+
+    Needs the optional `torch_dct` package; without it the reference warns and mean-pools, and so do we."""
+
+    def __init__(self, embed_dim: int, dct_components: int = 64):
+        super().__init__()
+        self.embed_dim = embed_dim
+        self.dct_components = dct_components
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if _dct is not None:
+            return _dct.dct(x.transpose(1, 2))[:, :, : self.dct_components].mean(dim=2)
+        warnings.warn("DCT pooling unavailable, falling back to mean pooling. "
+                      "Consider installing torch_dct or re-tuning hyperparameters.")
+        return x.mean(dim=1)
+
+
+class AttentionPooling(nn.Module):
+    """softmax(w2(gelu(w1 x))) weighted sum over the sequence (spectre.py:159-172)."""
+
+    def __init__(self, embed_dim: int, hidden_dim: int = 256):
+        super().__init__()
+        self.w1 = nn.Linear(embed_dim, hidden_dim)
+        self.w2 = nn.Linear(hidden_dim, 1)
+        self.activation = nn.GELU()
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        w = F.softmax(self.w2(self.activation(self.w1(x))), dim=1)
+        return (x * w).sum(dim=1)
+
+
+class MeanPool(nn.Module):
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return x.mean(dim=1)
+
+
+# --------------------------------------------------------------------------------------------------
+# the fused op as an autograd node (forward only)
+# --------------------------------------------------------------------------------------------------
+class _SpectralMixFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, V, gate, memory_fft, n_fft):
+        return spectral_mix(V, gate, memory_fft, n_fft)
+
+    @staticmethod
+    def backward(ctx, *grads):  # pragma: no cover
+        raise NotImplementedError(
+            "fft_amd: backward of the fused spectral mix is not implemented yet (forward-only scope); "
+            "run under torch.no_grad() / inference_mode()")
+
+
+# --------------------------------------------------------------------------------------------------
+# the layer
+# --------------------------------------------------------------------------------------------------
+class SpectreHead(nn.Module):
+    """Frequency-domain token mixer for one head — same surface as spectre.py:400-557."""
+
+    def __init__(self, embed_dim: int, fft_size: int, *, num_groups: int = 4, num_buckets: Optional[int] = None,
+                 d_gate: int = 256, use_toeplitz: bool = False, toeplitz_bw: int = 4, dropout_p: float = 0.0,
+                 pooling_type: str = "dct"):
+        super().__init__()
+        assert embed_dim % num_groups == 0, "embed_dim must be divisible by num_groups"
+        self.d = embed_dim
+        self.n_fft = fft_size
+        self.G = num_groups
+        self.d_g = embed_dim // num_groups
+        self.F_half = fft_size // 2 + 1
+        self.B = max(4, num_buckets or int(math.sqrt(self.F_half)))     # anchors per group
+
+        self.W_q = nn.Linear(embed_dim, embed_dim, bias=False)
+        self.W_v = nn.Linear(embed_dim, embed_dim, bias=False)
+        self.gate_mlp = nn.Sequential(nn.Linear(embed_dim, d_gate), nn.GELU(), nn.Linear(d_gate, 2 * self.B * self.G))
+        self.q_norm = nn.LayerNorm(embed_dim)
+        self.modrelu = ComplexModReLU(self.F_half * self.G)
+        if pooling_type == "dct":
+            self.pooling = DCTPooling(embed_dim)
+        elif pooling_type == "attention":
+            self.pooling = AttentionPooling(embed_dim)
+        else:
+            self.pooling = MeanPool()
+
+        self.use_toeplitz = use_toeplitz
+        self.toeplitz_kernel = None
+        if use_toeplitz:
+            # the reference cannot construct this option on current PyTorch (register_parameter on an
+            # existing attribute, spectre.py:453-457), so there is nothing to be compatible with
+            raise NotImplementedError("use_toeplitz=True is not supported (the reference itself fails to construct it)")
+        self.toeplitz_bw = toeplitz_bw
+        self.dropout = nn.Dropout(dropout_p) if dropout_p > 0 else nn.Identity()
+
+    # ---- host logic: everything up to the filter the kernel consumes (spectre.py:502-503, :511-536) --
+    def spectral_gate(self, x: torch.Tensor, pos_phase: Optional[torch.Tensor] = None
+                      ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """Returns (V (B,N,d), gate (B,G,F_half) complex64, q_pool (B,d))."""
+        Bsz, N, d = x.shape
+        assert d == self.d
+        Q = self.W_q(x)
+        V = self.W_v(x)
+        q_pool = self.q_norm(self.pooling(Q))
+        anchors = torch.view_as_complex(self.gate_mlp(q_pool).view(Bsz, self.G, self.B, 2))
+        gate = resample_complex(anchors, self.F_half, mode="cubic")
+        gate = self.modrelu(gate.reshape(Bsz, -1)).view_as(gate)
+        if pos_phase is not None:
+            gate = gate * pos_phase.unsqueeze(1 if pos_phase.dim() == 2 else 0)
+        return V, gate, q_pool
+
+    def forward(self, x: torch.Tensor, pos_phase: Optional[torch.Tensor] = None, return_q_pool: bool = False,
+                memory_fft: Optional[torch.Tensor] = None):
+        V, gate, q_pool = self.spectral_gate(x, pos_phase)
+        gate = gate.to(torch.complex64)
+        if memory_fft is not None:
+            memory_fft = memory_fft.to(torch.complex64)
+        if torch.is_grad_enabled() and (V.requires_grad or gate.requires_grad):
+            mixed = _SpectralMixFn.apply(V, gate, memory_fft, self.n_fft)
+        else:
+            mixed = spectral_mix(V, gate, memory_fft, self.n_fft)          # spectre.py:506, :542-553
+        result = self.dropout(mixed)
+        if return_q_pool:
+            return result, q_pool
+        return result

@@ -1,0 +1,63 @@
+"""The N>1 path on CPU: world_size-2 `gloo` processes shard the batch exactly as bench.py does on GPUs
+(contiguous runs of B per rank, memory_fft replicated, NO collective in the data path), each rank runs the
+mix on its shard (the oracle stands in for the kernel — there is no GPU here), and the concatenation of
+the shards must equal the unsharded result; timing is reduced with MAX over ranks as bench.py does."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, B, N, D, G, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from fft_amd import batch_shard
+    from oracle.spectral_mix_oracle import spectral_mix_torch
+    gen = torch.Generator().manual_seed(123)                 # every rank builds the same global problem
+    V = torch.randn(B, N, D, generator=gen)
+    F = N // 2 + 1
+    gate = torch.complex(torch.randn(B, G, F, generator=gen), torch.randn(B, G, F, generator=gen)) * 0.3
+    mem = torch.complex(torch.randn(F, D, generator=gen), torch.randn(F, D, generator=gen)) * 0.1
+    s, e = batch_shard(B, world, rank)
+    y_local = spectral_mix_torch(V[s:e], gate[s:e], mem, N)  # shard of V and gate, replicated mem
+    # bench.py timing convention: barrier, time, MAX over ranks
+    dist.barrier()
+    t = torch.tensor([0.01 * (rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    assert abs(t.item() - 0.01 * world) < 1e-12
+    # gather only to CHECK (outside any timed region); the data path itself needs no collective
+    sizes = [batch_shard(B, world, r) for r in range(world)]
+    outs = [torch.empty(se - ss, N, D) for ss, se in sizes]
+    dist.all_gather(outs, y_local) if len({o.shape for o in outs}) == 1 else dist.all_gather_object(outs, y_local)
+    if rank == 0:
+        full = spectral_mix_torch(V, gate, mem, N)
+        cat = torch.cat([torch.as_tensor(o) for o in outs], dim=0)
+        np.save(os.path.join(tmp, "maxdiff.npy"), np.array([(cat - full).abs().max().item(), float(cat.shape[0])]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B", [4, 5])
+def test_batch_shard_world2_gloo(tmp_path, B):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), B, 64, 8, 2, str(tmp_path)), nprocs=world, join=True)
+    maxdiff, rows = np.load(tmp_path / "maxdiff.npy")
+    assert rows == B
+    assert maxdiff == 0.0        # per-(b, c) independence: sharding changes nothing, bit for bit
