@@ -41,6 +41,8 @@ struct RegtileArgs {
   int B, N_in, D, G, d_g, F;
   int tiles_per_row, n_tiles;
   long long v_sb, v_sn, out_sb, out_sn;   // element strides
+  int tpw;              // tiles per workgroup (>= 1): amortises workgroup launch + twiddle loads
+  int n_wg;             // workgroups launched = ceil(n_tiles / tpw) rounded up to even
 };
 
 template <int R> struct RegtileCfg;
@@ -48,9 +50,12 @@ template <> struct RegtileCfg<64> { static constexpr int RA = 8, RB = 8; };
 template <> struct RegtileCfg<32> { static constexpr int RA = 4, RB = 8; };
 template <> struct RegtileCfg<16> { static constexpr int RA = 4, RB = 4; };
 
-template <int R> constexpr int regtile_threads() { return 8 * R; }
-template <int R> constexpr int regtile_rowb() { return R * 32 + 32; }          // LDS bytes per destination index (one float plane)
-template <int R> constexpr int regtile_lds_bytes() { return R * regtile_rowb<R>(); }
+// PC = pair-columns per tile (8 -> 16 channels = 64-byte fp32 row segments; 4 -> 8 channels, two workgroups per CU)
+template <int R, int PC = 8> constexpr int regtile_threads() { return PC * R; }
+template <int R, int PC = 8> constexpr int regtile_rowb() { return R * PC * 4 + PC * 4; }   // LDS bytes per destination index (one float plane)
+template <int R, int PC = 8> constexpr int regtile_lds_bytes() { return R * regtile_rowb<R, PC>(); }   // exchange image
+template <int R> constexpr int regtile_gate_lds_bytes() { return (R * R / 2 + 1) * 8; }               // half-spectrum gate
+template <int R, int PC = 8> constexpr int regtile_lds_total() { return regtile_lds_bytes<R, PC>() + regtile_gate_lds_bytes<R>(); }
 
 // Workgroup id -> tile.  Workgroup w is observed to run on XCD w % 8 (speed only, never correctness):
 // give every XCD a contiguous run of tiles so tiles sharing 128-B lines meet in one L2.  Bijective for any n.
@@ -76,11 +81,11 @@ __device__ __forceinline__ uint32_t f32_to_bf16_rne(float f) {
 // set at R complex values (R re in + R im out) instead of 1.5 R for a two-round 8-byte exchange.
 // Every ds_write_b32 is lane-linear (256 B per wave); every ds_read_b32 of a 32-lane group hits 32
 // distinct banks thanks to the 32-byte pad per destination row.
-template <int R, int RA, int RB, bool DIGREV>
+template <int R, int RA, int RB, bool DIGREV, int PC = 8>
 __device__ __forceinline__ void exchange(float2 (&z)[R], char* smem, int p, int u) {
-  constexpr int ROWB = regtile_rowb<R>();
+  constexpr int ROWB = regtile_rowb<R, PC>();
   auto dest = [](int j) constexpr { return DIGREV ? (j / RB) + RA * (j % RB) : j; };
-  float* wbase = reinterpret_cast<float*>(smem + u * 32 + p * 4);
+  float* wbase = reinterpret_cast<float*>(smem + u * (PC * 4) + p * 4);
   const float* rbase = reinterpret_cast<const float*>(smem + u * ROWB + p * 4);
   __syncthreads();                         // everyone done reading the previous exchange
   static_for<0, R>([&](auto jc) {
@@ -88,9 +93,9 @@ __device__ __forceinline__ void exchange(float2 (&z)[R], char* smem, int p, int 
     wbase[dest(j) * (ROWB / 4)] = z[j].x;
   });
   __syncthreads();
-  static_for<0, R>([&](auto mc) {
-    constexpr int m = decltype(mc)::value;
-    z[m].x = rbase[m * 8];
+  static_for<0, R>([&](auto ic) {     // read in the order the next butterfly stage consumes (q0 + RB*q1, q0 first)
+    constexpr int m = (decltype(ic)::value / RA) + RB * (decltype(ic)::value % RA);
+    z[m].x = rbase[m * PC];
   });
   __syncthreads();
   static_for<0, R>([&](auto jc) {
@@ -98,70 +103,164 @@ __device__ __forceinline__ void exchange(float2 (&z)[R], char* smem, int p, int 
     wbase[dest(j) * (ROWB / 4)] = z[j].y;
   });
   __syncthreads();
-  static_for<0, R>([&](auto mc) {
-    constexpr int m = decltype(mc)::value;
-    z[m].y = rbase[m * 8];
+  static_for<0, R>([&](auto ic) {
+    constexpr int m = (decltype(ic)::value / RA) + RB * (decltype(ic)::value % RA);
+    z[m].y = rbase[m * PC];
   });
 }
 
-// GENERAL=false: N_in >= n_fft (no row predicates) and no memory_fft.  GENERAL=true: both handled.
-template <int R, bool IN_BF16, bool OUT_BF16, bool GENERAL>
-__global__ void __launch_bounds__(8 * R) spectre_mix_regtile(const RegtileArgs a) {
+// MODE 0 (fast): N_in >= n_fft (no row predicates), no memory_fft, every tile inside one gate group (gate staged in LDS).
+// MODE 1 (general): row predicates, any even d_g (gate read from global memory).  MODE 2: general + memory_fft.
+// Variant: (re, im) pairs through ds_write_b64 / ds_read_b64 in two rounds (destinations < R/2, then >= R/2).
+// Same LDS footprint (R/2 rows of R*PC*8 bytes), half the DS instructions; costs R/2 more live complex
+// values in the waves that read first.
+template <int R, int RA, int RB, bool DIGREV, int PC = 8>
+__device__ __forceinline__ void exchange64(float2 (&z)[R], char* smem, int p, int u) {
+  constexpr int ROWB = R * PC * 8 + PC * 8;     // bytes per destination index; pad keeps ds_read_b64 conflict-free
+  constexpr int H = R / 2;
+  auto dest = [](int j) constexpr { return DIGREV ? (j / RB) + RA * (j % RB) : j; };
+  char* wbase = smem + u * (PC * 8) + p * 8;
+  const bool lower = u < H;                     // wave-uniform
+  const char* rbase = smem + (lower ? u : u - H) * ROWB + p * 8;
+  float2 in[R];
+  __syncthreads();
+  static_for<0, R>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    if constexpr (dest(j) < H) *reinterpret_cast<float2*>(wbase + dest(j) * ROWB) = z[j];
+  });
+  __syncthreads();
+  if (lower) {
+    static_for<0, R>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      in[m] = *reinterpret_cast<const float2*>(rbase + m * (PC * 8));
+    });
+  }
+  __syncthreads();
+  static_for<0, R>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    if constexpr (dest(j) >= H) *reinterpret_cast<float2*>(wbase + (dest(j) - H) * ROWB) = z[j];
+  });
+  __syncthreads();
+  if (!lower) {
+    static_for<0, R>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      in[m] = *reinterpret_cast<const float2*>(rbase + m * (PC * 8));
+    });
+  }
+  static_for<0, R>([&](auto mc) { z[decltype(mc)::value] = in[decltype(mc)::value]; });
+}
+template <int R, int PC = 8> constexpr int regtile_lds_bytes64() { return (R / 2) * (R * PC * 8 + PC * 8); }
+
+// ABL (ablation switches, tools/ablate_bench.hip only; 0 in the library): bit0 = no global loads/stores,
+// bit1 = no butterflies/twiddles/gate, bit2 = no LDS exchanges.
+template <int R, bool IN_BF16, bool OUT_BF16, int MODE, int ABL = 0, int PC = 8, int XCH = 0>
+__global__ void __launch_bounds__(PC * R) spectre_mix_regtile(const RegtileArgs a) {
+  constexpr bool GENERAL = MODE != 0, WITH_MEM = MODE == 2, GATE_LDS = MODE == 0;
+  constexpr bool NO_IO = (ABL & 1) != 0, NO_MATH = (ABL & 2) != 0, NO_LDS = (ABL & 4) != 0, NO_GATE = (ABL & 8) != 0;
   constexpr int RA = RegtileCfg<R>::RA, RB = RegtileCfg<R>::RB, N = R * R;
   constexpr int ES_IN = IN_BF16 ? 2 : 4, ES_OUT = OUT_BF16 ? 2 : 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int p = lane & 7;
-  const int u = (lane >> 3) + 8 * wave;          // team index: n2 in F1/I2, k1 = s in F2/I1
+  const int p0 = lane & (PC - 1);
+  const int u0 = (lane / PC) + (64 / PC) * wave; // team index: n2 in F1/I2, k1 = s in F2/I1
 
-  const int tile = xcd_contiguous(blockIdx.x, a.n_tiles);
+  // Workgroup w handles tpw tiles.  Workgroups 2m and 2m+1 (same XCD: ids differ by 8 in launch order, see
+  // wg_first_tile) walk through ADJACENT tiles in step, so the two 64-byte halves of every 128-byte line are
+  // requested within the same few microseconds and merge in that XCD's L2.
+  const int wg_lin = xcd_contiguous(blockIdx.x, a.n_wg);      // position of this workgroup in XCD-contiguous order
+  const int pair_base = (wg_lin >> 1) * a.tpw * 2 + (wg_lin & 1);
+  // per-thread twiddle bases: W_N^(u*ka) and W_N^(u*RA*kb); products give W_N^(u*j) for any j < R.
+  // They are (re)loaded from the L1/L2-resident table right where they are used, twice per tile: holding the
+  // 2*(RA+RB-2) registers across the whole tile loop pushes the R = 64 kernel past 256 VGPRs into scratch.
+  for (int it = 0; it < a.tpw; ++it) {
+  // Opaque per-iteration copies of the lane coordinates: otherwise LICM hoists every per-lane address
+  // (twiddle table, 64 gate offsets, row offsets) out of the tile loop and the register allocator spills them.
+  int p = p0, u = u0;
+  asm volatile("" : "+v"(p), "+v"(u));
+  auto load_twiddle_bases = [&](float2 (&wa)[RA], float2 (&wb)[RB]) {
+    static_for<1, RA>([&](auto jc) { constexpr int j = decltype(jc)::value; wa[j] = a.tw[u * j]; });
+    static_for<1, RB>([&](auto jc) { constexpr int j = decltype(jc)::value; wb[j] = a.tw[u * RA * j]; });
+  };
+  const int tile = pair_base + 2 * it;
+  if (tile >= a.n_tiles) break;                  // workgroup-uniform
+  // Opaque per-iteration copies of the row strides: without them LICM hoists all 2*R row offsets out of the
+  // tile loop, where they sit in ~250 SGPRs for the whole body and spill into VGPR lanes.
+  long long v_sn = a.v_sn, out_sn = a.out_sn;
+  asm volatile("" : "+s"(v_sn), "+s"(out_sn));
   const int b = tile / a.tiles_per_row;
   const int ct = tile - b * a.tiles_per_row;
-  const int c = ct * 16 + 2 * p;                 // first channel of this lane's pair
-
-  // per-thread twiddle bases: W_N^(u*ka) and W_N^(u*RA*kb); products give W_N^(u*j) for any j < R
-  float2 wa[RA], wb[RB];
-  static_for<1, RA>([&](auto jc) { constexpr int j = decltype(jc)::value; wa[j] = a.tw[u * j]; });
-  static_for<1, RB>([&](auto jc) { constexpr int j = decltype(jc)::value; wb[j] = a.tw[u * RA * j]; });
+  const int c = ct * (2 * PC) + 2 * p;           // first channel of this lane's pair
 
   float2 z[R];
 
   // ---- load: rows u + R*q, q = 0..R-1 (spectre.py:506 zero-pads / truncates to n_fft) -------------
   {
-    const char* vb = reinterpret_cast<const char*>(a.v) + ((size_t)b * a.v_sb + (size_t)ct * 16) * ES_IN;
-    const uint32_t voff = (uint32_t)(((long long)u * a.v_sn + 2 * p) * ES_IN);
-    static_for<0, R>([&](auto qc) {
-      constexpr int q = decltype(qc)::value;
-      const char* ptr = vb + (size_t)q * R * a.v_sn * ES_IN + voff;
+    const char* vb = reinterpret_cast<const char*>(a.v) + ((size_t)b * a.v_sb + (size_t)ct * (2 * PC)) * ES_IN;
+    const uint32_t voff = (uint32_t)(((long long)u * v_sn + 2 * p) * ES_IN);
+    static_for<0, R>([&](auto ic) {
+      // issue order = order of use: stage 1 of F1 works on {q0 + RB*q1}, q0 = 0, 1, ..., so its first
+      // butterflies start while the tail of the tile is still in flight
+      constexpr int q = (decltype(ic)::value / RA) + RB * (decltype(ic)::value % RA);
+      const char* ptr = vb + (size_t)q * R * v_sn * ES_IN + voff;
       bool ok = true;
-      if constexpr (GENERAL) ok = (u + R * q) < a.N_in;
-      if (ok) {
+      if constexpr (GENERAL) {                     // rows >= N_in read as zero (rfft's zero padding), branch-free:
+        ok = (u + R * q) < a.N_in;                 // load a row that exists, then select
+        ptr = ok ? ptr : vb + voff - (size_t)u * v_sn * ES_IN;
+      }
+      if constexpr (NO_IO) {
+        z[q] = make_float2(1.0f + q + u, 0.5f * p - q);
+      } else {
+        float2 val;
         if constexpr (IN_BF16) {
           const uint32_t wv = *reinterpret_cast<const uint32_t*>(ptr);
-          z[q] = make_float2(__uint_as_float(wv << 16), __uint_as_float(wv & 0xffff0000u));
+          val = make_float2(__uint_as_float(wv << 16), __uint_as_float(wv & 0xffff0000u));
         } else {
-          z[q] = *reinterpret_cast<const float2*>(ptr);
+          val = *reinterpret_cast<const float2*>(ptr);
         }
-      } else {
-        z[q] = make_float2(0.f, 0.f);
+        z[q] = ok ? val : make_float2(0.f, 0.f);
       }
     });
   }
 
-  // ---- F1 -------------------------------------------------------------------------------------------
-  fftA<RA, RB, false>(z);
-  static_for<1, R>([&](auto jc) {
-    constexpr int j = decltype(jc)::value;
-    constexpr int ka = j / RB, kb = j % RB;      // position j carries k1 = ka + RA*kb
-    if constexpr (ka > 0) z[j] = cmul(z[j], wa[ka]);
-    if constexpr (kb > 0) z[j] = cmul(z[j], wb[kb]);
-  });
+  // ---- gate -> LDS (behind the exchange image): each of the N/2+1 bins is fetched from global memory once per
+  // tile instead of once per wave, pre-scaled by 1/N, with Im(DC) and Im(Nyquist) already dropped.  Compile-time
+  // variant: the host picks it only when all 2*PC channels of a tile share one gate group (d_g % (2*PC) == 0);
+  // E1's barriers order fill and use.
+  constexpr bool gate_lds = GATE_LDS;
+  float2* glds = reinterpret_cast<float2*>(smem + regtile_lds_bytes<R, PC>());
+  if constexpr (gate_lds) {
+    constexpr float inv_n = 1.0f / (float)N;
+    const float2* gp = a.gate + ((size_t)b * a.G + (ct * (2 * PC)) / a.d_g) * a.F;
+    for (int k = tid; k <= N / 2; k += PC * R) {
+      float2 g = gp[k];
+      if (k == 0 || k == N / 2) g.y = 0.f;         // irfft ignores Im(DC), Im(Nyquist)
+      glds[k] = make_float2(g.x * inv_n, g.y * inv_n);
+    }
+  }
 
-  exchange<R, RA, RB, true>(z, smem, p, u);
+  // ---- F1 -------------------------------------------------------------------------------------------
+  if constexpr (!NO_MATH) {
+  fftA_stage1<RA, RB, false>(z);
+  {
+    float2 wa[RA], wb[RB];
+    __builtin_amdgcn_sched_barrier(0);           // keep the base loads (and their registers) out of stage 1
+    load_twiddle_bases(wa, wb);
+    static_for<0, RA>([&](auto kac) { fftA_stage2_group<RA, RB, false, decltype(kac)::value>(z); });
+    static_for<1, R>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      constexpr int ka = j / RB, kb = j % RB;    // position j carries k1 = ka + RA*kb
+      if constexpr (ka > 0) z[j] = cmul(z[j], wa[ka]);
+      if constexpr (kb > 0) z[j] = cmul(z[j], wb[kb]);
+    });
+  }
+  }
+
+  if constexpr (!NO_LDS) { if constexpr (XCH == 1) exchange64<R, RA, RB, true, PC>(z, smem, p, u); else exchange<R, RA, RB, true, PC>(z, smem, p, u); }
 
   // ---- F2 (stage 1), then per register group: F2 stage 2 -> gate -> I1 stage 1 --------------------
+  if constexpr (!NO_MATH) {
   fftA_stage1<RA, RB, false>(z);
   {
     const int grp = c / a.d_g;
@@ -170,30 +269,46 @@ __global__ void __launch_bounds__(8 * R) spectre_mix_regtile(const RegtileArgs a
     // bin of register (ka, kb): k = u + R*k2, k2 = ka + RA*kb.  k2 >= R/2 means k > N/2 (or k == N/2 for
     // u == 0): the Hermitian extension reads conj(g[N - k]).
     auto gate_index = [&](int k2) { return (k2 >= R / 2) ? R * (R - k2) - u : u + R * k2; };
-    float2 gcur[RB], gnxt[RB];
-    static_for<0, RB>([&](auto kbc) { constexpr int kb = decltype(kbc)::value; gcur[kb] = gp[gate_index(RA * kb)]; });
-    static_for<0, RA>([&](auto kac) {
-      constexpr int ka = decltype(kac)::value;
-      if constexpr (ka + 1 < RA) {   // software prefetch of the next group's 8 gate bins (16 VGPRs)
-        static_for<0, RB>([&](auto kbc) {
-          constexpr int kb = decltype(kbc)::value;
-          gnxt[kb] = gp[gate_index(ka + 1 + RA * kb)];
-        });
+    // one group of RB bins: from LDS (already scaled, edges fixed) or straight from global memory
+    auto fetch_gate = [&](int k2, bool upper, bool edge) -> float2 {
+      if (NO_GATE) return make_float2(0.5f, 0.25f * u);
+      float2 g;
+      if constexpr (gate_lds) {
+        g = glds[gate_index(k2)];
+      } else {
+        g = gp[gate_index(k2)];
+        if (edge && u == 0) g.y = 0.f;                   // irfft ignores Im(DC), Im(Nyquist)
+        g.x *= inv_n; g.y *= inv_n;
       }
-      fftA_stage2_group<RA, RB, false, ka>(z);
+      if (upper) g.y = -g.y;
+      return g;
+    };
+    // HAS_MEM is a compile-time variant (MODE 2): a per-element test of a.mem would put 64 branches into the unrolled
+    // body and wreck scheduling and register allocation.
+    auto mid = [&](auto has_mem_c) {
+      constexpr bool HAS_MEM = decltype(has_mem_c)::value;
+      float2 gcur[RB], gnxt[RB];
       static_for<0, RB>([&](auto kbc) {
         constexpr int kb = decltype(kbc)::value;
-        constexpr int j = RB * ka + kb;
-        constexpr int k2 = ka + RA * kb;
-        constexpr bool upper = k2 >= R / 2;
-        constexpr bool edge = (k2 == 0) || (k2 == R / 2);
-        float2 g = gcur[kb];
-        if constexpr (upper) g.y = -g.y;
-        if constexpr (edge) { if (u == 0) g.y = 0.f; }   // irfft ignores Im(DC), Im(Nyquist)
-        g.x *= inv_n; g.y *= inv_n;
-        z[j] = cmul(z[j], g);
-        if constexpr (GENERAL) {
-          if (a.mem != nullptr) {
+        gcur[kb] = fetch_gate(RA * kb, RA * kb >= R / 2, RA * kb == 0 || RA * kb == R / 2);
+      });
+      static_for<0, RA>([&](auto kac) {
+        constexpr int ka = decltype(kac)::value;
+        if constexpr (ka + 1 < RA && !HAS_MEM) {   // software prefetch of the next group's RB gate bins (2*RB VGPRs)
+          static_for<0, RB>([&](auto kbc) {
+            constexpr int k2n = ka + 1 + RA * decltype(kbc)::value;
+            gnxt[decltype(kbc)::value] = fetch_gate(k2n, k2n >= R / 2, k2n == 0 || k2n == R / 2);
+          });
+        }
+        fftA_stage2_group<RA, RB, false, ka>(z);
+        static_for<0, RB>([&](auto kbc) {
+          constexpr int kb = decltype(kbc)::value;
+          constexpr int j = RB * ka + kb;
+          constexpr int k2 = ka + RA * kb;
+          constexpr bool upper = k2 >= R / 2;
+          constexpr bool edge = (k2 == 0) || (k2 == R / 2);
+          z[j] = cmul(z[j], gcur[kb]);
+          if constexpr (HAS_MEM) {
             const int idx = gate_index(k2);
             const float4 m = *reinterpret_cast<const float4*>(a.mem + ((size_t)idx * a.D + c) * 2);
             float2 add;
@@ -202,36 +317,54 @@ __global__ void __launch_bounds__(8 * R) spectre_mix_regtile(const RegtileArgs a
             else                add = make_float2(m.x - m.w, m.y + m.z);
             z[j].x += add.x * inv_n; z[j].y += add.y * inv_n;
           }
+        });
+        fftB_stage1_group<RA, RB, true, ka>(z);
+        if constexpr (ka + 1 < RA) {
+          if constexpr (HAS_MEM) {   // no double buffering next to the 4-register memory_fft loads: fetch just in time
+            static_for<0, RB>([&](auto kbc) {
+              constexpr int k2n = ka + 1 + RA * decltype(kbc)::value;
+              gcur[decltype(kbc)::value] = fetch_gate(k2n, k2n >= R / 2, k2n == 0 || k2n == R / 2);
+            });
+          } else {
+            static_for<0, RB>([&](auto kbc) { gcur[decltype(kbc)::value] = gnxt[decltype(kbc)::value]; });
+          }
         }
+        __builtin_amdgcn_sched_barrier(0);   // keep the gate prefetch one group deep (register budget)
       });
-      fftB_stage1_group<RA, RB, true, ka>(z);
-      if constexpr (ka + 1 < RA) {
-        static_for<0, RB>([&](auto kbc) { gcur[decltype(kbc)::value] = gnxt[decltype(kbc)::value]; });
-      }
-      __builtin_amdgcn_sched_barrier(0);   // keep the gate prefetch one group deep (register budget)
+    };
+    mid(std::integral_constant<bool, WITH_MEM>{});
+  }
+  {
+    float2 wa[RA], wb[RB];
+    __builtin_amdgcn_sched_barrier(0);
+    load_twiddle_bases(wa, wb);                  // latency hidden behind the last butterfly stage
+    fftB_stage2<RA, RB, true>(z);
+    static_for<1, R>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;     // position j carries n2 = j = ja + RA*jb
+      constexpr int ja = j % RA, jb = j / RA;
+      if constexpr (ja > 0) z[j] = cmulc(z[j], wa[ja]);
+      if constexpr (jb > 0) z[j] = cmulc(z[j], wb[jb]);
     });
   }
-  fftB_stage2<RA, RB, true>(z);
-  static_for<1, R>([&](auto jc) {
-    constexpr int j = decltype(jc)::value;       // position j carries n2 = j = ja + RA*jb
-    constexpr int ja = j % RA, jb = j / RA;
-    if constexpr (ja > 0) z[j] = cmulc(z[j], wa[ja]);
-    if constexpr (jb > 0) z[j] = cmulc(z[j], wb[jb]);
-  });
 
-  exchange<R, RA, RB, false>(z, smem, p, u);
+  }  // !NO_MATH
+
+  if constexpr (!NO_LDS) { if constexpr (XCH == 1) exchange64<R, RA, RB, false, PC>(z, smem, p, u); else exchange<R, RA, RB, false, PC>(z, smem, p, u); }
 
   // ---- I2 and store (spectre.py:553 keeps rows < min(N, n_fft)) --------------------------------------
-  fftA<RA, RB, true>(z);
+  if constexpr (!NO_MATH) fftA_stage1<RA, RB, true>(z);
   {
-    char* ob = reinterpret_cast<char*>(a.out) + ((size_t)b * a.out_sb + (size_t)ct * 16) * ES_OUT;
-    const uint32_t ooff = (uint32_t)(((long long)u * a.out_sn + 2 * p) * ES_OUT);
+    char* ob = reinterpret_cast<char*>(a.out) + ((size_t)b * a.out_sb + (size_t)ct * (2 * PC)) * ES_OUT;
+    const uint32_t ooff = (uint32_t)(((long long)u * out_sn + 2 * p) * ES_OUT);
     static_for<0, R>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
+      // the last butterfly stage runs group by group; each group's RB rows are stored as soon as they exist
+      if constexpr (!NO_MATH && (j % RB) == 0) fftA_stage2_group<RA, RB, true, j / RB>(z);
       constexpr int n1 = (j / RB) + RA * (j % RB);
-      char* ptr = ob + (size_t)n1 * R * a.out_sn * ES_OUT + ooff;
+      char* ptr = ob + (size_t)n1 * R * out_sn * ES_OUT + ooff;
       bool ok = true;
       if constexpr (GENERAL) ok = (u + R * n1) < a.N_in;
+      if constexpr (NO_IO) ok = (z[j].x == 1.2345e-30f);   // keeps the math alive, never true
       if (ok) {
         if constexpr (OUT_BF16) {
           *reinterpret_cast<uint32_t*>(ptr) = f32_to_bf16_rne(z[j].x) | (f32_to_bf16_rne(z[j].y) << 16);
@@ -241,18 +374,18 @@ __global__ void __launch_bounds__(8 * R) spectre_mix_regtile(const RegtileArgs a
       }
     });
   }
+  }  // tile loop
 }
 
 // host-side launcher for one R (defined in regtile_r*.hip so the heavy kernels compile in parallel)
 template <int R>
-hipError_t launch_regtile(const RegtileArgs& a, bool in_bf16, bool out_bf16, bool general, hipStream_t stream);
+hipError_t launch_regtile(const RegtileArgs& a, bool in_bf16, bool out_bf16, int mode, hipStream_t stream);
 
 #define SFFT_DEFINE_REGTILE_LAUNCHER(RR)                                                                     \
   template <>                                                                                                \
-  hipError_t launch_regtile<RR>(const RegtileArgs& a, bool in_bf16, bool out_bf16, bool general,             \
-                                hipStream_t stream) {                                                        \
-    const dim3 grid(a.n_tiles), block(regtile_threads<RR>());                                                \
-    const size_t lds = regtile_lds_bytes<RR>();                                                              \
+  hipError_t launch_regtile<RR>(const RegtileArgs& a, bool in_bf16, bool out_bf16, int mode, hipStream_t stream) { \
+    const dim3 grid(a.n_wg), block(regtile_threads<RR>());                                                   \
+    const size_t lds = regtile_lds_total<RR>();                                                              \
     auto go = [&](auto kern) -> hipError_t {                                                                 \
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
@@ -260,16 +393,21 @@ hipError_t launch_regtile(const RegtileArgs& a, bool in_bf16, bool out_bf16, boo
       hipLaunchKernelGGL(kern, grid, block, lds, stream, a);                                                 \
       return hipGetLastError();                                                                              \
     };                                                                                                       \
-    const int key = (in_bf16 ? 4 : 0) | (out_bf16 ? 2 : 0) | (general ? 1 : 0);                              \
+    const int key = (in_bf16 ? 8 : 0) | (out_bf16 ? 4 : 0) | mode;                                           \
     switch (key) {                                                                                           \
-      case 0: return go(spectre_mix_regtile<RR, false, false, false>);                                       \
-      case 1: return go(spectre_mix_regtile<RR, false, false, true>);                                        \
-      case 2: return go(spectre_mix_regtile<RR, false, true, false>);                                        \
-      case 3: return go(spectre_mix_regtile<RR, false, true, true>);                                         \
-      case 4: return go(spectre_mix_regtile<RR, true, false, false>);                                        \
-      case 5: return go(spectre_mix_regtile<RR, true, false, true>);                                         \
-      case 6: return go(spectre_mix_regtile<RR, true, true, false>);                                         \
-      default: return go(spectre_mix_regtile<RR, true, true, true>);                                         \
+      case 0: return go(spectre_mix_regtile<RR, false, false, 0>);                                           \
+      case 1: return go(spectre_mix_regtile<RR, false, false, 1>);                                           \
+      case 2: return go(spectre_mix_regtile<RR, false, false, 2>);                                           \
+      case 4: return go(spectre_mix_regtile<RR, false, true, 0>);                                            \
+      case 5: return go(spectre_mix_regtile<RR, false, true, 1>);                                            \
+      case 6: return go(spectre_mix_regtile<RR, false, true, 2>);                                            \
+      case 8: return go(spectre_mix_regtile<RR, true, false, 0>);                                            \
+      case 9: return go(spectre_mix_regtile<RR, true, false, 1>);                                            \
+      case 10: return go(spectre_mix_regtile<RR, true, false, 2>);                                           \
+      case 12: return go(spectre_mix_regtile<RR, true, true, 0>);                                            \
+      case 13: return go(spectre_mix_regtile<RR, true, true, 1>);                                            \
+      case 14: return go(spectre_mix_regtile<RR, true, true, 2>);                                            \
+      default: return hipErrorInvalidValue;                                                                  \
     }                                                                                                        \
   }
 

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -21,9 +22,9 @@
 
 namespace sfft {
 // defined in regtile_r16.hip / regtile_r32.hip / regtile_r64.hip
-template <> hipError_t launch_regtile<16>(const RegtileArgs&, bool, bool, bool, hipStream_t);
-template <> hipError_t launch_regtile<32>(const RegtileArgs&, bool, bool, bool, hipStream_t);
-template <> hipError_t launch_regtile<64>(const RegtileArgs&, bool, bool, bool, hipStream_t);
+template <> hipError_t launch_regtile<16>(const RegtileArgs&, bool, bool, int, hipStream_t);
+template <> hipError_t launch_regtile<32>(const RegtileArgs&, bool, bool, int, hipStream_t);
+template <> hipError_t launch_regtile<64>(const RegtileArgs&, bool, bool, int, hipStream_t);
 }  // namespace sfft
 
 namespace {
@@ -169,7 +170,7 @@ int get_plan(int device, int64_t n, Plan** out) {
 struct Choice {
   bool regtile = false;
   int R = 0;
-  bool general = false;
+  int mode = 0;            // 0 fast, 1 general (row predicates / gate from global), 2 general + memory_fft
   // stockham
   int P = 0, S = 0, solo = 0;
   const char* why_not_regtile = "";
@@ -218,7 +219,7 @@ int choose(const SpectreMixArgs* a, const Plan* plan, Choice* c) {
   if (can_regtile && a->algo != SPECTRE_ALGO_STOCKHAM) {
     c->regtile = true;
     c->R = R;
-    c->general = (a->mem != nullptr) || (a->N_in < a->n_fft);
+    c->mode = a->mem ? 2 : ((a->N_in < a->n_fft) || (d_g % 16 != 0)) ? 1 : 0;
     return SPECTRE_OK;
   }
   // Stockham / Bluestein in LDS
@@ -236,6 +237,17 @@ int choose(const SpectreMixArgs* a, const Plan* plan, Choice* c) {
   const int64_t groups = (c->S + P - 1) / P;
   if (a->B * groups >= ((int64_t)1 << 31)) return fail(SPECTRE_E_UNSUPPORTED, "grid too large");
   return SPECTRE_OK;
+}
+
+// Tiles per workgroup of the register-tile kernel: a workgroup launch costs ~3.6 us (dispatch, LDS allocation,
+// twiddle loads) against ~40 us of work per tile, so loop over a few tiles when there are enough of them to
+// keep dynamic balance across the 256 CUs (profiles/r01_ablation.log).  SPECTRE_TPW overrides (tuning aid).
+int tiles_per_workgroup(int n_tiles) {
+  static const int forced = [] { const char* e = getenv("SPECTRE_TPW"); return e ? atoi(e) : 0; }();
+  if (forced > 0) return forced;
+  if (n_tiles >= 256 * 16) return 4;
+  if (n_tiles >= 256 * 6) return 2;
+  return 1;
 }
 
 struct DeviceGuard {
@@ -260,10 +272,12 @@ int launch(const SpectreMixArgs* a, const Plan* plan, const Choice& c) {
     k.d_g = (int)(a->D / a->G_tot); k.F = (int)(a->n_fft / 2 + 1);
     k.tiles_per_row = (int)(a->D / 16); k.n_tiles = (int)(a->B * (a->D / 16));
     k.v_sb = a->v_sb; k.v_sn = a->v_sn; k.out_sb = a->out_sb; k.out_sn = a->out_sn;
+    k.tpw = tiles_per_workgroup(k.n_tiles);
+    k.n_wg = 2 * ((k.n_tiles + 2 * k.tpw - 1) / (2 * k.tpw));
     const bool ib = a->in_dtype == SPECTRE_BF16, ob = a->out_dtype == SPECTRE_BF16;
-    if (c.R == 16) e = sfft::launch_regtile<16>(k, ib, ob, c.general, stream);
-    else if (c.R == 32) e = sfft::launch_regtile<32>(k, ib, ob, c.general, stream);
-    else e = sfft::launch_regtile<64>(k, ib, ob, c.general, stream);
+    if (c.R == 16) e = sfft::launch_regtile<16>(k, ib, ob, c.mode, stream);
+    else if (c.R == 32) e = sfft::launch_regtile<32>(k, ib, ob, c.mode, stream);
+    else e = sfft::launch_regtile<64>(k, ib, ob, c.mode, stream);
   } else {
     sfft::StockhamArgs k{};
     k.v = a->v; k.gate = reinterpret_cast<const float2*>(a->gate); k.mem = reinterpret_cast<const float*>(a->mem); k.out = a->out;
@@ -347,7 +361,7 @@ int spectre_mix_describe(const SpectreMixArgs* a, char* buf, size_t cap) {
   const char* in = a->in_dtype == SPECTRE_BF16 ? "bf16" : "f32";
   const char* out = a->out_dtype == SPECTRE_BF16 ? "bf16" : "f32";
   if (c.regtile) {
-    snprintf(buf, cap, "regtile R=%d in=%s out=%s general=%d tiles=%lld", c.R, in, out, c.general ? 1 : 0,
+    snprintf(buf, cap, "regtile R=%d in=%s out=%s mode=%d tiles=%lld", c.R, in, out, c.mode,
              (long long)(a->B * (a->D / 16)));
   } else {
     std::string r;

@@ -53,7 +53,15 @@ __global__ void __launch_bounds__(512) copy_tile(const float* __restrict__ in, f
     int xcd = t % nx, idx = t / nx;
     t = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
   }
-  const int b = t / tiles_per_row, ct = t % tiles_per_row;
+  int b = t / tiles_per_row, ct = t % tiles_per_row;
+  if (order == 2 && tiles_per_row % 8 == 0) {
+    // XCD-striped: XCD x owns channel tiles [x*cpx, (x+1)*cpx) of EVERY batch element, so all 8 XCDs stream the
+    // same rows (same DRAM pages) at the same time instead of rows 2^27-aligned apart.
+    const int cpx = tiles_per_row / 8;
+    const int xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
+    ct = xcd * cpx + idx % cpx;
+    b = idx / cpx;
+  }
   const int p = threadIdx.x % LPR;
   const int r = threadIdx.x / LPR;
   // uniform (scalar) tile base + one 32-bit per-lane byte offset -> saddr-form global loads
@@ -133,10 +141,10 @@ int main(int argc, char** argv) {
   // tile variants:  (SEG, order, delay, lds)
   struct Cfg { int seg, order, delay, lds; };
   std::vector<Cfg> cfgs;
-  for (int seg : {16, 32, 64, 128, 256})
-    for (int order : {0, 1})
-      for (int delay : {0, 30, 60})
-        for (int lds : {0, 100 * 1024})
+  for (int seg : {32, 64, 128})
+    for (int order : {1, 2})
+      for (int delay : {0, 60})
+        for (int lds : {100 * 1024})
           cfgs.push_back({seg, order, delay, lds});
   printf("# SEG order delay lds_KB : ms GB/s   (EPT = rows per thread; order 1 = XCD-contiguous tiles)\n");
   for (auto c : cfgs) {

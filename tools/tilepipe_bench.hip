@@ -38,7 +38,8 @@ __global__ void __launch_bounds__(THREADS) tile_kernel(const float* __restrict__
                                                        int delay_iters, float fa, float fb, int nt, int stagger_iters, int rot, int* qctr) {
   constexpr int EPT = 64, PE = EPT / H;
   const int p = threadIdx.x % LPR, r = threadIdx.x / LPR;
-  const uint32_t voff = (uint32_t)(r * D + p * 2) * 4u;
+  const int Deff = (rot & 4) ? SEG / 4 : D;     // dense tiles: row stride = segment
+  const uint32_t voff = (uint32_t)(r * Deff + p * 2) * 4u;
   float2 v[H][PE];
   float acc = 0.f;
   // de-synchronise the persistent workgroups: pairs of neighbouring tiles (which share 128-B lines)
@@ -50,19 +51,25 @@ __global__ void __launch_bounds__(THREADS) tile_kernel(const float* __restrict__
     acc += d * 1e-30f;
   }
   // optional rotation of the row-block order so that workgroups in the same phase hit different rows
-  const int qrot = rot ? ((blockIdx.x / 16) * 5) % PE : 0;
+  const int qrot = (rot & 1) ? ((blockIdx.x / 16) * 5) % PE : 0;
   // virtual persistent order: workgroup w handles tiles w, w + grid, ...  (then XCD-contiguous remap)
   auto tile_ptrs = [&](int it, const char*& si, char*& so) {
     int t = blockIdx.x + it * gridDim.x;
     t = xcd_tile(t % n_tiles, n_tiles);
-    const int b = t / tiles_per_row, ct = t % tiles_per_row;
+    int b = t / tiles_per_row, ct = t % tiles_per_row;
+    if (rot & 2) { b = (blockIdx.x * 37 + it * 11) % (n_tiles / tiles_per_row); ct = (blockIdx.x * 5 + it) % tiles_per_row; }  // scattered tiles
+    if (rot & 4) {   // dense tile: 256 KiB contiguous
+      si = reinterpret_cast<const char*>(in + (size_t)t * N * (SEG / 4));
+      so = reinterpret_cast<char*>(out + (size_t)t * N * (SEG / 4));
+      return;
+    }
     si = reinterpret_cast<const char*>(in + (size_t)b * N * D + (size_t)ct * (SEG / 4));
     so = reinterpret_cast<char*>(out + (size_t)b * N * D + (size_t)ct * (SEG / 4));
   };
   auto load_part = [&](const char* si, int h) {
 #pragma unroll
     for (int q = 0; q < PE; ++q) {
-      const f32x2* ptr = reinterpret_cast<const f32x2*>(si + (size_t)((h * PE + ((q + qrot) % PE)) * RC) * D * 4 + voff);
+      const f32x2* ptr = reinterpret_cast<const f32x2*>(si + (size_t)((h * PE + ((q + qrot) % PE)) * RC) * Deff * 4 + voff);
       f32x2 t = nt ? __builtin_nontemporal_load(ptr) : *ptr;
       v[h][q] = make_float2(t.x, t.y);
     }
@@ -70,7 +77,7 @@ __global__ void __launch_bounds__(THREADS) tile_kernel(const float* __restrict__
   auto store_part = [&](char* so, int h) {
 #pragma unroll
     for (int q = 0; q < PE; ++q) {
-      f32x2* ptr = reinterpret_cast<f32x2*>(so + (size_t)((h * PE + ((q + qrot) % PE)) * RC) * D * 4 + voff);
+      f32x2* ptr = reinterpret_cast<f32x2*>(so + (size_t)((h * PE + ((q + qrot) % PE)) * RC) * Deff * 4 + voff);
       f32x2 t; t.x = v[h][q].x; t.y = v[h][q].y;
       if (nt) __builtin_nontemporal_store(t, ptr); else *ptr = t;
     }
@@ -198,6 +205,18 @@ int main(int argc, char** argv) {
         run<2, 1>("pipe", in, out, B, N, D, 256, n_tiles / 256, delay, nt);
         run<4, 1>("pipe", in, out, B, N, D, 256, n_tiles / 256, delay, nt);
       }
+  } else if (part == 3) {
+    // (d) what slows a CU down when a few neighbours are active?  static persistent copy, 48 tiles each
+    for (int grid : {8, 16, 32, 64, 128, 256})
+      for (int rot : {0, 2, 4}) {
+        run<1, 0>(rot == 0 ? "adjacent" : rot == 2 ? "scattered" : "dense", in, out, B, N, D, grid, 24, 0, 0, 0, rot);
+      }
+    for (int grid : {8, 64, 256}) {
+      run<1, 2>("ld-adj", in, out, B, N, D, grid, 24, 0, 0, 0, 0);
+      run<1, 2>("ld-dense", in, out, B, N, D, grid, 24, 0, 0, 0, 4);
+      run<1, 3>("st-adj", in, out, B, N, D, grid, 24, 0, 0, 0, 0);
+      run<1, 3>("st-dense", in, out, B, N, D, grid, 24, 0, 0, 0, 4);
+    }
   } else if (part == 2) {
     // (c) from one tile per workgroup to fully persistent (static), and the dynamic per-XCD queue
     for (int delay : {0, 60})
