@@ -12,7 +12,7 @@ import threading
 import torch  # noqa: F401  — must be imported first: the library binds to the HIP runtime torch already loaded
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libspectre_hip.so")
+LIB_PATH = os.environ.get("SPECTRE_HIP_LIB") or os.path.join(_HERE, "lib", "libspectre_hip.so")   # env: A/B builds
 
 ABI_VERSION = 1
 F32, BF16 = 0, 1

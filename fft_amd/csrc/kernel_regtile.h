@@ -30,6 +30,10 @@
 #include <stdint.h>
 #include "fft_regs.h"
 
+#ifndef SFFT_R32_WAVES4
+#define SFFT_R32_WAVES4 0
+#endif
+
 namespace sfft {
 
 struct RegtileArgs {
@@ -87,7 +91,8 @@ __device__ __forceinline__ void exchange(float2 (&z)[R], char* smem, int p, int 
   auto dest = [](int j) constexpr { return DIGREV ? (j / RB) + RA * (j % RB) : j; };
   float* wbase = reinterpret_cast<float*>(smem + u * (PC * 4) + p * 4);
   const float* rbase = reinterpret_cast<const float*>(smem + u * ROWB + p * 4);
-  __syncthreads();                         // everyone done reading the previous exchange
+  // (the image is free: every exchange ENDS with a barrier, so these writes may be scheduled into the
+  //  butterfly/twiddle code that produces z[j] instead of waiting behind a barrier of their own)
   static_for<0, R>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
     wbase[dest(j) * (ROWB / 4)] = z[j].x;
@@ -107,6 +112,7 @@ __device__ __forceinline__ void exchange(float2 (&z)[R], char* smem, int p, int 
     constexpr int m = (decltype(ic)::value / RA) + RB * (decltype(ic)::value % RA);
     z[m].y = rbase[m * PC];
   });
+  __syncthreads();                         // image free again for the next exchange
 }
 
 // MODE 0 (fast): N_in >= n_fft (no row predicates), no memory_fft, every tile inside one gate group (gate staged in LDS).
@@ -154,7 +160,7 @@ template <int R, int PC = 8> constexpr int regtile_lds_bytes64() { return (R / 2
 // ABL (ablation switches, tools/ablate_bench.hip only; 0 in the library): bit0 = no global loads/stores,
 // bit1 = no butterflies/twiddles/gate, bit2 = no LDS exchanges.
 template <int R, bool IN_BF16, bool OUT_BF16, int MODE, int ABL = 0, int PC = 8, int XCH = 0>
-__global__ void __launch_bounds__(PC * R) spectre_mix_regtile(const RegtileArgs a) {
+__global__ void __launch_bounds__(PC * R, (R == 32 && PC == 8 && SFFT_R32_WAVES4) ? 4 : 1) spectre_mix_regtile(const RegtileArgs a) {
   constexpr bool GENERAL = MODE != 0, WITH_MEM = MODE == 2, GATE_LDS = MODE == 0;
   constexpr bool NO_IO = (ABL & 1) != 0, NO_MATH = (ABL & 2) != 0, NO_LDS = (ABL & 4) != 0, NO_GATE = (ABL & 8) != 0;
   constexpr int RA = RegtileCfg<R>::RA, RB = RegtileCfg<R>::RB, N = R * R;
@@ -193,6 +199,23 @@ __global__ void __launch_bounds__(PC * R) spectre_mix_regtile(const RegtileArgs 
   const int ct = tile - b * a.tiles_per_row;
   const int c = ct * (2 * PC) + 2 * p;           // first channel of this lane's pair
 
+  // ---- gate -> LDS (behind the exchange image): each of the N/2+1 bins is fetched from global memory once per
+  // tile instead of once per wave, pre-scaled by 1/N, with Im(DC) and Im(Nyquist) already dropped.  Compile-time
+  // variant: the host picks it only when all 2*PC channels of a tile share one gate group (d_g % (2*PC) == 0);
+  // E1's barriers order fill and use.
+  // Issued BEFORE the tile loads: VMEM returns in order, behind them the fill would wait for the whole tile.
+  constexpr bool gate_lds = GATE_LDS;
+  float2* glds = reinterpret_cast<float2*>(smem + regtile_lds_bytes<R, PC>());
+  if constexpr (gate_lds) {
+    constexpr float inv_n = 1.0f / (float)N;
+    const float2* gp = a.gate + ((size_t)b * a.G + (ct * (2 * PC)) / a.d_g) * a.F;
+    for (int k = tid; k <= N / 2; k += PC * R) {
+      float2 g = gp[k];
+      if (k == 0 || k == N / 2) g.y = 0.f;         // irfft ignores Im(DC), Im(Nyquist)
+      glds[k] = make_float2(g.x * inv_n, g.y * inv_n);
+    }
+  }
+
   float2 z[R];
 
   // ---- load: rows u + R*q, q = 0..R-1 (spectre.py:506 zero-pads / truncates to n_fft) -------------
@@ -222,22 +245,6 @@ __global__ void __launch_bounds__(PC * R) spectre_mix_regtile(const RegtileArgs 
         z[q] = ok ? val : make_float2(0.f, 0.f);
       }
     });
-  }
-
-  // ---- gate -> LDS (behind the exchange image): each of the N/2+1 bins is fetched from global memory once per
-  // tile instead of once per wave, pre-scaled by 1/N, with Im(DC) and Im(Nyquist) already dropped.  Compile-time
-  // variant: the host picks it only when all 2*PC channels of a tile share one gate group (d_g % (2*PC) == 0);
-  // E1's barriers order fill and use.
-  constexpr bool gate_lds = GATE_LDS;
-  float2* glds = reinterpret_cast<float2*>(smem + regtile_lds_bytes<R, PC>());
-  if constexpr (gate_lds) {
-    constexpr float inv_n = 1.0f / (float)N;
-    const float2* gp = a.gate + ((size_t)b * a.G + (ct * (2 * PC)) / a.d_g) * a.F;
-    for (int k = tid; k <= N / 2; k += PC * R) {
-      float2 g = gp[k];
-      if (k == 0 || k == N / 2) g.y = 0.f;         // irfft ignores Im(DC), Im(Nyquist)
-      glds[k] = make_float2(g.x * inv_n, g.y * inv_n);
-    }
   }
 
   // ---- F1 -------------------------------------------------------------------------------------------
