@@ -239,15 +239,14 @@ int choose(const SpectreMixArgs* a, const Plan* plan, Choice* c) {
   return SPECTRE_OK;
 }
 
-// Tiles per workgroup of the register-tile kernel: a workgroup launch costs ~3.6 us (dispatch, LDS allocation,
-// twiddle loads) against ~40 us of work per tile, so loop over a few tiles when there are enough of them to
-// keep dynamic balance across the 256 CUs (profiles/r01_ablation.log).  SPECTRE_TPW overrides (tuning aid).
+// Tiles per workgroup of the register-tile kernel.  Measured on MI355X (tools/size_sweep.py): looping over 2-4
+// tiles inside a workgroup does not help at n_fft = 4096 (the workgroup launch is not what is exposed) and costs
+// 5-10 % at n_fft <= 1024, where several workgroups per CU overlap each other and finer dispatch balances better.
+// One tile per workgroup therefore; SPECTRE_TPW overrides (tuning aid).
 int tiles_per_workgroup(int n_tiles) {
   static const int forced = [] { const char* e = getenv("SPECTRE_TPW"); return e ? atoi(e) : 0; }();
-  if (forced > 0) return forced;
-  if (n_tiles >= 256 * 16) return 4;
-  if (n_tiles >= 256 * 6) return 2;
-  return 1;
+  (void)n_tiles;
+  return forced > 0 ? forced : 1;
 }
 
 struct DeviceGuard {
