@@ -19,7 +19,8 @@ LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libspectre_hip.so")
 
-SOURCES = ["spectre_hip.hip", "regtile_r16.hip", "regtile_r32.hip", "regtile_r64.hip"]
+SOURCES = ["spectre_hip.hip", "regtile_n4096.hip", "regtile_n2048.hip", "regtile_n1024.hip", "regtile_n512.hip",
+           "regtile_n256.hip"]
 HEADERS = ["fft_regs.h", "kernel_regtile.h", "kernel_stockham.h", os.path.join("..", "..", "include", "spectre_hip.h")]
 
 # -fno-slp-vectorize: SLP packs the butterflies into v_pk_*_f32 (no faster than two scalar ops on gfx950)

@@ -139,48 +139,54 @@ __device__ __forceinline__ void bfly(float2 (&z)[NTOT]) {
   }
 }
 
-// ---- type A -------------------------------------------------------------------------------------
+// ---- type A (on the sub-array z[OFF .. OFF + RA*RB) of an NTOT-element register array) --------------
 // stage 1: for every q0, radix-RA over q1 (positions RB*q1 + q0), then * W_R^(q0*ka)
-template <int RA, int RB, bool INV>
-__device__ __forceinline__ void fftA_stage1(float2 (&z)[RA * RB]) {
+template <int RA, int RB, bool INV, int OFF = 0, int NTOT = RA * RB>
+__device__ __forceinline__ void fftA_stage1(float2 (&z)[NTOT]) {
   constexpr int R = RA * RB, U = 64 / R;   // W_R = W_64^U
   static_for<0, RB>([&](auto q0c) {
     constexpr int q0 = decltype(q0c)::value;
-    bfly<RA, INV, q0, RB, R>(z);
+    bfly<RA, INV, OFF + q0, RB, NTOT>(z);
     static_for<1, RA>([&](auto kac) {
       constexpr int ka = decltype(kac)::value;
-      z[RB * ka + q0] = twid64<U * q0 * ka, INV>(z[RB * ka + q0]);
+      z[OFF + RB * ka + q0] = twid64<U * q0 * ka, INV>(z[OFF + RB * ka + q0]);
     });
   });
 }
 // stage 2 for one ka: radix-RB over q0 (positions RB*ka + q0) -> kb at RB*ka + kb
-template <int RA, int RB, bool INV, int KA>
-__device__ __forceinline__ void fftA_stage2_group(float2 (&z)[RA * RB]) {
-  bfly<RB, INV, RB * KA, 1, RA * RB>(z);
+template <int RA, int RB, bool INV, int KA, int OFF = 0, int NTOT = RA * RB>
+__device__ __forceinline__ void fftA_stage2_group(float2 (&z)[NTOT]) {
+  bfly<RB, INV, OFF + RB * KA, 1, NTOT>(z);
 }
-template <int RA, int RB, bool INV>
-__device__ __forceinline__ void fftA(float2 (&z)[RA * RB]) {
-  fftA_stage1<RA, RB, INV>(z);
-  static_for<0, RA>([&](auto kac) { fftA_stage2_group<RA, RB, INV, decltype(kac)::value>(z); });
+template <int RA, int RB, bool INV, int OFF = 0, int NTOT = RA * RB>
+__device__ __forceinline__ void fftA(float2 (&z)[NTOT]) {
+  fftA_stage1<RA, RB, INV, OFF, NTOT>(z);
+  static_for<0, RA>([&](auto kac) { fftA_stage2_group<RA, RB, INV, decltype(kac)::value, OFF, NTOT>(z); });
 }
 
 // ---- type B -------------------------------------------------------------------------------------
 // stage 1 for one ka: radix-RB over kb (positions RB*ka + kb) -> n_lo, then * W_R^(ka*n_lo)
-template <int RA, int RB, bool INV, int KA>
-__device__ __forceinline__ void fftB_stage1_group(float2 (&z)[RA * RB]) {
+template <int RA, int RB, bool INV, int KA, int OFF = 0, int NTOT = RA * RB>
+__device__ __forceinline__ void fftB_stage1_group(float2 (&z)[NTOT]) {
   constexpr int R = RA * RB, U = 64 / R;
-  bfly<RB, INV, RB * KA, 1, R>(z);
+  bfly<RB, INV, OFF + RB * KA, 1, NTOT>(z);
   if constexpr (KA > 0) {
     static_for<1, RB>([&](auto nc) {
       constexpr int nlo = decltype(nc)::value;
-      z[RB * KA + nlo] = twid64<U * KA * nlo, INV>(z[RB * KA + nlo]);
+      z[OFF + RB * KA + nlo] = twid64<U * KA * nlo, INV>(z[OFF + RB * KA + nlo]);
     });
   }
 }
 // stage 2: for every n_lo, radix-RA over ka (positions RB*ka + n_lo) -> n_hi at RB*n_hi + n_lo
-template <int RA, int RB, bool INV>
-__device__ __forceinline__ void fftB_stage2(float2 (&z)[RA * RB]) {
-  static_for<0, RB>([&](auto nc) { bfly<RA, INV, decltype(nc)::value, RB, RA * RB>(z); });
+template <int RA, int RB, bool INV, int OFF = 0, int NTOT = RA * RB>
+__device__ __forceinline__ void fftB_stage2(float2 (&z)[NTOT]) {
+  static_for<0, RB>([&](auto nc) { bfly<RA, INV, OFF + decltype(nc)::value, RB, NTOT>(z); });
 }
+
+// factorisation used for each in-register length
+template <int X> struct FftCfg;
+template <> struct FftCfg<64> { static constexpr int RA = 8, RB = 8; };
+template <> struct FftCfg<32> { static constexpr int RA = 4, RB = 8; };
+template <> struct FftCfg<16> { static constexpr int RA = 4, RB = 4; };
 
 }  // namespace sfft

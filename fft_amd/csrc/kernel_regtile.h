@@ -1,38 +1,35 @@
-// kernel_regtile.h — register-resident spectral mix for n_fft = R*R (R = 16, 32, 64) on gfx950.
+// kernel_regtile.h — register-resident spectral mix for n_fft = RF*RS, RF in {RS, 2*RS}, RS in {16, 32, 64}
+// (n_fft = 256, 512, 1024, 2048, 4096) on gfx950.
 //
-// One workgroup owns a tile of 16 adjacent channels (one 64-byte row segment in fp32) for ALL n_fft rows
-// of one batch element; the tile never leaves the CU between the single HBM read and the single HBM write
-// (replaces /root/reference/spectre.py:506 + :542-553, which make 8-9 HBM passes).
+// One workgroup owns a tile of 16 adjacent channels (one 64-byte row segment in fp32) for ALL n_fft rows of one
+// batch element; the tile never leaves the CU between the single HBM read and the single HBM write (replaces
+// /root/reference/spectre.py:506 + :542-553, which make 8-9 HBM passes).
 //
-// Math.  Two real channels (c, c+1) of the same gate group are packed as one complex sequence
-// z = x_c + i x_{c+1}.  Because the filter's impulse response irfft(gate) is REAL, filtering acts on Re and
-// Im independently, so   y_c + i y_{c+1} = IDFT( Gf * DFT(z) + Mf ),   with Gf the Hermitian extension of the
-// half-spectrum gate (Im dropped at DC and Nyquist — spectre.py:551's irfft ignores them) and
-// Mf[k] = mem_c[k] + i mem_{c+1}[k] (k <= N/2), conj(mem_c[N-k]) + i conj(mem_{c+1}[N-k]) otherwise.
+// Math.  Two real channels (c, c+1) of the same gate group are packed as one complex sequence z = x_c + i x_{c+1}.
+// Because the filter's impulse response irfft(gate) is REAL, filtering acts on Re and Im independently, so
+//   y_c + i y_{c+1} = IDFT( Gf * DFT(z) + Mf ),
+// with Gf the Hermitian extension of the half-spectrum gate (Im dropped at DC and Nyquist — spectre.py:551's irfft
+// ignores them) and Mf[k] = mem_c[k] + i mem_{c+1}[k] (k <= N/2), conj(mem_c[N-k]) + i conj(mem_{c+1}[N-k]) otherwise.
 //
-// The length-N complex DFT is the two-pass Cooley-Tukey split n = n2 + R n1, k = k1 + R k2:
-//   F1  thread (p,u):  A[k1]  = sum_n1 z[u + R n1] W_R^(n1 k1)          (in registers, type A)
+// The length-N complex DFT is the two-pass Cooley-Tukey split n = n2 + RS*n1 (n1 < RF), k = k1 + RF*k2 (k2 < RS):
+//   F1  thread (p,u):  A[k1]  = sum_n1 z[u + RS n1] W_RF^(n1 k1)        (RF-point, in registers, type A)
 //                      A[k1] *= W_N^(u k1)                               (per-thread twiddle bases)
-//   E1  exchange through LDS: value (u, k1) -> thread k1, slot u
-//   F2  thread (p,s):  X[s + R k2] = sum_n2 A_n2[s] W_R^(n2 k2)          (type A; last stage fused with ..)
-//       gate:          Y = X * Gf (+ Mf), 1/N folded in
-//   I1                 C[n2]  = sum_k2 Y[s + R k2] W_R^(-n2 k2)          (.. the first stage of type B)
-//                      C[n2] *= conj(W_N^(s n2))
-//   E2  exchange: value (s, n2) -> thread n2, slot s
-//   I2  thread (p,u):  y[u + R n1] = sum_k1 C_k1[u] W_R^(-n1 k1)         (type A, inverse)
+//   E1  exchange through LDS: value (u, k1) -> thread k1 mod RS, set k1 div RS, slot u
+//   F2  thread (p,s), each set t (k1 = s + RS t):  X[k1 + RF k2] = sum_n2 A_n2[k1] W_RS^(n2 k2)   (type A)
+//       gate:          Y = X * Gf (+ Mf), 1/N folded in       } fused per register group with the last stage of F2
+//   I1                 C[n2]  = sum_k2 Y[k1 + RF k2] W_RS^(-n2 k2)   (type B)   } and the first stage of I1
+//   E2  exchange: value (s, t, n2) -> thread n2, slot k1
+//                      C[k1] *= conj(W_N^(u k1))                         (same bases as F1)
+//   I2  thread (p,u):  y[u + RS n1] = sum_k1 C[k1] W_RF^(-n1 k1)         (type A, inverse)
 //
-// Geometry.  lane = (p = lane & 7 : pair-column, row class = lane >> 3), u = row class + 8 * wave, so a
-// wave-wide 8-byte load covers 8 rows x 64 contiguous bytes.  64-byte segments reach the copy ceiling only
-// when the neighbouring tile (other half of the 128-B line) is in flight in the same XCD's L2 at the same
-// time: tiles are therefore dealt to workgroups XCD-contiguously (profiles/r01_segcopy_microbench.log).
+// Geometry.  lane = (p = lane & 7 : pair-column, row class = lane >> 3), u = row class + 8 * wave, so a wave-wide
+// 8-byte load covers 8 rows x 64 contiguous bytes.  64-byte segments reach the copy ceiling only when the
+// neighbouring tile (other half of the 128-B line) is in flight in the same XCD's L2 at the same time: tiles are
+// therefore dealt to workgroups XCD-contiguously (profiles/r01_segcopy_microbench.log).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "fft_regs.h"
-
-#ifndef SFFT_R32_WAVES4
-#define SFFT_R32_WAVES4 0
-#endif
 
 namespace sfft {
 
@@ -45,24 +42,21 @@ struct RegtileArgs {
   int B, N_in, D, G, d_g, F;
   int tiles_per_row, n_tiles;
   long long v_sb, v_sn, out_sb, out_sn;   // element strides
-  int tpw;              // tiles per workgroup (>= 1): amortises workgroup launch + twiddle loads
-  int n_wg;             // workgroups launched = ceil(n_tiles / tpw) rounded up to even
+  int tpw;              // tiles per workgroup (>= 1)
+  int n_wg;             // workgroups launched = 2 * ceil(n_tiles / (2 * tpw))
 };
 
-template <int R> struct RegtileCfg;
-template <> struct RegtileCfg<64> { static constexpr int RA = 8, RB = 8; };
-template <> struct RegtileCfg<32> { static constexpr int RA = 4, RB = 8; };
-template <> struct RegtileCfg<16> { static constexpr int RA = 4, RB = 4; };
+constexpr int kPC = 8;                       // pair-columns per tile: 16 channels, 64-byte fp32 row segments
 
-// PC = pair-columns per tile (8 -> 16 channels = 64-byte fp32 row segments; 4 -> 8 channels, two workgroups per CU)
-template <int R, int PC = 8> constexpr int regtile_threads() { return PC * R; }
-template <int R, int PC = 8> constexpr int regtile_rowb() { return R * PC * 4 + PC * 4; }   // LDS bytes per destination index (one float plane)
-template <int R, int PC = 8> constexpr int regtile_lds_bytes() { return R * regtile_rowb<R, PC>(); }   // exchange image
-template <int R> constexpr int regtile_gate_lds_bytes() { return (R * R / 2 + 1) * 8; }               // half-spectrum gate
-template <int R, int PC = 8> constexpr int regtile_lds_total() { return regtile_lds_bytes<R, PC>() + regtile_gate_lds_bytes<R>(); }
+template <int RF, int RS> constexpr int regtile_threads() { return kPC * RS; }
+// LDS exchange image, one float plane: E1 is [RF rows][RS sources][8 columns], E2 is [RS rows][RF sources][8];
+// every row is padded by 32 bytes so that the 4 team indices of a 32-lane group read from distinct banks
+template <int RF, int RS> constexpr int regtile_image_bytes() { return RF * RS * kPC * 4 + (RF > RS ? RF : RS) * kPC * 4; }
+template <int RF, int RS> constexpr int regtile_gate_lds_bytes() { return (RF * RS / 2 + 1) * 8; }   // half-spectrum gate
+template <int RF, int RS> constexpr int regtile_lds_total() { return regtile_image_bytes<RF, RS>() + regtile_gate_lds_bytes<RF, RS>(); }
 
-// Workgroup id -> tile.  Workgroup w is observed to run on XCD w % 8 (speed only, never correctness):
-// give every XCD a contiguous run of tiles so tiles sharing 128-B lines meet in one L2.  Bijective for any n.
+// Workgroup id -> position.  Workgroup w is observed to run on XCD w % 8 (speed only, never correctness): give
+// every XCD a contiguous run of tiles so tiles sharing 128-B lines meet in one L2.  Bijective for any n.
 __device__ __forceinline__ int xcd_contiguous(int wg, int n) {
   const int nx = 8;
   const int q = n / nx, rem = n % nx;
@@ -77,159 +71,111 @@ __device__ __forceinline__ uint32_t f32_to_bf16_rne(float f) {
   return x >> 16;
 }
 
-// LDS exchange: the value at register position j goes to thread dest(j), which receives it in slot
-// (sender's team index).  DIGREV: position j = RB*ka + kb carries index ka + RA*kb (type-A output);
-// otherwise position j carries index j (type-B output).
-// The tile (R*R*8 columns*8 B = 256 KiB at R = 64) does not fit the 160 KiB LDS, so real and imaginary
-// parts go through the same R*R*8*4-byte image one after the other; this also keeps the live register
-// set at R complex values (R re in + R im out) instead of 1.5 R for a two-round 8-byte exchange.
-// Every ds_write_b32 is lane-linear (256 B per wave); every ds_read_b32 of a 32-lane group hits 32
-// distinct banks thanks to the 32-byte pad per destination row.
-template <int R, int RA, int RB, bool DIGREV, int PC = 8>
-__device__ __forceinline__ void exchange(float2 (&z)[R], char* smem, int p, int u) {
-  constexpr int ROWB = regtile_rowb<R, PC>();
-  auto dest = [](int j) constexpr { return DIGREV ? (j / RB) + RA * (j % RB) : j; };
-  float* wbase = reinterpret_cast<float*>(smem + u * (PC * 4) + p * 4);
-  const float* rbase = reinterpret_cast<const float*>(smem + u * ROWB + p * 4);
-  // (the image is free: every exchange ENDS with a barrier, so these writes may be scheduled into the
-  //  butterfly/twiddle code that produces z[j] instead of waiting behind a barrier of their own)
-  static_for<0, R>([&](auto jc) {
-    constexpr int j = decltype(jc)::value;
-    wbase[dest(j) * (ROWB / 4)] = z[j].x;
+// LDS exchange of one float plane at a time (real parts, then imaginary parts): the tile (RF*RS*8 columns*8 B =
+// 256 KiB at 4096) does not fit the 160 KiB LDS, and this keeps the live register set at RF complex values (re in +
+// im out) instead of 1.5x for a two-round 8-byte exchange, which spills.  wr(j) / rd(m) give the float index inside
+// the image for register position j (write) and m (read).  Every ds_write_b32 is lane-linear (256 B per wave);
+// every ds_read_b32 of a 32-lane group hits 32 distinct banks thanks to the 32-byte pad per row.
+// The image is free on entry: every exchange ENDS with a barrier, so the first writes can be scheduled into the
+// code that produces z[j].  Reads follow the order in which the next butterfly stage consumes them.
+template <int E, int RA, int RB, class WR, class RD>
+__device__ __forceinline__ void exchange_planes(float2 (&z)[E], float* img, WR wr, RD rd) {
+  constexpr int SUB = RA * RB;             // consumer works on sub-arrays of SUB values (E / SUB sets)
+  static_for<0, E>([&](auto jc) { constexpr int j = decltype(jc)::value; img[wr(jc)] = z[j].x; });
+  __syncthreads();
+  static_for<0, E>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    constexpr int m = (i / SUB) * SUB + ((i % SUB) / RA) + RB * ((i % SUB) % RA);
+    z[m].x = img[rd(std::integral_constant<int, m>{})];
   });
   __syncthreads();
-  static_for<0, R>([&](auto ic) {     // read in the order the next butterfly stage consumes (q0 + RB*q1, q0 first)
-    constexpr int m = (decltype(ic)::value / RA) + RB * (decltype(ic)::value % RA);
-    z[m].x = rbase[m * PC];
-  });
+  static_for<0, E>([&](auto jc) { constexpr int j = decltype(jc)::value; img[wr(jc)] = z[j].y; });
   __syncthreads();
-  static_for<0, R>([&](auto jc) {
-    constexpr int j = decltype(jc)::value;
-    wbase[dest(j) * (ROWB / 4)] = z[j].y;
-  });
-  __syncthreads();
-  static_for<0, R>([&](auto ic) {
-    constexpr int m = (decltype(ic)::value / RA) + RB * (decltype(ic)::value % RA);
-    z[m].y = rbase[m * PC];
+  static_for<0, E>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    constexpr int m = (i / SUB) * SUB + ((i % SUB) / RA) + RB * ((i % SUB) % RA);
+    z[m].y = img[rd(std::integral_constant<int, m>{})];
   });
   __syncthreads();                         // image free again for the next exchange
 }
 
 // MODE 0 (fast): N_in >= n_fft (no row predicates), no memory_fft, every tile inside one gate group (gate staged in LDS).
 // MODE 1 (general): row predicates, any even d_g (gate read from global memory).  MODE 2: general + memory_fft.
-// Variant: (re, im) pairs through ds_write_b64 / ds_read_b64 in two rounds (destinations < R/2, then >= R/2).
-// Same LDS footprint (R/2 rows of R*PC*8 bytes), half the DS instructions; costs R/2 more live complex
-// values in the waves that read first.
-template <int R, int RA, int RB, bool DIGREV, int PC = 8>
-__device__ __forceinline__ void exchange64(float2 (&z)[R], char* smem, int p, int u) {
-  constexpr int ROWB = R * PC * 8 + PC * 8;     // bytes per destination index; pad keeps ds_read_b64 conflict-free
-  constexpr int H = R / 2;
-  auto dest = [](int j) constexpr { return DIGREV ? (j / RB) + RA * (j % RB) : j; };
-  char* wbase = smem + u * (PC * 8) + p * 8;
-  const bool lower = u < H;                     // wave-uniform
-  const char* rbase = smem + (lower ? u : u - H) * ROWB + p * 8;
-  float2 in[R];
-  __syncthreads();
-  static_for<0, R>([&](auto jc) {
-    constexpr int j = decltype(jc)::value;
-    if constexpr (dest(j) < H) *reinterpret_cast<float2*>(wbase + dest(j) * ROWB) = z[j];
-  });
-  __syncthreads();
-  if (lower) {
-    static_for<0, R>([&](auto mc) {
-      constexpr int m = decltype(mc)::value;
-      in[m] = *reinterpret_cast<const float2*>(rbase + m * (PC * 8));
-    });
-  }
-  __syncthreads();
-  static_for<0, R>([&](auto jc) {
-    constexpr int j = decltype(jc)::value;
-    if constexpr (dest(j) >= H) *reinterpret_cast<float2*>(wbase + (dest(j) - H) * ROWB) = z[j];
-  });
-  __syncthreads();
-  if (!lower) {
-    static_for<0, R>([&](auto mc) {
-      constexpr int m = decltype(mc)::value;
-      in[m] = *reinterpret_cast<const float2*>(rbase + m * (PC * 8));
-    });
-  }
-  static_for<0, R>([&](auto mc) { z[decltype(mc)::value] = in[decltype(mc)::value]; });
-}
-template <int R, int PC = 8> constexpr int regtile_lds_bytes64() { return (R / 2) * (R * PC * 8 + PC * 8); }
-
 // ABL (ablation switches, tools/ablate_bench.hip only; 0 in the library): bit0 = no global loads/stores,
-// bit1 = no butterflies/twiddles/gate, bit2 = no LDS exchanges.
-template <int R, bool IN_BF16, bool OUT_BF16, int MODE, int ABL = 0, int PC = 8, int XCH = 0>
-__global__ void __launch_bounds__(PC * R, (R == 32 && PC == 8 && SFFT_R32_WAVES4) ? 4 : 1) spectre_mix_regtile(const RegtileArgs a) {
+// bit1 = no butterflies/twiddles/gate, bit2 = no LDS exchanges, bit3 = constant gate.
+template <int RF, int RS, bool IN_BF16, bool OUT_BF16, int MODE, int ABL = 0>
+__global__ void __launch_bounds__(kPC * RS) spectre_mix_regtile(const RegtileArgs a) {
   constexpr bool GENERAL = MODE != 0, WITH_MEM = MODE == 2, GATE_LDS = MODE == 0;
   constexpr bool NO_IO = (ABL & 1) != 0, NO_MATH = (ABL & 2) != 0, NO_LDS = (ABL & 4) != 0, NO_GATE = (ABL & 8) != 0;
-  constexpr int RA = RegtileCfg<R>::RA, RB = RegtileCfg<R>::RB, N = R * R;
+  static_assert(RF == RS || RF == 2 * RS, "n_fft = RS*RS or 2*RS*RS");
+  constexpr int N = RF * RS, NS = RF / RS;                  // NS sets of RS values per thread in the middle phase
+  constexpr int RAF = FftCfg<RF>::RA, RBF = FftCfg<RF>::RB; // RF-point transforms (F1, I2)
+  constexpr int RAS = FftCfg<RS>::RA, RBS = FftCfg<RS>::RB; // RS-point transforms (F2, I1)
+  constexpr int ROW1 = RS * kPC + kPC, ROW2 = RF * kPC + kPC;   // image row lengths in floats (E1, E2)
   constexpr int ES_IN = IN_BF16 ? 2 : 4, ES_OUT = OUT_BF16 ? 2 : 4;
+  constexpr float inv_n = 1.0f / (float)N;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* img = reinterpret_cast<float*>(smem);
+  float2* glds = reinterpret_cast<float2*>(smem + regtile_image_bytes<RF, RS>());
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int p0 = lane & (PC - 1);
-  const int u0 = (lane / PC) + (64 / PC) * wave; // team index: n2 in F1/I2, k1 = s in F2/I1
+  const int p0 = lane & (kPC - 1);
+  const int u0 = (lane / kPC) + (64 / kPC) * wave;   // team index: n2 in F1/I2, k1 mod RS in F2/I1
 
-  // Workgroup w handles tpw tiles.  Workgroups 2m and 2m+1 (same XCD: ids differ by 8 in launch order, see
-  // wg_first_tile) walk through ADJACENT tiles in step, so the two 64-byte halves of every 128-byte line are
-  // requested within the same few microseconds and merge in that XCD's L2.
-  const int wg_lin = xcd_contiguous(blockIdx.x, a.n_wg);      // position of this workgroup in XCD-contiguous order
+  // Workgroup w handles tpw tiles.  Workgroups 2m and 2m+1 (same XCD) walk through ADJACENT tiles in step, so the
+  // two 64-byte halves of every 128-byte line are requested within the same few microseconds and merge in that L2.
+  const int wg_lin = xcd_contiguous(blockIdx.x, a.n_wg);
   const int pair_base = (wg_lin >> 1) * a.tpw * 2 + (wg_lin & 1);
-  // per-thread twiddle bases: W_N^(u*ka) and W_N^(u*RA*kb); products give W_N^(u*j) for any j < R.
-  // They are (re)loaded from the L1/L2-resident table right where they are used, twice per tile: holding the
-  // 2*(RA+RB-2) registers across the whole tile loop pushes the R = 64 kernel past 256 VGPRs into scratch.
+
   for (int it = 0; it < a.tpw; ++it) {
-  // Opaque per-iteration copies of the lane coordinates: otherwise LICM hoists every per-lane address
-  // (twiddle table, 64 gate offsets, row offsets) out of the tile loop and the register allocator spills them.
-  int p = p0, u = u0;
-  asm volatile("" : "+v"(p), "+v"(u));
-  auto load_twiddle_bases = [&](float2 (&wa)[RA], float2 (&wb)[RB]) {
-    static_for<1, RA>([&](auto jc) { constexpr int j = decltype(jc)::value; wa[j] = a.tw[u * j]; });
-    static_for<1, RB>([&](auto jc) { constexpr int j = decltype(jc)::value; wb[j] = a.tw[u * RA * j]; });
-  };
   const int tile = pair_base + 2 * it;
   if (tile >= a.n_tiles) break;                  // workgroup-uniform
-  // Opaque per-iteration copies of the row strides: without them LICM hoists all 2*R row offsets out of the
-  // tile loop, where they sit in ~250 SGPRs for the whole body and spill into VGPR lanes.
+  // Opaque per-iteration copies of the lane coordinates and row strides: otherwise LICM hoists every per-lane
+  // address (twiddle table, gate offsets, 2*RF row offsets) out of the tile loop and the allocator spills them.
+  int p = p0, u = u0;
+  asm volatile("" : "+v"(p), "+v"(u));
   long long v_sn = a.v_sn, out_sn = a.out_sn;
   asm volatile("" : "+s"(v_sn), "+s"(out_sn));
   const int b = tile / a.tiles_per_row;
   const int ct = tile - b * a.tiles_per_row;
-  const int c = ct * (2 * PC) + 2 * p;           // first channel of this lane's pair
+  const int c = ct * (2 * kPC) + 2 * p;          // first channel of this lane's pair
+
+  // per-thread twiddle bases W_N^(u*ka), W_N^(u*RAF*kb): products give W_N^(u*k1) for any k1 < RF.  They are
+  // (re)loaded from the L1/L2-resident table where they are used, twice per tile: holding 2*(RAF+RBF-2) registers
+  // across the whole tile pushes the 64-point kernel past 256 VGPRs into scratch.
+  auto load_twiddle_bases = [&](float2 (&wa)[RAF], float2 (&wb)[RBF]) {
+    static_for<1, RAF>([&](auto jc) { constexpr int j = decltype(jc)::value; wa[j] = a.tw[u * j]; });
+    static_for<1, RBF>([&](auto jc) { constexpr int j = decltype(jc)::value; wb[j] = a.tw[u * RAF * j]; });
+  };
 
   // ---- gate -> LDS (behind the exchange image): each of the N/2+1 bins is fetched from global memory once per
   // tile instead of once per wave, pre-scaled by 1/N, with Im(DC) and Im(Nyquist) already dropped.  Compile-time
-  // variant: the host picks it only when all 2*PC channels of a tile share one gate group (d_g % (2*PC) == 0);
-  // E1's barriers order fill and use.
-  // Issued BEFORE the tile loads: VMEM returns in order, behind them the fill would wait for the whole tile.
-  constexpr bool gate_lds = GATE_LDS;
-  float2* glds = reinterpret_cast<float2*>(smem + regtile_lds_bytes<R, PC>());
-  if constexpr (gate_lds) {
-    constexpr float inv_n = 1.0f / (float)N;
-    const float2* gp = a.gate + ((size_t)b * a.G + (ct * (2 * PC)) / a.d_g) * a.F;
-    for (int k = tid; k <= N / 2; k += PC * R) {
+  // variant: the host picks it only when all 16 channels of a tile share one gate group (d_g % 16 == 0); E1's
+  // barriers order fill and use.  Issued BEFORE the tile loads: VMEM returns in order.
+  if constexpr (GATE_LDS) {
+    const float2* gp = a.gate + ((size_t)b * a.G + (ct * (2 * kPC)) / a.d_g) * a.F;
+    for (int k = tid; k <= N / 2; k += kPC * RS) {
       float2 g = gp[k];
       if (k == 0 || k == N / 2) g.y = 0.f;         // irfft ignores Im(DC), Im(Nyquist)
       glds[k] = make_float2(g.x * inv_n, g.y * inv_n);
     }
   }
 
-  float2 z[R];
+  float2 z[RF];
 
-  // ---- load: rows u + R*q, q = 0..R-1 (spectre.py:506 zero-pads / truncates to n_fft) -------------
+  // ---- load: rows u + RS*q, q = 0..RF-1 (spectre.py:506 zero-pads / truncates to n_fft) -------------
   {
-    const char* vb = reinterpret_cast<const char*>(a.v) + ((size_t)b * a.v_sb + (size_t)ct * (2 * PC)) * ES_IN;
+    const char* vb = reinterpret_cast<const char*>(a.v) + ((size_t)b * a.v_sb + (size_t)ct * (2 * kPC)) * ES_IN;
     const uint32_t voff = (uint32_t)(((long long)u * v_sn + 2 * p) * ES_IN);
-    static_for<0, R>([&](auto ic) {
-      // issue order = order of use: stage 1 of F1 works on {q0 + RB*q1}, q0 = 0, 1, ..., so its first
-      // butterflies start while the tail of the tile is still in flight
-      constexpr int q = (decltype(ic)::value / RA) + RB * (decltype(ic)::value % RA);
-      const char* ptr = vb + (size_t)q * R * v_sn * ES_IN + voff;
+    static_for<0, RF>([&](auto ic) {
+      // issue order = order of use: stage 1 of F1 works on {q0 + RBF*q1}, q0 = 0, 1, ..., so its first butterflies
+      // start while the tail of the tile is still in flight
+      constexpr int q = (decltype(ic)::value / RAF) + RBF * (decltype(ic)::value % RAF);
+      const char* ptr = vb + (size_t)q * RS * v_sn * ES_IN + voff;
       bool ok = true;
       if constexpr (GENERAL) {                     // rows >= N_in read as zero (rfft's zero padding), branch-free:
-        ok = (u + R * q) < a.N_in;                 // load a row that exists, then select
+        ok = (u + RS * q) < a.N_in;                // load a row that exists, then select
         ptr = ok ? ptr : vb + voff - (size_t)u * v_sn * ES_IN;
       }
       if constexpr (NO_IO) {
@@ -247,130 +193,134 @@ __global__ void __launch_bounds__(PC * R, (R == 32 && PC == 8 && SFFT_R32_WAVES4
     });
   }
 
-  // ---- F1 -------------------------------------------------------------------------------------------
+  // ---- F1: RF-point forward transform over n1, then W_N^(u*k1) ---------------------------------------
   if constexpr (!NO_MATH) {
-  fftA_stage1<RA, RB, false>(z);
-  {
-    float2 wa[RA], wb[RB];
+    fftA_stage1<RAF, RBF, false>(z);
+    float2 wa[RAF], wb[RBF];
     __builtin_amdgcn_sched_barrier(0);           // keep the base loads (and their registers) out of stage 1
     load_twiddle_bases(wa, wb);
-    static_for<0, RA>([&](auto kac) { fftA_stage2_group<RA, RB, false, decltype(kac)::value>(z); });
-    static_for<1, R>([&](auto jc) {
+    static_for<0, RAF>([&](auto kac) { fftA_stage2_group<RAF, RBF, false, decltype(kac)::value>(z); });
+    static_for<1, RF>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
-      constexpr int ka = j / RB, kb = j % RB;    // position j carries k1 = ka + RA*kb
+      constexpr int ka = j / RBF, kb = j % RBF;  // position j carries k1 = ka + RAF*kb
       if constexpr (ka > 0) z[j] = cmul(z[j], wa[ka]);
       if constexpr (kb > 0) z[j] = cmul(z[j], wb[kb]);
     });
   }
+
+  // ---- E1: position j (k1 = ka + RAF*kb) -> image row k1, column (u, p); thread s reads rows s + RS*t ----
+  if constexpr (!NO_LDS) {
+    exchange_planes<RF, RAS, RBS>(z, img,
+        [&](auto jc) { constexpr int j = decltype(jc)::value; constexpr int k1 = (j / RBF) + RAF * (j % RBF);
+                       return k1 * ROW1 + u * kPC + p; },
+        [&](auto mc) { constexpr int m = decltype(mc)::value; constexpr int t = m / RS, n2 = m % RS;
+                       return (u + RS * t) * ROW1 + n2 * kPC + p; });
   }
 
-  if constexpr (!NO_LDS) { if constexpr (XCH == 1) exchange64<R, RA, RB, true, PC>(z, smem, p, u); else exchange<R, RA, RB, true, PC>(z, smem, p, u); }
-
-  // ---- F2 (stage 1), then per register group: F2 stage 2 -> gate -> I1 stage 1 --------------------
+  // ---- middle: per set t (k1 = u + RS*t):  F2 stage 1, then per register group  F2 stage 2 -> gate -> I1 stage 1,
+  //      then I1 stage 2.  Bin of register (ka, kb) of set t: k = k1 + RF*k2, k2 = ka + RAS*kb.  k2 >= RS/2 means
+  //      k > N/2 (or k == N/2 when k1 == 0): the Hermitian extension reads conj(g[N - k]).
   if constexpr (!NO_MATH) {
-  fftA_stage1<RA, RB, false>(z);
-  {
     const int grp = c / a.d_g;
     const float2* gp = a.gate + ((size_t)b * a.G + grp) * a.F;
-    constexpr float inv_n = 1.0f / (float)N;
-    // bin of register (ka, kb): k = u + R*k2, k2 = ka + RA*kb.  k2 >= R/2 means k > N/2 (or k == N/2 for
-    // u == 0): the Hermitian extension reads conj(g[N - k]).
-    auto gate_index = [&](int k2) { return (k2 >= R / 2) ? R * (R - k2) - u : u + R * k2; };
-    // one group of RB bins: from LDS (already scaled, edges fixed) or straight from global memory
-    auto fetch_gate = [&](int k2, bool upper, bool edge) -> float2 {
-      if (NO_GATE) return make_float2(0.5f, 0.25f * u);
-      float2 g;
-      if constexpr (gate_lds) {
-        g = glds[gate_index(k2)];
-      } else {
-        g = gp[gate_index(k2)];
-        if (edge && u == 0) g.y = 0.f;                   // irfft ignores Im(DC), Im(Nyquist)
-        g.x *= inv_n; g.y *= inv_n;
-      }
-      if (upper) g.y = -g.y;
-      return g;
-    };
-    // HAS_MEM is a compile-time variant (MODE 2): a per-element test of a.mem would put 64 branches into the unrolled
-    // body and wreck scheduling and register allocation.
-    auto mid = [&](auto has_mem_c) {
-      constexpr bool HAS_MEM = decltype(has_mem_c)::value;
-      float2 gcur[RB], gnxt[RB];
-      static_for<0, RB>([&](auto kbc) {
-        constexpr int kb = decltype(kbc)::value;
-        gcur[kb] = fetch_gate(RA * kb, RA * kb >= R / 2, RA * kb == 0 || RA * kb == R / 2);
+    static_for<0, NS>([&](auto tc) {
+      constexpr int t = decltype(tc)::value;
+      constexpr int OFF = t * RS;
+      const int k1 = u + RS * t;
+      fftA_stage1<RAS, RBS, false, OFF, RF>(z);
+      auto gate_index = [&](int k2) { return (k2 >= RS / 2) ? RF * (RS - k2) - k1 : k1 + RF * k2; };
+      auto fetch_gate = [&](int k2, bool upper, bool edge) -> float2 {
+        if (NO_GATE) return make_float2(0.5f, 0.25f * u);
+        float2 g;
+        if constexpr (GATE_LDS) {
+          g = glds[gate_index(k2)];                          // already scaled, edges fixed
+        } else {
+          g = gp[gate_index(k2)];
+          if (edge && k1 == 0) g.y = 0.f;                    // irfft ignores Im(DC), Im(Nyquist)
+          g.x *= inv_n; g.y *= inv_n;
+        }
+        if (upper) g.y = -g.y;
+        return g;
+      };
+      float2 gcur[RBS], gnxt[RBS];
+      static_for<0, RBS>([&](auto kbc) {
+        constexpr int k2 = RAS * decltype(kbc)::value;
+        gcur[decltype(kbc)::value] = fetch_gate(k2, k2 >= RS / 2, k2 == 0 || k2 == RS / 2);
       });
-      static_for<0, RA>([&](auto kac) {
+      static_for<0, RAS>([&](auto kac) {
         constexpr int ka = decltype(kac)::value;
-        if constexpr (ka + 1 < RA && !HAS_MEM) {   // software prefetch of the next group's RB gate bins (2*RB VGPRs)
-          static_for<0, RB>([&](auto kbc) {
-            constexpr int k2n = ka + 1 + RA * decltype(kbc)::value;
-            gnxt[decltype(kbc)::value] = fetch_gate(k2n, k2n >= R / 2, k2n == 0 || k2n == R / 2);
+        if constexpr (ka + 1 < RAS && !WITH_MEM) {   // software prefetch of the next group's gate bins
+          static_for<0, RBS>([&](auto kbc) {
+            constexpr int k2n = ka + 1 + RAS * decltype(kbc)::value;
+            gnxt[decltype(kbc)::value] = fetch_gate(k2n, k2n >= RS / 2, k2n == 0 || k2n == RS / 2);
           });
         }
-        fftA_stage2_group<RA, RB, false, ka>(z);
-        static_for<0, RB>([&](auto kbc) {
+        fftA_stage2_group<RAS, RBS, false, ka, OFF, RF>(z);
+        static_for<0, RBS>([&](auto kbc) {
           constexpr int kb = decltype(kbc)::value;
-          constexpr int j = RB * ka + kb;
-          constexpr int k2 = ka + RA * kb;
-          constexpr bool upper = k2 >= R / 2;
-          constexpr bool edge = (k2 == 0) || (k2 == R / 2);
+          constexpr int j = OFF + RBS * ka + kb;
+          constexpr int k2 = ka + RAS * kb;
+          constexpr bool upper = k2 >= RS / 2;
+          constexpr bool edge = (k2 == 0) || (k2 == RS / 2);
           z[j] = cmul(z[j], gcur[kb]);
-          if constexpr (HAS_MEM) {
+          if constexpr (WITH_MEM) {                  // spectre.py:548-549
             const int idx = gate_index(k2);
             const float4 m = *reinterpret_cast<const float4*>(a.mem + ((size_t)idx * a.D + c) * 2);
             float2 add;
-            if (edge && u == 0) add = make_float2(m.x, m.z);
-            else if (upper)     add = make_float2(m.x + m.w, m.z - m.y);
-            else                add = make_float2(m.x - m.w, m.y + m.z);
+            if (edge && k1 == 0) add = make_float2(m.x, m.z);
+            else if (upper)      add = make_float2(m.x + m.w, m.z - m.y);
+            else                 add = make_float2(m.x - m.w, m.y + m.z);
             z[j].x += add.x * inv_n; z[j].y += add.y * inv_n;
           }
         });
-        fftB_stage1_group<RA, RB, true, ka>(z);
-        if constexpr (ka + 1 < RA) {
-          if constexpr (HAS_MEM) {   // no double buffering next to the 4-register memory_fft loads: fetch just in time
-            static_for<0, RB>([&](auto kbc) {
-              constexpr int k2n = ka + 1 + RA * decltype(kbc)::value;
-              gcur[decltype(kbc)::value] = fetch_gate(k2n, k2n >= R / 2, k2n == 0 || k2n == R / 2);
+        fftB_stage1_group<RAS, RBS, true, ka, OFF, RF>(z);
+        if constexpr (ka + 1 < RAS) {
+          if constexpr (WITH_MEM) {   // no double buffering next to the 4-register memory_fft loads
+            static_for<0, RBS>([&](auto kbc) {
+              constexpr int k2n = ka + 1 + RAS * decltype(kbc)::value;
+              gcur[decltype(kbc)::value] = fetch_gate(k2n, k2n >= RS / 2, k2n == 0 || k2n == RS / 2);
             });
           } else {
-            static_for<0, RB>([&](auto kbc) { gcur[decltype(kbc)::value] = gnxt[decltype(kbc)::value]; });
+            static_for<0, RBS>([&](auto kbc) { gcur[decltype(kbc)::value] = gnxt[decltype(kbc)::value]; });
           }
         }
         __builtin_amdgcn_sched_barrier(0);   // keep the gate prefetch one group deep (register budget)
       });
-    };
-    mid(std::integral_constant<bool, WITH_MEM>{});
-  }
-  {
-    float2 wa[RA], wb[RB];
-    __builtin_amdgcn_sched_barrier(0);
-    load_twiddle_bases(wa, wb);                  // latency hidden behind the last butterfly stage
-    fftB_stage2<RA, RB, true>(z);
-    static_for<1, R>([&](auto jc) {
-      constexpr int j = decltype(jc)::value;     // position j carries n2 = j = ja + RA*jb
-      constexpr int ja = j % RA, jb = j / RA;
-      if constexpr (ja > 0) z[j] = cmulc(z[j], wa[ja]);
-      if constexpr (jb > 0) z[j] = cmulc(z[j], wb[jb]);
+      fftB_stage2<RAS, RBS, true, OFF, RF>(z);   // natural order: position OFF + n2
     });
   }
 
-  }  // !NO_MATH
+  // ---- E2: position t*RS + n2 -> image row n2, column (k1 = u + RS*t, p); thread u reads its row, slot k1 ----
+  if constexpr (!NO_LDS) {
+    exchange_planes<RF, RAF, RBF>(z, img,
+        [&](auto jc) { constexpr int j = decltype(jc)::value; constexpr int t = j / RS, n2 = j % RS;
+                       return n2 * ROW2 + (u + RS * t) * kPC + p; },
+        [&](auto mc) { constexpr int m = decltype(mc)::value; return u * ROW2 + m * kPC + p; });
+  }
 
-  if constexpr (!NO_LDS) { if constexpr (XCH == 1) exchange64<R, RA, RB, false, PC>(z, smem, p, u); else exchange<R, RA, RB, false, PC>(z, smem, p, u); }
-
-  // ---- I2 and store (spectre.py:553 keeps rows < min(N, n_fft)) --------------------------------------
-  if constexpr (!NO_MATH) fftA_stage1<RA, RB, true>(z);
+  // ---- conj twiddle, I2 and store (spectre.py:553 keeps rows < min(N, n_fft)) -----------------------------
+  if constexpr (!NO_MATH) {
+    float2 wa[RAF], wb[RBF];
+    load_twiddle_bases(wa, wb);
+    static_for<1, RF>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;     // position j carries k1 = j = ja + RAF*jb
+      constexpr int ja = j % RAF, jb = j / RAF;
+      if constexpr (ja > 0) z[j] = cmulc(z[j], wa[ja]);
+      if constexpr (jb > 0) z[j] = cmulc(z[j], wb[jb]);
+    });
+    fftA_stage1<RAF, RBF, true>(z);
+  }
   {
-    char* ob = reinterpret_cast<char*>(a.out) + ((size_t)b * a.out_sb + (size_t)ct * (2 * PC)) * ES_OUT;
+    char* ob = reinterpret_cast<char*>(a.out) + ((size_t)b * a.out_sb + (size_t)ct * (2 * kPC)) * ES_OUT;
     const uint32_t ooff = (uint32_t)(((long long)u * out_sn + 2 * p) * ES_OUT);
-    static_for<0, R>([&](auto jc) {
+    static_for<0, RF>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
-      // the last butterfly stage runs group by group; each group's RB rows are stored as soon as they exist
-      if constexpr (!NO_MATH && (j % RB) == 0) fftA_stage2_group<RA, RB, true, j / RB>(z);
-      constexpr int n1 = (j / RB) + RA * (j % RB);
-      char* ptr = ob + (size_t)n1 * R * out_sn * ES_OUT + ooff;
+      // the last butterfly stage runs group by group; each group's rows are stored as soon as they exist
+      if constexpr (!NO_MATH && (j % RBF) == 0) fftA_stage2_group<RAF, RBF, true, j / RBF>(z);
+      constexpr int n1 = (j / RBF) + RAF * (j % RBF);
+      char* ptr = ob + (size_t)n1 * RS * out_sn * ES_OUT + ooff;
       bool ok = true;
-      if constexpr (GENERAL) ok = (u + R * n1) < a.N_in;
+      if constexpr (GENERAL) ok = (u + RS * n1) < a.N_in;
       if constexpr (NO_IO) ok = (z[j].x == 1.2345e-30f);   // keeps the math alive, never true
       if (ok) {
         if constexpr (OUT_BF16) {
@@ -384,15 +334,16 @@ __global__ void __launch_bounds__(PC * R, (R == 32 && PC == 8 && SFFT_R32_WAVES4
   }  // tile loop
 }
 
-// host-side launcher for one R (defined in regtile_r*.hip so the heavy kernels compile in parallel)
-template <int R>
+// host-side launcher for one (RF, RS) (defined in regtile_*.hip so the heavy kernels compile in parallel)
+template <int RF, int RS>
 hipError_t launch_regtile(const RegtileArgs& a, bool in_bf16, bool out_bf16, int mode, hipStream_t stream);
 
-#define SFFT_DEFINE_REGTILE_LAUNCHER(RR)                                                                     \
+#define SFFT_DEFINE_REGTILE_LAUNCHER(RF_, RS_)                                                               \
   template <>                                                                                                \
-  hipError_t launch_regtile<RR>(const RegtileArgs& a, bool in_bf16, bool out_bf16, int mode, hipStream_t stream) { \
-    const dim3 grid(a.n_wg), block(regtile_threads<RR>());                                                   \
-    const size_t lds = regtile_lds_total<RR>();                                                              \
+  hipError_t launch_regtile<RF_, RS_>(const RegtileArgs& a, bool in_bf16, bool out_bf16, int mode,           \
+                                      hipStream_t stream) {                                                  \
+    const dim3 grid(a.n_wg), block(regtile_threads<RF_, RS_>());                                             \
+    const size_t lds = regtile_lds_total<RF_, RS_>();                                                        \
     auto go = [&](auto kern) -> hipError_t {                                                                 \
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
@@ -402,18 +353,18 @@ hipError_t launch_regtile(const RegtileArgs& a, bool in_bf16, bool out_bf16, int
     };                                                                                                       \
     const int key = (in_bf16 ? 8 : 0) | (out_bf16 ? 4 : 0) | mode;                                           \
     switch (key) {                                                                                           \
-      case 0: return go(spectre_mix_regtile<RR, false, false, 0>);                                           \
-      case 1: return go(spectre_mix_regtile<RR, false, false, 1>);                                           \
-      case 2: return go(spectre_mix_regtile<RR, false, false, 2>);                                           \
-      case 4: return go(spectre_mix_regtile<RR, false, true, 0>);                                            \
-      case 5: return go(spectre_mix_regtile<RR, false, true, 1>);                                            \
-      case 6: return go(spectre_mix_regtile<RR, false, true, 2>);                                            \
-      case 8: return go(spectre_mix_regtile<RR, true, false, 0>);                                            \
-      case 9: return go(spectre_mix_regtile<RR, true, false, 1>);                                            \
-      case 10: return go(spectre_mix_regtile<RR, true, false, 2>);                                           \
-      case 12: return go(spectre_mix_regtile<RR, true, true, 0>);                                            \
-      case 13: return go(spectre_mix_regtile<RR, true, true, 1>);                                            \
-      case 14: return go(spectre_mix_regtile<RR, true, true, 2>);                                            \
+      case 0: return go(spectre_mix_regtile<RF_, RS_, false, false, 0>);                                     \
+      case 1: return go(spectre_mix_regtile<RF_, RS_, false, false, 1>);                                     \
+      case 2: return go(spectre_mix_regtile<RF_, RS_, false, false, 2>);                                     \
+      case 4: return go(spectre_mix_regtile<RF_, RS_, false, true, 0>);                                      \
+      case 5: return go(spectre_mix_regtile<RF_, RS_, false, true, 1>);                                      \
+      case 6: return go(spectre_mix_regtile<RF_, RS_, false, true, 2>);                                      \
+      case 8: return go(spectre_mix_regtile<RF_, RS_, true, false, 0>);                                      \
+      case 9: return go(spectre_mix_regtile<RF_, RS_, true, false, 1>);                                      \
+      case 10: return go(spectre_mix_regtile<RF_, RS_, true, false, 2>);                                     \
+      case 12: return go(spectre_mix_regtile<RF_, RS_, true, true, 0>);                                      \
+      case 13: return go(spectre_mix_regtile<RF_, RS_, true, true, 1>);                                      \
+      case 14: return go(spectre_mix_regtile<RF_, RS_, true, true, 2>);                                      \
       default: return hipErrorInvalidValue;                                                                  \
     }                                                                                                        \
   }

@@ -18,7 +18,8 @@
 
 namespace sfft {
 
-constexpr int kStockhamThreads = 256;
+constexpr int kStockhamMaxThreads = 1024;   // block size is chosen at launch (256..1024): a workgroup that takes most of the
+                                            // LDS is alone on its CU and needs all the waves it can get to hide LDS latency
 constexpr int kMaxPasses = 16;
 
 struct StockhamArgs {
@@ -100,7 +101,7 @@ __device__ __forceinline__ void stockham_pass(const float2* __restrict__ in, flo
                                               const float2* __restrict__ tw) {
   const int nb = L / R;                 // butterflies per sequence
   const int tstep = L / (Ns * R);       // W_(Ns R)^(k r) = tw[k r tstep]
-  for (int wi = threadIdx.x; wi < nb * P; wi += kStockhamThreads) {
+  for (int wi = threadIdx.x; wi < nb * P; wi += blockDim.x) {
     const int j = wi / P, pp = wi - j * P;
     const int k = j % Ns;
     float2 v[R];
@@ -150,7 +151,7 @@ __device__ __forceinline__ float2* dft_n(float2* cur, float2** other, const Stoc
   }
   const int N = a.N, M = a.L;
   // a[n] = x[n] w[n] (n < N), 0 (N <= n < M)
-  for (int i = threadIdx.x; i < M * P; i += kStockhamThreads) {
+  for (int i = threadIdx.x; i < M * P; i += blockDim.x) {
     const int n = i / P;
     cur[i] = (n < N) ? cmul(cur[i], a.chirp[n]) : make_float2(0.f, 0.f);
   }
@@ -158,7 +159,7 @@ __device__ __forceinline__ float2* dft_n(float2* cur, float2** other, const Stoc
   float2* r = stockham_fft(cur, oth, M, P, a.radix, a.n_pass, a.tw);
   float2* o = (r == cur) ? oth : cur;
   // circular convolution with the conj chirp: multiply spectra; inverse FFT as conj(FFT(conj(.))) / M
-  for (int i = threadIdx.x; i < M * P; i += kStockhamThreads) {
+  for (int i = threadIdx.x; i < M * P; i += blockDim.x) {
     const float2 t = cmul(r[i], a.bhat[i / P]);
     r[i] = make_float2(t.x, -t.y);
   }
@@ -166,7 +167,7 @@ __device__ __forceinline__ float2* dft_n(float2* cur, float2** other, const Stoc
   float2* r2 = stockham_fft(r, o, M, P, a.radix, a.n_pass, a.tw);
   float2* o2 = (r2 == r) ? o : r;
   const float inv_m = 1.0f / (float)M;
-  for (int i = threadIdx.x; i < N * P; i += kStockhamThreads) {
+  for (int i = threadIdx.x; i < N * P; i += blockDim.x) {
     const float2 t = make_float2(r2[i].x * inv_m, -r2[i].y * inv_m);
     r2[i] = cmul(t, a.chirp[i / P]);
   }
@@ -175,7 +176,7 @@ __device__ __forceinline__ float2* dft_n(float2* cur, float2** other, const Stoc
   return r2;
 }
 
-__global__ void __launch_bounds__(kStockhamThreads) spectre_mix_stockham(const StockhamArgs a) {
+__global__ void __launch_bounds__(kStockhamMaxThreads) spectre_mix_stockham(const StockhamArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float2* buf0 = reinterpret_cast<float2*>(smem_raw);
   float2* buf1 = buf0 + (size_t)a.L * a.P;
@@ -185,7 +186,7 @@ __global__ void __launch_bounds__(kStockhamThreads) spectre_mix_stockham(const S
   const int n_out = a.N_in < N ? a.N_in : N;
 
   // ---- load (zero-pad / truncate to n_fft, spectre.py:506) ----------------------------------------
-  for (int i = threadIdx.x; i < N * P; i += kStockhamThreads) {
+  for (int i = threadIdx.x; i < N * P; i += blockDim.x) {
     const int n = i / P, pp = i - n * P;
     const int slot = slot0 + pp;
     float2 val = make_float2(0.f, 0.f);
@@ -211,7 +212,7 @@ __global__ void __launch_bounds__(kStockhamThreads) spectre_mix_stockham(const S
 
   // ---- filter: Y[k] = Gf[k] X[k] + Mf[k]; stored conjugated for the conj-trick inverse ------------
   const bool even = (N % 2) == 0;
-  for (int i = threadIdx.x; i < N * P; i += kStockhamThreads) {
+  for (int i = threadIdx.x; i < N * P; i += blockDim.x) {
     const int k = i / P, pp = i - k * P;
     const int slot = slot0 + pp;
     float2 y = make_float2(0.f, 0.f);
@@ -243,7 +244,7 @@ __global__ void __launch_bounds__(kStockhamThreads) spectre_mix_stockham(const S
 
   // ---- store rows < min(N_in, n_fft) (spectre.py:553) -----------------------------------------------
   const float inv_n = 1.0f / (float)N;
-  for (int i = threadIdx.x; i < n_out * P; i += kStockhamThreads) {
+  for (int i = threadIdx.x; i < n_out * P; i += blockDim.x) {
     const int n = i / P, pp = i - n * P;
     const int slot = slot0 + pp;
     if (slot >= a.S) continue;

@@ -1,0 +1,3 @@
+// regtile_n512.hip — n_fft = 512 (= 32 x 16) instantiations of the register-resident kernel (own TU: parallel builds)
+#include "kernel_regtile.h"
+namespace sfft { SFFT_DEFINE_REGTILE_LAUNCHER(32, 16) }

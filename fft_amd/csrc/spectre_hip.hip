@@ -21,10 +21,12 @@
 #include "kernel_stockham.h"
 
 namespace sfft {
-// defined in regtile_r16.hip / regtile_r32.hip / regtile_r64.hip
-template <> hipError_t launch_regtile<16>(const RegtileArgs&, bool, bool, int, hipStream_t);
-template <> hipError_t launch_regtile<32>(const RegtileArgs&, bool, bool, int, hipStream_t);
-template <> hipError_t launch_regtile<64>(const RegtileArgs&, bool, bool, int, hipStream_t);
+// defined in regtile_n256.hip ... regtile_n4096.hip
+template <> hipError_t launch_regtile<16, 16>(const RegtileArgs&, bool, bool, int, hipStream_t);
+template <> hipError_t launch_regtile<32, 16>(const RegtileArgs&, bool, bool, int, hipStream_t);
+template <> hipError_t launch_regtile<32, 32>(const RegtileArgs&, bool, bool, int, hipStream_t);
+template <> hipError_t launch_regtile<64, 32>(const RegtileArgs&, bool, bool, int, hipStream_t);
+template <> hipError_t launch_regtile<64, 64>(const RegtileArgs&, bool, bool, int, hipStream_t);
 }  // namespace sfft
 
 namespace {
@@ -169,7 +171,7 @@ int get_plan(int device, int64_t n, Plan** out) {
 
 struct Choice {
   bool regtile = false;
-  int R = 0;
+  int RF = 0, RS = 0;      // n_fft = RF * RS
   int mode = 0;            // 0 fast, 1 general (row predicates / gate from global), 2 general + memory_fft
   // stockham
   int P = 0, S = 0, solo = 0;
@@ -199,10 +201,17 @@ int validate(const SpectreMixArgs* a) {
 int choose(const SpectreMixArgs* a, const Plan* plan, Choice* c) {
   const int64_t n = a->n_fft, D = a->D, d_g = D / a->G_tot;
   const int es_in = a->in_dtype == SPECTRE_BF16 ? 2 : 4, es_out = a->out_dtype == SPECTRE_BF16 ? 2 : 4;
-  int R = 0;
-  if (n == 256) R = 16; else if (n == 1024) R = 32; else if (n == 4096) R = 64;
+  int RF = 0, RS = 0;
+  switch (n) {
+    case 256: RF = 16; RS = 16; break;
+    case 512: RF = 32; RS = 16; break;
+    case 1024: RF = 32; RS = 32; break;
+    case 2048: RF = 64; RS = 32; break;
+    case 4096: RF = 64; RS = 64; break;
+    default: break;
+  }
   const char* why = "";
-  if (!R) why = "n_fft is not 256/1024/4096";
+  if (!RF) why = "n_fft is not 256/512/1024/2048/4096";
   else if (D % 16) why = "D % 16 != 0";
   else if (d_g % 2) why = "odd group width";
   else if ((reinterpret_cast<uintptr_t>(a->v) % (2 * es_in)) || (a->v_sn % 2) || (a->v_sb % 2)) why = "v not pair-aligned";
@@ -218,7 +227,7 @@ int choose(const SpectreMixArgs* a, const Plan* plan, Choice* c) {
                 "register-tile kernel not applicable: %s", why);
   if (can_regtile && a->algo != SPECTRE_ALGO_STOCKHAM) {
     c->regtile = true;
-    c->R = R;
+    c->RF = RF; c->RS = RS;
     c->mode = a->mem ? 2 : ((a->N_in < a->n_fft) || (d_g % 16 != 0)) ? 1 : 0;
     return SPECTRE_OK;
   }
@@ -274,9 +283,11 @@ int launch(const SpectreMixArgs* a, const Plan* plan, const Choice& c) {
     k.tpw = tiles_per_workgroup(k.n_tiles);
     k.n_wg = 2 * ((k.n_tiles + 2 * k.tpw - 1) / (2 * k.tpw));
     const bool ib = a->in_dtype == SPECTRE_BF16, ob = a->out_dtype == SPECTRE_BF16;
-    if (c.R == 16) e = sfft::launch_regtile<16>(k, ib, ob, c.mode, stream);
-    else if (c.R == 32) e = sfft::launch_regtile<32>(k, ib, ob, c.mode, stream);
-    else e = sfft::launch_regtile<64>(k, ib, ob, c.mode, stream);
+    if (c.RF == 16) e = sfft::launch_regtile<16, 16>(k, ib, ob, c.mode, stream);
+    else if (c.RF == 32 && c.RS == 16) e = sfft::launch_regtile<32, 16>(k, ib, ob, c.mode, stream);
+    else if (c.RF == 32) e = sfft::launch_regtile<32, 32>(k, ib, ob, c.mode, stream);
+    else if (c.RS == 32) e = sfft::launch_regtile<64, 32>(k, ib, ob, c.mode, stream);
+    else e = sfft::launch_regtile<64, 64>(k, ib, ob, c.mode, stream);
   } else {
     sfft::StockhamArgs k{};
     k.v = a->v; k.gate = reinterpret_cast<const float2*>(a->gate); k.mem = reinterpret_cast<const float*>(a->mem); k.out = a->out;
@@ -297,8 +308,9 @@ int launch(const SpectreMixArgs* a, const Plan* plan, const Choice& c) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(sfft::spectre_mix_stockham),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e == hipSuccess) {
-      hipLaunchKernelGGL(sfft::spectre_mix_stockham, dim3((unsigned)(a->B * k.groups_per_batch)), dim3(sfft::kStockhamThreads),
-                         lds, stream, k);
+      // one thread per radix-8 butterfly of a pass, rounded to whole waves, at most 1024
+      int threads = (int)std::min<int64_t>(sfft::kStockhamMaxThreads, std::max<int64_t>(64, (((int64_t)k.L / 8) * k.P + 63) / 64 * 64));
+      hipLaunchKernelGGL(sfft::spectre_mix_stockham, dim3((unsigned)(a->B * k.groups_per_batch)), dim3(threads), lds, stream, k);
       e = hipGetLastError();
     }
   }
@@ -360,7 +372,7 @@ int spectre_mix_describe(const SpectreMixArgs* a, char* buf, size_t cap) {
   const char* in = a->in_dtype == SPECTRE_BF16 ? "bf16" : "f32";
   const char* out = a->out_dtype == SPECTRE_BF16 ? "bf16" : "f32";
   if (c.regtile) {
-    snprintf(buf, cap, "regtile R=%d in=%s out=%s mode=%d tiles=%lld", c.R, in, out, c.mode,
+    snprintf(buf, cap, "regtile %dx%d in=%s out=%s mode=%d tiles=%lld", c.RF, c.RS, in, out, c.mode,
              (long long)(a->B * (a->D / 16)));
   } else {
     std::string r;

@@ -80,7 +80,7 @@ const char* spectre_last_error(void);
 int spectre_mix_fwd(const SpectreMixArgs* args);
 
 /* Which kernel spectre_mix_fwd would run for these arguments, e.g.
- * "regtile R=64 in=f32 out=f32 mem=0 full=1" or "stockham P=2 radices=16,16,16 bluestein=0".
+ * "regtile 64x64 in=f32 out=f32 mode=0 tiles=12288" or "stockham P=2 radices=16,16,16 bluestein=0".
  * Writes a NUL-terminated string of at most `cap` bytes. */
 int spectre_mix_describe(const SpectreMixArgs* args, char* buf, size_t cap);
 

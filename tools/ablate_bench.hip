@@ -11,10 +11,11 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 using namespace sfft;
 
-template <int ABL, bool BF, int PC = 8, int XCH = 0>
+template <int ABL, bool BF>
 void run(const char* name, RegtileArgs a) {
-  auto kern = spectre_mix_regtile<64, BF, BF, 0, ABL, PC, XCH>;
-  const size_t lds = (XCH ? regtile_lds_bytes64<64, PC>() : regtile_lds_bytes<64, PC>()) + regtile_gate_lds_bytes<64>();
+  constexpr int PC = 8;
+  auto kern = spectre_mix_regtile<64, 64, BF, BF, 0, ABL>;
+  const size_t lds = regtile_lds_total<64, 64>();
   a.tiles_per_row = a.D / (2 * PC); a.n_tiles = a.B * a.tiles_per_row;
   if (a.tpw < 1) a.tpw = 1;
   a.n_wg = 2 * ((a.n_tiles + 2 * a.tpw - 1) / (2 * a.tpw));
