@@ -88,10 +88,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = local % max(1, torch.cuda.device_count())           # (several ranks on one GPU only in dry runs)
+    backend = os.environ.get("SPECTRE_BENCH_BACKEND", "nccl")  # RCCL; "gloo" for dry runs — no tensor data crosses ranks
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
     _native.load()                                            # fail loudly if the HIP library is missing
@@ -128,7 +133,7 @@ def main():
     barrier()
     wall = time.perf_counter() - t0
     kern_ms = ev0.elapsed_time(ev1) / a.steps                 # average launch duration over the timed region
-    tw = torch.tensor([wall, kern_ms], dtype=torch.float64, device=dev)
+    tw = torch.tensor([wall, kern_ms], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
     wall, kern_ms = float(tw[0]), float(tw[1])

@@ -79,7 +79,7 @@ std::map<std::pair<int, int64_t>, std::unique_ptr<Plan>> g_plans;
 
 bool factorize(int64_t n, std::vector<int>& out) {
   out.clear();
-  static const int radices[] = {8, 4, 2, 3, 5, 7, 11, 13};
+  static const int radices[] = {16, 8, 4, 2, 25, 15, 5, 3, 7, 11, 13};
   for (int r : radices)
     while (n % r == 0 && n > 1) { out.push_back(r); n /= r; }
   return n == 1;
@@ -231,17 +231,23 @@ int choose(const SpectreMixArgs* a, const Plan* plan, Choice* c) {
     c->mode = a->mem ? 2 : ((a->N_in < a->n_fft) || (d_g % 16 != 0)) ? 1 : 0;
     return SPECTRE_OK;
   }
-  // Stockham / Bluestein in LDS
+  // Stockham / Bluestein in LDS: one buffer of L points per slot; P slots per workgroup, limited by the LDS and by
+  // every pass having to be register-resident ((L/R)*P butterflies <= 1024 threads * stockham_kmax(R))
   const int64_t L = plan->bluestein ? plan->m : n;
+  const std::vector<int>& rad = plan->bluestein ? plan->radix_m : plan->radix_n;
   c->solo = (d_g % 2) ? 1 : 0;
   c->S = (int)(c->solo ? D : D / 2);
-  int64_t P = (int64_t)kLdsBytes / (16 * L);
-  if (P > 8) P = 8;
+  int64_t P = (int64_t)kLdsBytes / (8 * L);
+  if (P > 16) P = 16;
   if (P > c->S) P = c->S;
+  for (int r : rad) {
+    const int64_t cap = (int64_t)sfft::kStockhamMaxThreads * sfft::stockham_kmax(r) * r / L;
+    if (P > cap) P = cap;
+  }
   if (P < 1)
     return fail(SPECTRE_E_UNSUPPORTED,
                 "n_fft=%lld needs %lld bytes of LDS per sequence (transform length %lld%s); the CU has %zu",
-                (long long)n, (long long)(16 * L), (long long)L, plan->bluestein ? ", Bluestein" : "", kLdsBytes);
+                (long long)n, (long long)(8 * L), (long long)L, plan->bluestein ? ", Bluestein" : "", kLdsBytes);
   c->P = (int)P;
   const int64_t groups = (c->S + P - 1) / P;
   if (a->B * groups >= ((int64_t)1 << 31)) return fail(SPECTRE_E_UNSUPPORTED, "grid too large");
@@ -300,16 +306,21 @@ int launch(const SpectreMixArgs* a, const Plan* plan, const Choice& c) {
     k.L = (int)(plan->bluestein ? plan->m : a->n_fft);
     k.n_pass = (int)rad.size();
     if (k.n_pass > sfft::kMaxPasses) return fail(SPECTRE_E_UNSUPPORTED, "too many Stockham passes (%d)", k.n_pass);
-    for (int i = 0; i < k.n_pass; ++i) k.radix[i] = rad[(size_t)i];
+    for (int i = 0; i < k.n_pass; ++i) k.radix_packed[i / 8] |= (unsigned long long)rad[(size_t)i] << (8 * (i % 8));
     k.tw = plan->bluestein ? plan->tw_m : plan->tw_n;
     k.bluestein = plan->bluestein ? 1 : 0;
     k.chirp = plan->chirp; k.bhat = plan->bhat;
-    const size_t lds = (size_t)2 * k.L * k.P * sizeof(float2);
+    const size_t lds = (size_t)k.L * k.P * sizeof(float2);
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(sfft::spectre_mix_stockham),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e == hipSuccess) {
-      // one thread per radix-8 butterfly of a pass, rounded to whole waves, at most 1024
-      int threads = (int)std::min<int64_t>(sfft::kStockhamMaxThreads, std::max<int64_t>(64, (((int64_t)k.L / 8) * k.P + 63) / 64 * 64));
+      // enough threads to hold every pass in registers, and at least one per 8 points for the pointwise loops
+      int64_t need = ((int64_t)k.L * k.P + 7) / 8;
+      for (int i = 0; i < k.n_pass; ++i) {
+        const int r = rad[(size_t)i];
+        need = std::max<int64_t>(need, (((int64_t)k.L / r) * k.P + sfft::stockham_kmax(r) - 1) / sfft::stockham_kmax(r));
+      }
+      const int threads = (int)std::min<int64_t>(sfft::kStockhamMaxThreads, std::max<int64_t>(64, (need + 63) / 64 * 64));
       hipLaunchKernelGGL(sfft::spectre_mix_stockham, dim3((unsigned)(a->B * k.groups_per_batch)), dim3(threads), lds, stream, k);
       e = hipGetLastError();
     }

@@ -80,7 +80,7 @@ SHAPES = [  # (B, N, D, G, n_fft)
     (2, 1000, 32, 2, 1024), (2, 5000, 32, 2, 4096), (1, 100, 16, 2, 128),          # pad / truncate
     (2, 97, 12, 2, 97), (2, 331, 8, 2, 331), (1, 2039, 8, 1, 2039),                # primes: Bluestein
     (2, 60, 6, 2, 60), (2, 64, 10, 2, 64), (2, 256, 24, 8, 256),                   # odd d_g (solo), D%16 != 0
-    (1, 8192, 8, 2, 8192), (1, 6000, 8, 2, 6000), (2, 1, 4, 2, 1), (2, 2, 4, 2, 2), (2, 3, 4, 1, 3),
+    (1, 8192, 8, 2, 8192), (1, 6000, 8, 2, 6000), (1, 16384, 4, 1, 16384), (1, 10000, 4, 2, 10000), (1, 5003, 4, 1, 5003), (2, 1, 4, 2, 1), (2, 2, 4, 2, 2), (2, 3, 4, 1, 3),
 ]
 
 
@@ -158,8 +158,8 @@ def test_error_behaviour():
     with pytest.raises(TypeError):
         spectral_mix(V.double().to(DEV), gate.to(DEV), None, 64)            # fp64 unsupported (as in the reference)
     with pytest.raises(NotImplementedError, match="LDS"):
-        big = torch.zeros(1, 16384, 2, device=DEV)
-        spectral_mix(big, torch.ones(1, 1, 8193, dtype=torch.complex64, device=DEV), None, 16384)
+        big = torch.zeros(1, 32768, 2, device=DEV)
+        spectral_mix(big, torch.ones(1, 1, 16385, dtype=torch.complex64, device=DEV), None, 32768)
     y = spectral_mix(V[:0].to(DEV), gate[:0].to(DEV), None, 64)             # empty batch
     assert tuple(y.shape) == (0, 64, 8)
 
