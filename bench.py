@@ -138,6 +138,23 @@ def main():
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
     wall, kern_ms = float(tw[0]), float(tw[1])
 
+    # other storage dtypes of the same workload, same run (informational; `value` above is the --io default).
+    # BASELINE.json configs[2] words the headline shape as "bf16 in / fp32 compute": both readings are reported.
+    variants = {}
+    if world == 1:
+        from fft_amd import time_kernel
+        for name, tin, tout in (("bf16_in_bf16_out", torch.bfloat16, torch.bfloat16), ("bf16_in_f32_out", torch.bfloat16, torch.float32),
+                                ("f32_in_f32_out", torch.float32, torch.float32)):
+            if (tin == dt and tout == dt):
+                continue
+            Vv = V.to(tin)
+            ov = torch.empty(B, N, D, dtype=tout, device=dev)
+            ms = time_kernel(Vv, gate, None, N, out=ov, warmup=2, iters=max(3, a.steps // 2))
+            byt = algorithmic_bytes(B, N, N, D, G, Vv.element_size(), ov.element_size())
+            variants[name] = {"tokens_per_s": B * N / (ms * 1e-3), "kernel_ms": ms, "achieved_GBps": byt / ms / 1e6,
+                              "roofline_frac": byt / ms / 1e6 / HBM_PEAK_GBS}
+            del Vv, ov
+
     if rank == 0:
         es = V.element_size()
         alg = algorithmic_bytes(B, N, N, D, G, es, es)
@@ -172,6 +189,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg, "kernel_ms": kern_ms},
         }
+        if variants:
+            res["variants"] = variants
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(N, D, G)
         print(json.dumps(res), flush=True)
