@@ -344,14 +344,20 @@ hipError_t launch_regtile(const RegtileArgs& a, bool in_bf16, bool out_bf16, int
                                       hipStream_t stream) {                                                  \
     const dim3 grid(a.n_wg), block(regtile_threads<RF_, RS_>());                                             \
     const size_t lds = regtile_lds_total<RF_, RS_>();                                                        \
+    const int key = (in_bf16 ? 8 : 0) | (out_bf16 ? 4 : 0) | mode;                                           \
+    static bool lds_opt_in[16][16] = {};   /* [device][variant]: >64 KiB of dynamic LDS needs a one-time opt-in */ \
     auto go = [&](auto kern) -> hipError_t {                                                                 \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
-      if (e != hipSuccess) return e;                                                                         \
+      int dev = 0;                                                                                           \
+      (void)hipGetDevice(&dev);                                                                              \
+      if (dev < 0 || dev >= 16 || !lds_opt_in[dev][key]) {                                                   \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                              \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
+        if (e != hipSuccess) return e;                                                                       \
+        if (dev >= 0 && dev < 16) lds_opt_in[dev][key] = true;                                               \
+      }                                                                                                      \
       hipLaunchKernelGGL(kern, grid, block, lds, stream, a);                                                 \
       return hipGetLastError();                                                                              \
     };                                                                                                       \
-    const int key = (in_bf16 ? 8 : 0) | (out_bf16 ? 4 : 0) | mode;                                           \
     switch (key) {                                                                                           \
       case 0: return go(spectre_mix_regtile<RF_, RS_, false, false, 0>);                                     \
       case 1: return go(spectre_mix_regtile<RF_, RS_, false, false, 1>);                                     \
