@@ -14,13 +14,14 @@ import torch  # noqa: F401  — must be imported first: the library binds to the
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPECTRE_HIP_LIB") or os.path.join(_HERE, "lib", "libspectre_hip.so")   # env: A/B builds
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 F32, BF16 = 0, 1
 ALGO = {"auto": 0, "stockham": 1, "regtile": 2}
 
 # every symbol include/spectre_hip.h declares
 EXPORTS = ("spectre_version", "spectre_last_error", "spectre_mix_fwd", "spectre_mix_describe",
-           "spectre_plan_create", "spectre_plan_destroy", "spectre_mix_time")
+           "spectre_plan_create", "spectre_plan_destroy", "spectre_mix_time", "spectre_mix_bwd",
+           "spectre_mix_bwd_workspace_bytes")
 
 
 class SpectreMixArgs(ctypes.Structure):
@@ -31,6 +32,18 @@ class SpectreMixArgs(ctypes.Structure):
         ("v_sb", ctypes.c_int64), ("v_sn", ctypes.c_int64), ("out_sb", ctypes.c_int64), ("out_sn", ctypes.c_int64),
         ("in_dtype", ctypes.c_int32), ("out_dtype", ctypes.c_int32), ("algo", ctypes.c_int32), ("device", ctypes.c_int32),
         ("stream", ctypes.c_void_p),
+    ]
+
+
+class SpectreMixBwdArgs(ctypes.Structure):
+    _fields_ = [
+        ("v", ctypes.c_void_p), ("gate", ctypes.c_void_p), ("dout", ctypes.c_void_p), ("dv", ctypes.c_void_p),
+        ("dgate", ctypes.c_void_p), ("workspace", ctypes.c_void_p),
+        ("B", ctypes.c_int64), ("N_in", ctypes.c_int64), ("n_fft", ctypes.c_int64), ("D", ctypes.c_int64),
+        ("G_tot", ctypes.c_int64),
+        ("v_sb", ctypes.c_int64), ("v_sn", ctypes.c_int64), ("dout_sb", ctypes.c_int64), ("dout_sn", ctypes.c_int64),
+        ("dv_sb", ctypes.c_int64), ("dv_sn", ctypes.c_int64),
+        ("io_dtype", ctypes.c_int32), ("device", ctypes.c_int32), ("stream", ctypes.c_void_p),
     ]
 
 
@@ -71,6 +84,10 @@ def load():
         lib.spectre_mix_time.argtypes = [ctypes.POINTER(SpectreMixArgs), ctypes.c_int, ctypes.c_int,
                                          ctypes.POINTER(ctypes.c_float)]
         lib.spectre_mix_time.restype = ctypes.c_int
+        lib.spectre_mix_bwd.argtypes = [ctypes.POINTER(SpectreMixBwdArgs)]
+        lib.spectre_mix_bwd.restype = ctypes.c_int
+        lib.spectre_mix_bwd_workspace_bytes.argtypes = [ctypes.c_int64] * 3
+        lib.spectre_mix_bwd_workspace_bytes.restype = ctypes.c_int64
         ver = lib.spectre_version()
         if ver != ABI_VERSION:
             raise NativeLibraryError(f"ABI mismatch: library {ver}, binding {ABI_VERSION}")

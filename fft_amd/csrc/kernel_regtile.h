@@ -44,6 +44,7 @@ struct RegtileArgs {
   long long v_sb, v_sn, out_sb, out_sn;   // element strides
   int tpw;              // tiles per workgroup (>= 1)
   int n_wg;             // workgroups launched = 2 * ceil(n_tiles / (2 * tpw))
+  int conj_gate;        // 1: filter with conj(gate) — the adjoint w.r.t. v (dV = mix(dOut, conj(gate)))
 };
 
 constexpr int kPC = 8;                       // pair-columns per tile: 16 channels, 64-byte fp32 row segments
@@ -158,6 +159,7 @@ __global__ void __launch_bounds__(kPC * RS) spectre_mix_regtile(const RegtileArg
     for (int k = tid; k <= N / 2; k += kPC * RS) {
       float2 g = gp[k];
       if (k == 0 || k == N / 2) g.y = 0.f;         // irfft ignores Im(DC), Im(Nyquist)
+      if (a.conj_gate) g.y = -g.y;
       glds[k] = make_float2(g.x * inv_n, g.y * inv_n);
     }
   }
@@ -236,6 +238,7 @@ __global__ void __launch_bounds__(kPC * RS) spectre_mix_regtile(const RegtileArg
           g = glds[gate_index(k2)];                          // already scaled, edges fixed
         } else {
           g = gp[gate_index(k2)];
+          if (a.conj_gate) g.y = -g.y;
           if (edge && k1 == 0) g.y = 0.f;                    // irfft ignores Im(DC), Im(Nyquist)
           g.x *= inv_n; g.y *= inv_n;
         }

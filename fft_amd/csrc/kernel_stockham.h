@@ -49,6 +49,11 @@ struct StockhamArgs {
   int bluestein;
   const float2* chirp;   // w[n] = exp(-i pi n^2 / N), n < N
   const float2* bhat;    // DFT_M of the wrapped conj chirp
+  int conj_gate;         // 1: filter with conj(gate) (adjoint w.r.t. v: dV = mix(dOut, conj(gate)))
+  // gate-gradient kernel only
+  const void* dout;      // (B, N_out, D), same dtype as v
+  long long dout_sb, dout_sn;
+  float2* ws;            // (B, G, N) complex accumulator, zeroed by the host
 };
 
 constexpr double kCos15[15] = {1, 0.91354545764260087, 0.66913060635885824, 0.30901699437494745, -0.10452846326765333, -0.49999999999999978, -0.80901699437494734, -0.97814760073380569, -0.97814760073380569, -0.80901699437494756, -0.50000000000000044, -0.10452846326765423, 0.30901699437494723, 0.66913060635885846, 0.91354545764260098};
@@ -293,6 +298,7 @@ __global__ void __launch_bounds__(kStockhamMaxThreads) spectre_mix_stockham(cons
       const int idx = upper ? N - k : k;
       const bool edge = (k == 0) || (even && 2 * k == N);
       float2 g = a.gate[((size_t)b * a.G + grp) * a.F + idx];
+      if (a.conj_gate) g.y = -g.y;
       if (upper) g.y = -g.y;
       if (edge) g.y = 0.f;                             // irfft ignores Im(DC), Im(Nyquist)
       y = cmul(buf[i], g);
@@ -331,6 +337,76 @@ __global__ void __launch_bounds__(kStockhamMaxThreads) spectre_mix_stockham(cons
       po[0] = yr;
       if (!a.solo) po[1] = yi;
     }
+  }
+}
+
+// ---- gradient w.r.t. the gate ----------------------------------------------------------
+// dgate[b,g,k] = (w_k / N) * sum_{c in g} conj(X_c[k]) R_c[k],  X = rfft(v), R = rfft(dOut zero-padded), w_k = 2
+// (1 at DC / Nyquist).  With two channels per complex sequence (Z = X_c + i X_{c+1}, W = R_c + i R_{c+1})
+//   P[k] = conj(Z[k]) W[k] = S[k] + i T[k],   P[N-k] = conj(S[k]) + i conj(T[k])   =>   S[k] = (P[k] + conj(P[N-k])) / 2
+// so the kernel only accumulates P over the channel pairs of a group for ALL N bins (atomics into ws), and the k <-> N-k
+// pairing happens once per (b, g) in spectre_gate_grad_finish.  Slots 0..P-1 of the LDS buffer hold the v sequences,
+// slots P..2P-1 the dOut sequences; one Stockham run transforms all 2P.  The host picks P | (slots per group).
+__global__ void __launch_bounds__(kStockhamMaxThreads) spectre_gate_grad_stockham(const StockhamArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float2* buf = reinterpret_cast<float2*>(smem_raw);
+  const int P = a.P, P2 = 2 * a.P, N = a.N;
+  const int b = blockIdx.x / a.groups_per_batch;
+  const int slot0 = (blockIdx.x - b * a.groups_per_batch) * P;
+  const int n_dy = a.N_in < N ? a.N_in : N;        // rows of dOut (= rows the forward kept)
+
+#pragma unroll 2
+  for (int i = threadIdx.x; i < N * P2; i += blockDim.x) {
+    const int n = i / P2, pp = i - n * P2;
+    const bool is_dy = pp >= P;
+    const int slot = slot0 + (is_dy ? pp - P : pp);
+    float2 val = make_float2(0.f, 0.f);
+    if (slot < a.S && n < (is_dy ? n_dy : a.N_in)) {
+      const int c0 = a.solo ? slot : 2 * slot;
+      const size_t off = is_dy ? (size_t)b * a.dout_sb + (size_t)n * a.dout_sn + c0
+                               : (size_t)b * a.v_sb + (size_t)n * a.v_sn + c0;
+      const void* base = is_dy ? a.dout : a.v;
+      if (a.in_bf16) {
+        const uint16_t* pv = reinterpret_cast<const uint16_t*>(base) + off;
+        val.x = __uint_as_float((uint32_t)pv[0] << 16);
+        if (!a.solo) val.y = __uint_as_float((uint32_t)pv[1] << 16);
+      } else {
+        const float* pv = reinterpret_cast<const float*>(base) + off;
+        val.x = pv[0];
+        if (!a.solo) val.y = pv[1];
+      }
+    }
+    buf[i] = val;
+  }
+  __syncthreads();
+
+  StockhamArgs a2 = a;          // the transform sees 2P interleaved sequences
+  a2.P = P2;
+  dft_n(buf, a2);
+
+  const int c_first = a.solo ? slot0 : 2 * slot0;
+  float2* wsp = a.ws + ((size_t)b * a.G + c_first / a.d_g) * N;
+  for (int k = threadIdx.x; k < N; k += blockDim.x) {
+    float2 acc = make_float2(0.f, 0.f);
+    for (int pp = 0; pp < P; ++pp) {
+      if (slot0 + pp < a.S) acc = cadd(acc, cmulc(buf[k * P2 + P + pp], buf[k * P2 + pp]));   // W * conj(Z)
+    }
+    atomicAdd(&wsp[k].x, acc.x);
+    atomicAdd(&wsp[k].y, acc.y);
+  }
+}
+
+// dgate[b,g,k] = (P[k] + conj(P[N-k])) / N for 0 < k < N/2 (w_k = 2, times 1/2), Re(P[k]) / N at DC / Nyquist
+__global__ void __launch_bounds__(256) spectre_gate_grad_finish(const float2* __restrict__ ws, float2* __restrict__ dgate, int BG, int N, int F) {
+  const long long total = (long long)BG * F;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % F);
+    const long long bg = i / F;
+    const float2 pk = ws[bg * N + k];
+    const float2 pm = ws[bg * N + (k == 0 ? 0 : N - k)];
+    const float inv_n = 1.0f / (float)N;
+    const bool edge = (k == 0) || (2 * k == N);
+    dgate[i] = edge ? make_float2(pk.x * inv_n, 0.f) : make_float2((pk.x + pm.x) * inv_n, (pk.y - pm.y) * inv_n);
   }
 }
 

@@ -274,7 +274,7 @@ struct DeviceGuard {
   ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 
-int launch(const SpectreMixArgs* a, const Plan* plan, const Choice& c) {
+int launch(const SpectreMixArgs* a, const Plan* plan, const Choice& c, bool conj_gate = false) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(a->stream);
   if (a->B == 0) return SPECTRE_OK;
   hipError_t e;
@@ -286,6 +286,7 @@ int launch(const SpectreMixArgs* a, const Plan* plan, const Choice& c) {
     k.d_g = (int)(a->D / a->G_tot); k.F = (int)(a->n_fft / 2 + 1);
     k.tiles_per_row = (int)(a->D / 16); k.n_tiles = (int)(a->B * (a->D / 16));
     k.v_sb = a->v_sb; k.v_sn = a->v_sn; k.out_sb = a->out_sb; k.out_sn = a->out_sn;
+    k.conj_gate = conj_gate ? 1 : 0;
     k.tpw = tiles_per_workgroup(k.n_tiles);
     k.n_wg = 2 * ((k.n_tiles + 2 * k.tpw - 1) / (2 * k.tpw));
     const bool ib = a->in_dtype == SPECTRE_BF16, ob = a->out_dtype == SPECTRE_BF16;
@@ -310,6 +311,7 @@ int launch(const SpectreMixArgs* a, const Plan* plan, const Choice& c) {
     k.tw = plan->bluestein ? plan->tw_m : plan->tw_n;
     k.bluestein = plan->bluestein ? 1 : 0;
     k.chirp = plan->chirp; k.bhat = plan->bhat;
+    k.conj_gate = conj_gate ? 1 : 0;
     const size_t lds = (size_t)k.L * k.P * sizeof(float2);
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(sfft::spectre_mix_stockham),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -420,6 +422,91 @@ int spectre_mix_time(const SpectreMixArgs* a, int warmup, int iters, float* ms_p
   (void)hipEventDestroy(e1);
   if (e != hipSuccess) return fail(SPECTRE_E_HIP, "timing failed: %s", hipGetErrorString(e));
   *ms_per_launch = ms / (float)iters;
+  return SPECTRE_OK;
+}
+
+int64_t spectre_mix_bwd_workspace_bytes(int64_t B, int64_t n_fft, int64_t G_tot) {
+  if (B < 0 || n_fft < 1 || G_tot < 1) return 0;
+  return B * G_tot * n_fft * (int64_t)sizeof(float2);
+}
+
+int spectre_mix_bwd(const SpectreMixBwdArgs* a) {
+  if (!a) return fail(SPECTRE_E_INVALID, "args is NULL");
+  if (a->B < 0 || a->N_in < 1 || a->n_fft < 1 || a->D < 1 || a->G_tot < 1 || a->D % a->G_tot)
+    return fail(SPECTRE_E_INVALID, "bad sizes");
+  if (a->io_dtype != SPECTRE_F32 && a->io_dtype != SPECTRE_BF16) return fail(SPECTRE_E_UNSUPPORTED, "bad io_dtype");
+  if (a->B == 0) return SPECTRE_OK;
+  if (!a->v || !a->gate || !a->dout) return fail(SPECTRE_E_INVALID, "v, gate and dout must be non-NULL device pointers");
+  if (a->dgate && !a->workspace) return fail(SPECTRE_E_INVALID, "dgate requested without a workspace");
+  DeviceGuard g(a->device);
+  if (!g.ok) return fail(SPECTRE_E_HIP, "cannot select device %d", a->device);
+  hipStream_t stream = reinterpret_cast<hipStream_t>(a->stream);
+  const int64_t n_out = std::min(a->N_in, a->n_fft);
+  const int es = a->io_dtype == SPECTRE_BF16 ? 2 : 4;
+  int rc;
+  if (a->dv) {
+    // dV = mix(dOut, conj(gate)): rows [0, n_out); rows n_out..N_in (input truncated by rfft's n=) get zero gradient
+    SpectreMixArgs f{};
+    f.v = a->dout; f.gate = a->gate; f.mem = nullptr; f.out = a->dv;
+    f.B = a->B; f.N_in = n_out; f.n_fft = a->n_fft; f.D = a->D; f.G_tot = a->G_tot;
+    f.v_sb = a->dout_sb; f.v_sn = a->dout_sn; f.out_sb = a->dv_sb; f.out_sn = a->dv_sn;
+    f.in_dtype = a->io_dtype; f.out_dtype = a->io_dtype; f.algo = SPECTRE_ALGO_AUTO; f.device = a->device; f.stream = a->stream;
+    Plan* plan = nullptr;
+    Choice c;
+    if ((rc = prepare(&f, &plan, &c))) return rc;
+    if ((rc = launch(&f, plan, c, /*conj_gate=*/true))) return rc;
+    if (a->N_in > n_out) {
+      for (int64_t b = 0; b < a->B; ++b) {
+        char* p = reinterpret_cast<char*>(a->dv) + (b * a->dv_sb + n_out * a->dv_sn) * es;
+        hipError_t e = hipMemset2DAsync(p, (size_t)a->dv_sn * es, 0, (size_t)a->D * es, (size_t)(a->N_in - n_out), stream);
+        if (e != hipSuccess) return fail(SPECTRE_E_HIP, "hipMemset2DAsync: %s", hipGetErrorString(e));
+      }
+    }
+  }
+  if (a->dgate) {
+    Plan* plan = nullptr;
+    if ((rc = get_plan(a->device, a->n_fft, &plan))) return rc;
+    const int64_t n = a->n_fft, D = a->D, d_g = D / a->G_tot;
+    const int64_t L = plan->bluestein ? plan->m : n;
+    const std::vector<int>& rad = plan->bluestein ? plan->radix_m : plan->radix_n;
+    const int solo = (d_g % 2) ? 1 : 0;
+    const int64_t S = solo ? D : D / 2, Sg = solo ? d_g : d_g / 2;
+    // P slots of v + P slots of dOut share the LDS buffer; P must divide the slots of one gate group
+    int64_t P = 0;
+    for (int64_t cand = std::min<int64_t>(8, Sg); cand >= 1; --cand) {
+      if (Sg % cand) continue;
+      if (2 * cand * L * 8 > (int64_t)kLdsBytes) continue;
+      bool ok = true;
+      for (int r : rad) ok = ok && ((L / r) * 2 * cand <= (int64_t)sfft::kStockhamMaxThreads * sfft::stockham_kmax(r));
+      if (ok) { P = cand; break; }
+    }
+    if (P < 1) return fail(SPECTRE_E_UNSUPPORTED, "gate gradient: n_fft=%lld does not fit the LDS (transform length %lld)", (long long)n, (long long)L);
+    sfft::StockhamArgs k{};
+    k.v = a->v; k.gate = reinterpret_cast<const float2*>(a->gate); k.mem = nullptr; k.out = nullptr;
+    k.B = (int)a->B; k.N_in = (int)std::min<int64_t>(a->N_in, (int64_t)1 << 30); k.N = (int)n; k.D = (int)D; k.G = (int)a->G_tot;
+    k.d_g = (int)d_g; k.F = (int)(n / 2 + 1);
+    k.P = (int)P; k.S = (int)S; k.solo = solo; k.groups_per_batch = (int)((S + P - 1) / P);
+    k.in_bf16 = a->io_dtype == SPECTRE_BF16; k.out_bf16 = 0;
+    k.v_sb = a->v_sb; k.v_sn = a->v_sn;
+    k.L = (int)L; k.n_pass = (int)rad.size();
+    for (int i = 0; i < k.n_pass; ++i) k.radix_packed[i / 8] |= (unsigned long long)rad[(size_t)i] << (8 * (i % 8));
+    k.tw = plan->bluestein ? plan->tw_m : plan->tw_n;
+    k.bluestein = plan->bluestein ? 1 : 0; k.chirp = plan->chirp; k.bhat = plan->bhat;
+    k.dout = a->dout; k.dout_sb = a->dout_sb; k.dout_sn = a->dout_sn; k.ws = reinterpret_cast<float2*>(a->workspace);
+    hipError_t e = hipMemsetAsync(a->workspace, 0, (size_t)spectre_mix_bwd_workspace_bytes(a->B, n, a->G_tot), stream);
+    if (e != hipSuccess) return fail(SPECTRE_E_HIP, "hipMemsetAsync: %s", hipGetErrorString(e));
+    const size_t lds = (size_t)2 * k.L * k.P * sizeof(float2);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(sfft::spectre_gate_grad_stockham),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(SPECTRE_E_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(sfft::spectre_gate_grad_stockham, dim3((unsigned)(a->B * k.groups_per_batch)), dim3(sfft::kStockhamMaxThreads),
+                       lds, stream, k);
+    const int64_t total = a->B * a->G_tot * (n / 2 + 1);
+    hipLaunchKernelGGL(sfft::spectre_gate_grad_finish, dim3((unsigned)std::min<int64_t>(4096, (total + 255) / 256)), dim3(256), 0, stream,
+                       reinterpret_cast<const float2*>(a->workspace), reinterpret_cast<float2*>(a->dgate), (int)(a->B * a->G_tot), (int)n,
+                       (int)(n / 2 + 1));
+    if ((e = hipGetLastError()) != hipSuccess) return fail(SPECTRE_E_HIP, "gate-gradient launch failed: %s", hipGetErrorString(e));
+  }
   return SPECTRE_OK;
 }
 

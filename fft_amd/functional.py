@@ -91,6 +91,56 @@ def spectral_mix(V: torch.Tensor, gate: torch.Tensor, memory_fft: Optional[torch
     return out
 
 
+def spectral_mix_backward(V: torch.Tensor, gate: torch.Tensor, grad_out: torch.Tensor, n_fft: Optional[int] = None, *,
+                          need_dv: bool = True, need_dgate: bool = True):
+    """Gradients of `spectral_mix` w.r.t. V and gate for an upstream gradient `grad_out` (B, min(N, n_fft), D).
+
+    dV = mix(grad_out, conj(gate)) (the forward kernels with the conjugated filter), zero for rows the forward
+    truncated; dgate[b,g,k] = (w_k/n_fft) * sum_{c in g} conj(rfft(V)[k,c]) * rfft(grad_out)[k,c].  What autograd derives
+    through `torch.fft.rfft/irfft` in the reference (spectre.py:506, :542-553).  Returns (dV or None, dgate or None).
+    """
+    lib = _native.load()
+    if n_fft is None:
+        n_fft = V.shape[1]
+    if not V.is_cuda:
+        raise RuntimeError("spectral_mix_backward runs on a HIP device only (no CPU path)")
+    if V.dtype not in _DT or grad_out.dtype != V.dtype:
+        raise TypeError("V and grad_out must share a dtype (float32 or bfloat16)")
+    B, N, D = V.shape
+    F = n_fft // 2 + 1
+    n_out = min(N, n_fft)
+    if tuple(grad_out.shape) != (B, n_out, D):
+        raise ValueError(f"grad_out must be {(B, n_out, D)}, got {tuple(grad_out.shape)}")
+    if gate.dim() != 3 or gate.shape[0] != B or gate.shape[2] != F or gate.dtype != torch.complex64 or D % gate.shape[1]:
+        raise ValueError(f"gate must be (B={B}, G, F={F}) complex64 with G | D")
+    if V.stride(2) != 1:
+        V = V.contiguous()
+    if grad_out.stride(2) != 1:
+        grad_out = grad_out.contiguous()
+    gate = gate.contiguous()
+    G = gate.shape[1]
+    dv = torch.empty((B, N, D), dtype=V.dtype, device=V.device) if need_dv else None
+    dgate = torch.empty((B, G, F), dtype=torch.complex64, device=V.device) if need_dgate else None
+    ws = None
+    if need_dgate:
+        ws = torch.empty(lib.spectre_mix_bwd_workspace_bytes(B, n_fft, G), dtype=torch.uint8, device=V.device)
+    a = _native.SpectreMixBwdArgs()
+    a.v, a.gate, a.dout = V.data_ptr(), gate.data_ptr(), grad_out.data_ptr()
+    a.dv = dv.data_ptr() if dv is not None else None
+    a.dgate = dgate.data_ptr() if dgate is not None else None
+    a.workspace = ws.data_ptr() if ws is not None else None
+    a.B, a.N_in, a.n_fft, a.D, a.G_tot = B, N, n_fft, D, G
+    a.v_sb, a.v_sn = V.stride(0), V.stride(1)
+    a.dout_sb, a.dout_sn = grad_out.stride(0), grad_out.stride(1)
+    if dv is not None:
+        a.dv_sb, a.dv_sn = dv.stride(0), dv.stride(1)
+    a.io_dtype = _DT[V.dtype]
+    a.device = V.device.index if V.device.index is not None else torch.cuda.current_device()
+    a.stream = torch.cuda.current_stream(V.device).cuda_stream
+    _native.check(lib.spectre_mix_bwd(ctypes.byref(a)), "spectre_mix_bwd")
+    return dv, dgate
+
+
 def describe(V, gate, memory_fft=None, n_fft=None, *, out_dtype=None, algo="auto") -> str:
     """Name of the kernel `spectral_mix` would launch for these arguments."""
     lib = _native.load()

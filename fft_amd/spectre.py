@@ -12,8 +12,8 @@ What runs where
 * rfft -> gate multiply -> (+memory) -> irfft -> slice (spectre.py:506, :542-553): `fft_amd.functional.
   spectral_mix`, one fused gfx950 kernel through the C ABI.  HIP device only; CPU tensors raise.
 
-Forward only for now: the spectral mix is wrapped in an autograd.Function whose backward raises
-(SURVEY.md section 8(f), row N1).
+Training: the spectral mix is an autograd.Function; dV runs the same kernels with the conjugated filter and
+dgate a spectrum-product reduction kernel.
 """
 from __future__ import annotations
 
@@ -25,7 +25,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .functional import spectral_mix
+from .functional import spectral_mix, spectral_mix_backward
 
 try:  # optional, exactly as the reference treats it (spectre.py:10-14)
     import torch_dct as _dct
@@ -113,15 +113,24 @@ class MeanPool(nn.Module):
 # the fused op as an autograd node (forward only)
 # --------------------------------------------------------------------------------------------------
 class _SpectralMixFn(torch.autograd.Function):
+    """autograd node of the fused mix: dV reuses the forward kernels with conj(gate), dgate is a spectrum product
+    reduced over the channels of each group (fft_amd.functional.spectral_mix_backward)."""
+
     @staticmethod
     def forward(ctx, V, gate, memory_fft, n_fft):
+        if memory_fft is not None and memory_fft.requires_grad:
+            raise NotImplementedError("fft_amd: memory_fft is a frozen buffer in the reference (spectre.py:951-959); "
+                                      "its gradient is not implemented")
+        ctx.save_for_backward(V, gate)
+        ctx.n_fft = n_fft
         return spectral_mix(V, gate, memory_fft, n_fft)
 
     @staticmethod
-    def backward(ctx, *grads):  # pragma: no cover
-        raise NotImplementedError(
-            "fft_amd: backward of the fused spectral mix is not implemented yet (forward-only scope); "
-            "run under torch.no_grad() / inference_mode()")
+    def backward(ctx, grad_out):
+        V, gate = ctx.saved_tensors
+        dv, dgate = spectral_mix_backward(V, gate, grad_out.contiguous(), ctx.n_fft,
+                                          need_dv=ctx.needs_input_grad[0], need_dgate=ctx.needs_input_grad[1])
+        return dv, dgate, None, None
 
 
 # --------------------------------------------------------------------------------------------------

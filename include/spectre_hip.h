@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SPECTRE_ABI_VERSION 1
+#define SPECTRE_ABI_VERSION 2
 
 enum {
   SPECTRE_OK = 0,
@@ -89,6 +89,30 @@ int spectre_mix_describe(const SpectreMixArgs* args, char* buf, size_t cap);
  * graph-captured region.  Destroying a cached plan is allowed only when no launch using it is in flight. */
 int spectre_plan_create(int device, int64_t n_fft);
 int spectre_plan_destroy(int device, int64_t n_fft);
+
+/* Backward of spectre_mix_fwd (autograd through spectre.py:506, :542-553):
+ *   dv    (B, N_in, D)   = mix(dout, conj(gate))  zero-padded back to N_in rows   — same kernels as the forward
+ *   dgate (B, G_tot, F)  = (w_k / n_fft) * sum_{c in group} conj(rfft(v)[k, c]) * rfft(dout)[k, c],  w_k = 2 (1 at DC/Nyquist)
+ * `dout` is (B, min(N_in, n_fft), D) with the dtype of `v`; `dv` has the dtype of `v`; `dgate` is complex64.
+ * Either output may be NULL.  `workspace` must hold spectre_mix_bwd_workspace_bytes() bytes when dgate != NULL
+ * (the library zeroes it on the stream).  memory_fft gets no gradient: it is a frozen buffer in the reference
+ * (spectre.py:951-959). */
+typedef struct SpectreMixBwdArgs {
+  const void* v;
+  const void* gate;
+  const void* dout;
+  void* dv;      /* nullable */
+  void* dgate;   /* nullable */
+  void* workspace;
+  int64_t B, N_in, n_fft, D, G_tot;
+  int64_t v_sb, v_sn, dout_sb, dout_sn, dv_sb, dv_sn; /* element strides */
+  int32_t io_dtype;   /* SPECTRE_F32 | SPECTRE_BF16 for v, dout and dv */
+  int32_t device;
+  void* stream;
+} SpectreMixBwdArgs;
+
+int64_t spectre_mix_bwd_workspace_bytes(int64_t B, int64_t n_fft, int64_t G_tot);
+int spectre_mix_bwd(const SpectreMixBwdArgs* args);
 
 /* Measurement helper used by bench.py: runs `warmup` untimed + `iters` timed launches of the same
  * arguments on args->stream, bracketed by HIP events recorded on that stream, and returns the average

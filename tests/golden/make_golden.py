@@ -151,6 +151,34 @@ def case_fixed_gate(name, B, N, d, n_fft, G, seed, gate_fn, *, bf16=False, with_
     _save(name, x=x, head=head, V=V, gate=gate, out=out, mem=mem, extra=extra, with_sd=False)
 
 
+def case_backward(name, B, N, d, n_fft, G, seed):
+    """Gradients the reference's autograd produces at the inputs of the hot path (V = W_v(x), gate = modReLU output)
+    for a fixed upstream gradient dout: the N1 row of SURVEY.md section 8(f)."""
+    head = _head(d, n_fft, G, seed)
+    g = torch.Generator().manual_seed(seed + 3000)
+    x = torch.randn(B, N, d, generator=g)
+    cap = {}
+
+    def keep(key):
+        def hook(m, i, o):
+            o.retain_grad()
+            cap[key] = o
+        return hook
+    h1 = head.W_v.register_forward_hook(keep("V"))
+    h2 = head.modrelu.register_forward_hook(keep("g"))
+    out = head(x)
+    h1.remove()
+    h2.remove()
+    dout = torch.randn(out.shape, generator=g)
+    (out * dout).sum().backward()
+    V, gflat = cap["V"], cap["g"]
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, V=V.detach().numpy(), gate=gflat.detach().reshape(B, G, head.F_half).numpy().astype(np.complex64),
+                        dout=dout.numpy(), dV=V.grad.numpy(), dgate=gflat.grad.reshape(B, G, head.F_half).numpy().astype(np.complex64),
+                        out=out.detach().numpy(), n_fft=np.int64(n_fft), G=np.int64(G))
+    print(f"{name:28s} backward x{tuple(x.shape)} dV{tuple(V.grad.shape)} dgate{(B, G, head.F_half)}  {os.path.getsize(path) / 1e3:.0f} kB")
+
+
 def g_random(scale=0.3, zero_frac=0.18):
     def f(B, G, F, gen):
         z = torch.complex(torch.randn(B, G, F, generator=gen), torch.randn(B, G, F, generator=gen)) * scale
@@ -209,6 +237,13 @@ def main():
     case_fixed_gate("g7_n1024", 1, 1024, 16, 1024, 4, 19, g_random())
     case_fixed_gate("g7_n4096", 1, 4096, 16, 4096, 4, 20, g_random())
     case_fixed_gate("g7_n2048_mem", 1, 2048, 16, 2048, 2, 21, g_random(), with_mem=True)
+    # G9 — backward (reference autograd) at the hot path's inputs
+    case_backward("g9_bwd_n64", 2, 64, 16, 64, 2, 24)
+    case_backward("g9_bwd_n256", 2, 256, 32, 256, 4, 25)
+    case_backward("g9_bwd_pad_n50_fft64", 2, 50, 16, 64, 2, 26)
+    case_backward("g9_bwd_trunc_n80_fft64", 2, 80, 16, 64, 2, 27)
+    case_backward("g9_bwd_n60", 2, 60, 12, 60, 2, 28)
+    case_backward("g9_bwd_n1024", 1, 1024, 16, 1024, 2, 29)
     # G8 — bf16 input values; oracle = reference on x_bf16.float(); bf16 rounding of the result stored
     case_fixed_gate("g8_bf16_n1024", 1, 1024, 16, 1024, 4, 22, g_random(), bf16=True)
     case_fixed_gate("g8_bf16_n4096", 1, 4096, 16, 4096, 4, 23, g_random(), bf16=True)

@@ -59,9 +59,19 @@ def test_no_cpu_fallback_in_product_path():
     g = torch.ones(1, 2, 9, dtype=torch.complex64)
     with pytest.raises(RuntimeError, match="HIP device only"):
         spectral_mix(V, g, None, 16)
+    import ast
     for root, _, files in os.walk(os.path.join(ROOT, "fft_amd")):
         for f in files:
-            if f.endswith((".py", ".hip", ".h")):
-                src = open(os.path.join(root, f)).read()
-                assert "import oracle" not in src and "from oracle" not in src, f
-                assert "torch.fft" not in src.replace("torch.fft.rfft(V", "").replace("torch.fft.irfft(mixed", ""), f
+            path = os.path.join(root, f)
+            if f.endswith((".hip", ".h")):
+                src = open(path).read()
+                assert "hipfft" not in src.lower() and "rocfft" not in src.lower(), f
+            if not f.endswith(".py"):
+                continue
+            tree = ast.parse(open(path).read())
+            for node in ast.walk(tree):
+                if isinstance(node, (ast.Import, ast.ImportFrom)):
+                    names = [a.name for a in node.names] + [getattr(node, "module", None) or ""]
+                    assert not any(n.split(".")[0] == "oracle" for n in names), f"{f} imports the oracle"
+                if isinstance(node, ast.Attribute) and node.attr == "fft" and isinstance(node.value, ast.Name) and node.value.id == "torch":
+                    raise AssertionError(f"{f} calls torch.fft (line {node.lineno}): the product path must be the HIP kernel")

@@ -1,0 +1,88 @@
+"""spectre_mix_bwd on a real GPU: reference-autograd fixtures, the fp64 closed form at more shapes, and autograd
+through the drop-in module."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle.spectral_mix_oracle import assert_close, spectral_mix_backward_numpy
+from test_backward_cpu import BWD, IDS
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _bwd(V, gate, dout, n_fft, **k):
+    from fft_amd import spectral_mix_backward
+    dv, dg = spectral_mix_backward(V.to(DEV), gate.to(DEV), dout.to(DEV), n_fft, **k)
+    torch.cuda.synchronize()
+    return dv, dg
+
+
+def _check(dv, dg, dV_ref, dg_ref, what):
+    assert_close(dv.float().cpu().numpy(), dV_ref, what=what + " dV")
+    assert_close(torch.view_as_real(dg).cpu().numpy(), np.ascontiguousarray(dg_ref).astype(np.complex64).view(np.float32).reshape(*dg_ref.shape, 2),
+                 what=what + " dgate")
+
+
+@pytest.mark.parametrize("path", BWD, ids=IDS)
+def test_reference_autograd_fixtures(path):
+    d = load_golden(path)
+    dv, dg = _bwd(torch.from_numpy(d["V"]), torch.from_numpy(d["gate"]), torch.from_numpy(d["dout"]), int(d["n_fft"]))
+    _check(dv, dg, d["dV"], d["dgate"], path)
+
+
+SHAPES = [(2, 4096, 64, 4, 4096), (2, 2048, 32, 2, 2048), (3, 1024, 48, 3, 1024), (2, 512, 32, 4, 512), (2, 256, 32, 2, 256),
+          (2, 3000, 32, 2, 3000), (2, 97, 12, 2, 97), (2, 1000, 32, 2, 1024), (2, 5000, 32, 2, 4096), (2, 60, 6, 2, 60), (2, 64, 10, 2, 64)]
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=[f"B{s[0]}_N{s[1]}_D{s[2]}_G{s[3]}_fft{s[4]}" for s in SHAPES])
+def test_random_vs_fp64_closed_form(shape):
+    B, N, D, G, n_fft = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    V = torch.randn(B, N, D, generator=g)
+    F = n_fft // 2 + 1
+    gate = (torch.complex(torch.randn(B, G, F, generator=g), torch.randn(B, G, F, generator=g)) * 0.3).to(torch.complex64)
+    dout = torch.randn(B, min(N, n_fft), D, generator=g)
+    dV_ref, dg_ref = spectral_mix_backward_numpy(V.numpy(), gate.numpy(), dout.numpy(), n_fft)
+    dv, dg = _bwd(V, gate, dout, n_fft)
+    _check(dv, dg, dV_ref, dg_ref, str(shape))
+    # each output alone
+    dv2, none = _bwd(V, gate, dout, n_fft, need_dgate=False)
+    assert none is None and torch.equal(dv2, dv)
+    none, dg2 = _bwd(V, gate, dout, n_fft, need_dv=False)
+    assert none is None
+    assert_close(torch.view_as_real(dg2).cpu().numpy(), torch.view_as_real(dg).cpu().numpy(), rtol=1e-5, atol_rms=1e-5)   # atomics: order varies
+
+
+def test_bf16_backward():
+    g = torch.Generator().manual_seed(5)
+    V = torch.randn(2, 1024, 32, generator=g).bfloat16()
+    gate = (torch.complex(torch.randn(2, 2, 513, generator=g), torch.randn(2, 2, 513, generator=g)) * 0.3).to(torch.complex64)
+    dout = torch.randn(2, 1024, 32, generator=g).bfloat16()
+    dV_ref, dg_ref = spectral_mix_backward_numpy(V.float().numpy(), gate.numpy(), dout.float().numpy(), 1024)
+    dv, dg = _bwd(V, gate, dout, 1024)
+    assert dv.dtype == torch.bfloat16
+    assert_close(dv.float().cpu().numpy(), dV_ref, rtol=1e-2, atol_rms=1e-2, what="bf16 dV")      # bf16 storage of dV
+    assert_close(torch.view_as_real(dg).cpu().numpy(), dg_ref.astype(np.complex64).view(np.float32).reshape(2, 2, 513, 2), what="dgate")
+
+
+def test_module_autograd_matches_torch_fft_autograd():
+    """Gradients of the drop-in module's parameters == gradients of the same module with the hot path written in
+    torch.fft (the reference's statements), both on the GPU."""
+    from fft_amd import SpectreHead
+    torch.manual_seed(0)
+    head = SpectreHead(32, 256, num_groups=2, pooling_type="mean").to(DEV)
+    x = torch.randn(2, 256, 32, device=DEV)
+    w = torch.randn(2, 256, 32, device=DEV)
+    (head(x) * w).sum().backward()
+    got = {k: p.grad.clone() for k, p in head.named_parameters()}
+    head.zero_grad()
+    V, gate, _ = head.spectral_gate(x)
+    vf = torch.fft.rfft(V, n=256, dim=1)
+    y = torch.fft.irfft(gate.permute(0, 2, 1).repeat_interleave(head.d_g, dim=-1) * vf, n=256, dim=1)[:, :256]
+    (y * w).sum().backward()
+    for k, p in head.named_parameters():
+        ref = p.grad
+        scale = float(ref.abs().max()) + 1e-12
+        assert float((got[k] - ref).abs().max()) <= 2e-3 * scale, k

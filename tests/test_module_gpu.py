@@ -26,10 +26,11 @@ def test_module_forward_matches_reference(path, cid):
     assert_close(out.cpu().numpy(), d["out"], rtol=1e-4, atol_rms=2e-4, what=cid)
 
 
-def test_grad_mode_raises_not_silently_wrong():
+def test_memory_fft_gradient_is_refused_not_silently_dropped():
     from fft_amd import SpectreHead
     head = SpectreHead(32, 256, num_groups=2, pooling_type="mean").to("cuda:0")
     x = torch.randn(2, 256, 32, device="cuda:0")
-    y = head(x)                                                     # forward works under grad mode
-    with pytest.raises(NotImplementedError, match="backward"):
-        y.sum().backward()
+    mem = torch.randn(129, 32, dtype=torch.complex64, device="cuda:0", requires_grad=True)
+    with pytest.raises(NotImplementedError, match="memory_fft"):
+        head(x, memory_fft=mem)
+    head(x, memory_fft=mem.detach()).sum().backward()               # frozen memory (as in the reference) trains fine
