@@ -31,6 +31,12 @@
 #include <stdint.h>
 #include "fft_regs.h"
 
+// LDS image layout per (RF, RS): 1 = [row][column][slot] with 16-byte reads, 0 = [row][slot][column] with 4-byte reads.
+// The 16-byte layout needs 4 floats of padding per column instead of 8 per row; at n_fft = 2048 that pushes the image
+// from 74 KiB to 82 KiB per workgroup, i.e. from two workgroups per CU to one (1.17 ms instead of 0.71 ms), so that size
+// keeps the 4-byte layout.  Everywhere else the 16-byte reads win 2-3 % (profiles/r01_ablation.log).
+#define SFFT_EXCHANGE_B128(RF, RS) (((RF) == 64 && (RS) == 32) ? 0 : 1)
+
 namespace sfft {
 
 struct RegtileArgs {
@@ -52,9 +58,12 @@ constexpr int kPC = 8;                       // pair-columns per tile: 16 channe
 template <int RF, int RS> constexpr int regtile_threads() { return kPC * RS; }
 // LDS exchange image, one float plane: E1 is [RF rows][RS sources][8 columns], E2 is [RS rows][RF sources][8];
 // every row is padded by 32 bytes so that the 4 team indices of a 32-lane group read from distinct banks
-template <int RF, int RS> constexpr int regtile_image_bytes() { return RF * RS * kPC * 4 + (RF > RS ? RF : RS) * kPC * 4; }
+template <int RF, int RS, int XV = SFFT_EXCHANGE_B128(RF, RS)> constexpr int regtile_image_bytes() {
+  return XV ? (RF * kPC * (RS + 4) > RS * kPC * (RF + 4) ? RF * kPC * (RS + 4) : RS * kPC * (RF + 4)) * 4
+            : RF * RS * kPC * 4 + (RF > RS ? RF : RS) * kPC * 4;
+}
 template <int RF, int RS> constexpr int regtile_gate_lds_bytes() { return (RF * RS / 2 + 1) * 8; }   // half-spectrum gate
-template <int RF, int RS> constexpr int regtile_lds_total() { return regtile_image_bytes<RF, RS>() + regtile_gate_lds_bytes<RF, RS>(); }
+template <int RF, int RS, int XV = SFFT_EXCHANGE_B128(RF, RS)> constexpr int regtile_lds_total() { return regtile_image_bytes<RF, RS, XV>() + regtile_gate_lds_bytes<RF, RS>(); }
 
 // Workgroup id -> position.  Workgroup w is observed to run on XCD w % 8 (speed only, never correctness): give
 // every XCD a contiguous run of tiles so tiles sharing 128-B lines meet in one L2.  Bijective for any n.
@@ -100,11 +109,42 @@ __device__ __forceinline__ void exchange_planes(float2 (&z)[E], float* img, WR w
   __syncthreads();                         // image free again for the next exchange
 }
 
+// Variant with 16-byte reads: image laid out [row][column p][slot], slot fastest, every column padded by 4 floats.
+// A thread's slots of one row are then contiguous, so each plane is read with E/4 ds_read_b128 (256 B/clk) instead of
+// E/2 ds_read2_b32 (128 B/clk); the ds_write_b32 side stays conflict-free (bank = 4p + row class), as are the b128
+// reads (checked for every (RF, RS) with the lane-group table of MI355X_MICROARCH.md).  wr(j) -> float index of
+// position j; rd4(m4) -> float index of the 4 slots m4..m4+3 (16-byte aligned).
+template <int E, int RA, int RB, class WR, class RD4>
+__device__ __forceinline__ void exchange_planes_b128(float2 (&z)[E], float* img, WR wr, RD4 rd4) {
+  constexpr int SUB = RA * RB;             // consumer works on sub-arrays of SUB values
+  auto read_plane = [&](auto is_im) {
+    static_for<0, E / 4>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      // chunk order: within each sub-array, chunks holding slots {RB*q1 + 0..3} first (q1 = 0..RA-1), then +4..7, ...
+      constexpr int CPS = SUB / 4, CPR = (RB >= 4 ? RB / 4 : 1);     // chunks per sub-array, chunks per RB-run
+      constexpr int sub = i / CPS, ii = i % CPS;
+      constexpr int chunk = (RB >= 4) ? (ii / RA) + CPR * (ii % RA) : ii;
+      constexpr int m = sub * SUB + 4 * chunk;
+      const float4 v = *reinterpret_cast<const float4*>(img + rd4(std::integral_constant<int, m>{}));
+      if constexpr (decltype(is_im)::value) { z[m].y = v.x; z[m + 1].y = v.y; z[m + 2].y = v.z; z[m + 3].y = v.w; }
+      else { z[m].x = v.x; z[m + 1].x = v.y; z[m + 2].x = v.z; z[m + 3].x = v.w; }
+    });
+  };
+  static_for<0, E>([&](auto jc) { constexpr int j = decltype(jc)::value; img[wr(jc)] = z[j].x; });
+  __syncthreads();
+  read_plane(std::false_type{});
+  __syncthreads();
+  static_for<0, E>([&](auto jc) { constexpr int j = decltype(jc)::value; img[wr(jc)] = z[j].y; });
+  __syncthreads();
+  read_plane(std::true_type{});
+  __syncthreads();                         // image free again for the next exchange
+}
+
 // MODE 0 (fast): N_in >= n_fft (no row predicates), no memory_fft, every tile inside one gate group (gate staged in LDS).
 // MODE 1 (general): row predicates, any even d_g (gate read from global memory).  MODE 2: general + memory_fft.
 // ABL (ablation switches, tools/ablate_bench.hip only; 0 in the library): bit0 = no global loads/stores,
 // bit1 = no butterflies/twiddles/gate, bit2 = no LDS exchanges, bit3 = constant gate.
-template <int RF, int RS, bool IN_BF16, bool OUT_BF16, int MODE, int ABL = 0>
+template <int RF, int RS, bool IN_BF16, bool OUT_BF16, int MODE, int ABL = 0, int XV = SFFT_EXCHANGE_B128(RF, RS)>
 __global__ void __launch_bounds__(kPC * RS) spectre_mix_regtile(const RegtileArgs a) {
   constexpr bool GENERAL = MODE != 0, WITH_MEM = MODE == 2, GATE_LDS = MODE == 0;
   constexpr bool NO_IO = (ABL & 1) != 0, NO_MATH = (ABL & 2) != 0, NO_LDS = (ABL & 4) != 0, NO_GATE = (ABL & 8) != 0;
@@ -117,7 +157,7 @@ __global__ void __launch_bounds__(kPC * RS) spectre_mix_regtile(const RegtileArg
   constexpr float inv_n = 1.0f / (float)N;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* img = reinterpret_cast<float*>(smem);
-  float2* glds = reinterpret_cast<float2*>(smem + regtile_image_bytes<RF, RS>());
+  float2* glds = reinterpret_cast<float2*>(smem + regtile_image_bytes<RF, RS, XV>());
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -212,11 +252,20 @@ __global__ void __launch_bounds__(kPC * RS) spectre_mix_regtile(const RegtileArg
 
   // ---- E1: position j (k1 = ka + RAF*kb) -> image row k1, column (u, p); thread s reads rows s + RS*t ----
   if constexpr (!NO_LDS) {
-    exchange_planes<RF, RAS, RBS>(z, img,
-        [&](auto jc) { constexpr int j = decltype(jc)::value; constexpr int k1 = (j / RBF) + RAF * (j % RBF);
-                       return k1 * ROW1 + u * kPC + p; },
-        [&](auto mc) { constexpr int m = decltype(mc)::value; constexpr int t = m / RS, n2 = m % RS;
-                       return (u + RS * t) * ROW1 + n2 * kPC + p; });
+    if constexpr (XV) {
+      constexpr int PS = RS + 4, RW = kPC * PS;      // column stride, row stride (floats)
+      exchange_planes_b128<RF, RAS, RBS>(z, img,
+          [&](auto jc) { constexpr int j = decltype(jc)::value; constexpr int k1 = (j / RBF) + RAF * (j % RBF);
+                         return k1 * RW + p * PS + u; },
+          [&](auto mc) { constexpr int m = decltype(mc)::value; constexpr int t = m / RS, n2 = m % RS;
+                         return (u + RS * t) * RW + p * PS + n2; });
+    } else {
+      exchange_planes<RF, RAS, RBS>(z, img,
+          [&](auto jc) { constexpr int j = decltype(jc)::value; constexpr int k1 = (j / RBF) + RAF * (j % RBF);
+                         return k1 * ROW1 + u * kPC + p; },
+          [&](auto mc) { constexpr int m = decltype(mc)::value; constexpr int t = m / RS, n2 = m % RS;
+                         return (u + RS * t) * ROW1 + n2 * kPC + p; });
+    }
   }
 
   // ---- middle: per set t (k1 = u + RS*t):  F2 stage 1, then per register group  F2 stage 2 -> gate -> I1 stage 1,
@@ -295,10 +344,18 @@ __global__ void __launch_bounds__(kPC * RS) spectre_mix_regtile(const RegtileArg
 
   // ---- E2: position t*RS + n2 -> image row n2, column (k1 = u + RS*t, p); thread u reads its row, slot k1 ----
   if constexpr (!NO_LDS) {
-    exchange_planes<RF, RAF, RBF>(z, img,
-        [&](auto jc) { constexpr int j = decltype(jc)::value; constexpr int t = j / RS, n2 = j % RS;
-                       return n2 * ROW2 + (u + RS * t) * kPC + p; },
-        [&](auto mc) { constexpr int m = decltype(mc)::value; return u * ROW2 + m * kPC + p; });
+    if constexpr (XV) {
+      constexpr int PS = RF + 4, RW = kPC * PS;
+      exchange_planes_b128<RF, RAF, RBF>(z, img,
+          [&](auto jc) { constexpr int j = decltype(jc)::value; constexpr int t = j / RS, n2 = j % RS;
+                         return n2 * RW + p * PS + (u + RS * t); },
+          [&](auto mc) { constexpr int m = decltype(mc)::value; return u * RW + p * PS + m; });
+    } else {
+      exchange_planes<RF, RAF, RBF>(z, img,
+          [&](auto jc) { constexpr int j = decltype(jc)::value; constexpr int t = j / RS, n2 = j % RS;
+                         return n2 * ROW2 + (u + RS * t) * kPC + p; },
+          [&](auto mc) { constexpr int m = decltype(mc)::value; return u * ROW2 + m * kPC + p; });
+    }
   }
 
   // ---- conj twiddle, I2 and store (spectre.py:553 keeps rows < min(N, n_fft)) -----------------------------

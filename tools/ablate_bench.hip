@@ -11,11 +11,11 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 using namespace sfft;
 
-template <int ABL, bool BF>
+template <int ABL, bool BF, int XV = 1>
 void run(const char* name, RegtileArgs a) {
   constexpr int PC = 8;
-  auto kern = spectre_mix_regtile<64, 64, BF, BF, 0, ABL>;
-  const size_t lds = regtile_lds_total<64, 64>();
+  auto kern = spectre_mix_regtile<64, 64, BF, BF, 0, ABL, XV>;
+  const size_t lds = regtile_lds_total<64, 64, XV>();
   a.tiles_per_row = a.D / (2 * PC); a.n_tiles = a.B * a.tiles_per_row;
   if (a.tpw < 1) a.tpw = 1;
   a.n_wg = 2 * ((a.n_tiles + 2 * a.tpw - 1) / (2 * a.tpw));
@@ -28,7 +28,7 @@ void run(const char* name, RegtileArgs a) {
   for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kern, dim3(a.n_wg), dim3(PC * 64), lds, 0, a);
   CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
-  printf("%-44s %s PC=%d : %7.3f ms   %6.2f us/(16-channel tile)/CU\n", name, BF ? "bf16" : "f32 ", PC, ms, ms * 1e3 * 256 / (a.B * a.D / 16));
+  printf("%-44s %s XV=%d PC=%d : %7.3f ms   %6.2f us/(16-channel tile)/CU\n", name, BF ? "bf16" : "f32 ", XV, PC, ms, ms * 1e3 * 256 / (a.B * a.D / 16));
 }
 
 int main() {
@@ -52,16 +52,17 @@ int main() {
   a.v = v; a.gate = gate; a.mem = nullptr; a.out = out; a.tw = tw;
   a.B = B; a.N_in = N; a.D = D; a.G = G; a.d_g = D / G; a.F = F; a.tiles_per_row = D / 16; a.n_tiles = B * (D / 16);
   a.v_sb = (long long)N * D; a.v_sn = D; a.out_sb = (long long)N * D; a.out_sn = D;
-  run<0, false>("full kernel", a);
-  run<8, false>("full, constant gate (no gate loads)", a);
-  run<4, false>("no LDS exchange (I/O + math)", a);
-  run<12, false>("no LDS, no gate loads", a);
-  run<1, false>("no HBM I/O (math + LDS)", a);
-  run<9, false>("no HBM I/O, no gate loads", a);
-  run<5, false>("math only", a);
-  run<13, false>("math only, no gate loads", a);
+  for (int rep = 0; rep < 3; ++rep) {
+    run<0, false, 0>("full kernel", a);
+    run<0, false, 1>("full kernel", a);
+  }
+  run<1, false, 0>("no HBM I/O (math + LDS)", a);
+  run<1, false, 1>("no HBM I/O (math + LDS)", a);
+  run<3, false, 0>("LDS exchange only", a);
+  run<3, false, 1>("LDS exchange only", a);
+  run<0, true, 0>("full kernel", a);
+  run<0, true, 1>("full kernel", a);
   run<6, false>("I/O only", a);
   run<7, false>("empty", a);
-  run<15, false>("empty, no gate", a);
   return 0;
 }
