@@ -254,8 +254,11 @@ __global__ void __launch_bounds__(kStockhamMaxThreads) spectre_mix_stockham(cons
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float2* buf = reinterpret_cast<float2*>(smem_raw);
   const int P = a.P, N = a.N;
-  const int b = blockIdx.x / a.groups_per_batch;
-  const int slot0 = (blockIdx.x - b * a.groups_per_batch) * P;
+  // neighbouring channel groups share 128-byte lines: keep them on one XCD (same L2), as the register kernel does —
+  // in launch order the 48-byte segments of N = 3000 were fetched 3.4x over (rocprofv3 FETCH_SIZE)
+  const int wg = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int b = wg / a.groups_per_batch;
+  const int slot0 = (wg - b * a.groups_per_batch) * P;
   const int n_out = a.N_in < N ? a.N_in : N;
 
   // ---- load (zero-pad / truncate to n_fft, spectre.py:506) ----------------------------------------
@@ -351,8 +354,9 @@ __global__ void __launch_bounds__(kStockhamMaxThreads) spectre_gate_grad_stockha
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float2* buf = reinterpret_cast<float2*>(smem_raw);
   const int P = a.P, P2 = 2 * a.P, N = a.N;
-  const int b = blockIdx.x / a.groups_per_batch;
-  const int slot0 = (blockIdx.x - b * a.groups_per_batch) * P;
+  const int wg = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int b = wg / a.groups_per_batch;
+  const int slot0 = (wg - b * a.groups_per_batch) * P;
   const int n_dy = a.N_in < N ? a.N_in : N;        // rows of dOut (= rows the forward kept)
 
 #pragma unroll 2

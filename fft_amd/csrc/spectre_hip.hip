@@ -239,6 +239,7 @@ int choose(const SpectreMixArgs* a, const Plan* plan, Choice* c) {
   c->S = (int)(c->solo ? D : D / 2);
   int64_t P = (int64_t)kLdsBytes / (8 * L);
   if (P > 16) P = 16;
+  { static const int pmax = [] { const char* e = getenv("SPECTRE_STOCKHAM_PMAX"); return e ? atoi(e) : 0; }(); if (pmax > 0 && P > pmax) P = pmax; }
   if (P > c->S) P = c->S;
   for (int r : rad) {
     const int64_t cap = (int64_t)sfft::kStockhamMaxThreads * sfft::stockham_kmax(r) * r / L;
