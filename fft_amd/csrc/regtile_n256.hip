@@ -1,3 +1,3 @@
 // regtile_n256.hip — n_fft = 256 (= 16 x 16) instantiations of the register-resident kernel (own TU: parallel builds)
-#include "kernel_regtile.h"
-namespace sfft { SFFT_DEFINE_REGTILE_LAUNCHER(16, 16) }
+#include "kernel_regtile_grad.h"
+namespace sfft { SFFT_DEFINE_REGTILE_LAUNCHER(16, 16) SFFT_DEFINE_GATE_GRAD_LAUNCHER(16, 16) }

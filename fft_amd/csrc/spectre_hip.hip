@@ -17,7 +17,7 @@
 #include <vector>
 
 #include "../../include/spectre_hip.h"
-#include "kernel_regtile.h"
+#include "kernel_regtile_grad.h"
 #include "kernel_stockham.h"
 
 namespace sfft {
@@ -428,7 +428,8 @@ int spectre_mix_time(const SpectreMixArgs* a, int warmup, int iters, float* ms_p
 
 int64_t spectre_mix_bwd_workspace_bytes(int64_t B, int64_t n_fft, int64_t G_tot) {
   if (B < 0 || n_fft < 1 || G_tot < 1) return 0;
-  return B * G_tot * n_fft * (int64_t)sizeof(float2);
+  // Stockham path: (B, G, n_fft) spectrum sums; register-tile path: up to 8 partial half spectra per (batch, group)
+  return B * G_tot * std::max<int64_t>(n_fft, 8 * (n_fft / 2 + 1)) * (int64_t)sizeof(float2);
 }
 
 int spectre_mix_bwd(const SpectreMixBwdArgs* a) {
@@ -468,6 +469,43 @@ int spectre_mix_bwd(const SpectreMixBwdArgs* a) {
     Plan* plan = nullptr;
     if ((rc = get_plan(a->device, a->n_fft, &plan))) return rc;
     const int64_t n = a->n_fft, D = a->D, d_g = D / a->G_tot;
+    int RF = 0, RS = 0;
+    switch (n) {
+      case 256: RF = 16; RS = 16; break;
+      case 512: RF = 32; RS = 16; break;
+      case 1024: RF = 32; RS = 32; break;
+      case 2048: RF = 64; RS = 32; break;
+      case 4096: RF = 64; RS = 64; break;
+      default: break;
+    }
+    static const bool force_stockham = [] { const char* e = getenv("SPECTRE_GATE_GRAD"); return e && !strcmp(e, "stockham"); }();
+    if (RF && !force_stockham && a->v_sn * 64 * 4 < ((int64_t)1 << 31) && a->dout_sn * 64 * 4 < ((int64_t)1 << 31) &&
+        a->B * a->G_tot * 8 < ((int64_t)1 << 31)) {
+      // register-tile gate gradient (kernel_regtile_grad.h): 8-channel tiles, S workgroups per (batch, group)
+      sfft::GateGradArgs k{};
+      k.v = a->v; k.dout = a->dout; k.part = reinterpret_cast<float2*>(a->workspace); k.tw = plan->tw_n;
+      k.B = (int)a->B; k.N_in = (int)std::min<int64_t>(a->N_in, (int64_t)1 << 30); k.D = (int)D; k.G = (int)a->G_tot;
+      k.d_g = (int)d_g; k.F = (int)(n / 2 + 1);
+      k.T = (int)((d_g + 7) / 8);
+      int S = std::min(k.T, 4);
+      while (a->B * a->G_tot * S < 1024 && 2 * S <= std::min(k.T, 8)) S *= 2;
+      k.S = S; k.n_wg = (int)(a->B * a->G_tot * S);
+      k.v_sb = a->v_sb; k.v_sn = a->v_sn; k.dout_sb = a->dout_sb; k.dout_sn = a->dout_sn;
+      const bool bf = a->io_dtype == SPECTRE_BF16, general = (a->N_in < n) || (d_g % 8 != 0);
+      hipError_t e;
+      if (RF == 16) e = sfft::launch_gate_grad_regtile<16, 16>(k, bf, general, stream);
+      else if (RF == 32 && RS == 16) e = sfft::launch_gate_grad_regtile<32, 16>(k, bf, general, stream);
+      else if (RF == 32) e = sfft::launch_gate_grad_regtile<32, 32>(k, bf, general, stream);
+      else if (RS == 32) e = sfft::launch_gate_grad_regtile<64, 32>(k, bf, general, stream);
+      else e = sfft::launch_gate_grad_regtile<64, 64>(k, bf, general, stream);
+      if (e != hipSuccess) return fail(SPECTRE_E_HIP, "gate-gradient launch failed: %s", hipGetErrorString(e));
+      const int64_t total = a->B * a->G_tot * (n / 2 + 1);
+      hipLaunchKernelGGL(sfft::spectre_gate_grad_regtile_finish<0>, dim3((unsigned)std::min<int64_t>(4096, (total + 255) / 256)), dim3(256), 0,
+                         stream, reinterpret_cast<const float2*>(a->workspace), reinterpret_cast<float2*>(a->dgate), S, (int)(n / 2 + 1),
+                         (int)n, (long long)total);
+      if ((e = hipGetLastError()) != hipSuccess) return fail(SPECTRE_E_HIP, "gate-gradient finish failed: %s", hipGetErrorString(e));
+      return SPECTRE_OK;
+    }
     const int64_t L = plan->bluestein ? plan->m : n;
     const std::vector<int>& rad = plan->bluestein ? plan->radix_m : plan->radix_n;
     const int solo = (d_g % 2) ? 1 : 0;

@@ -33,7 +33,9 @@ def test_reference_autograd_fixtures(path):
 
 
 SHAPES = [(2, 4096, 64, 4, 4096), (2, 2048, 32, 2, 2048), (3, 1024, 48, 3, 1024), (2, 512, 32, 4, 512), (2, 256, 32, 2, 256),
-          (2, 3000, 32, 2, 3000), (2, 97, 12, 2, 97), (2, 1000, 32, 2, 1024), (2, 5000, 32, 2, 4096), (2, 60, 6, 2, 60), (2, 64, 10, 2, 64)]
+          (2, 3000, 32, 2, 3000), (2, 97, 12, 2, 97), (2, 1000, 32, 2, 1024), (2, 5000, 32, 2, 4096), (2, 60, 6, 2, 60), (2, 64, 10, 2, 64),
+          # register-tile gate gradient: ragged channel tiles (d_g = 6, 5, 20), many tiles per group (d_g = 200), short input
+          (2, 256, 12, 2, 256), (2, 512, 15, 3, 512), (3, 1024, 40, 2, 1024), (1, 2048, 200, 1, 2048), (2, 100, 24, 1, 256)]
 
 
 @pytest.mark.parametrize("shape", SHAPES, ids=[f"B{s[0]}_N{s[1]}_D{s[2]}_G{s[3]}_fft{s[4]}" for s in SHAPES])
@@ -52,7 +54,7 @@ def test_random_vs_fp64_closed_form(shape):
     assert none is None and torch.equal(dv2, dv)
     none, dg2 = _bwd(V, gate, dout, n_fft, need_dv=False)
     assert none is None
-    assert_close(torch.view_as_real(dg2).cpu().numpy(), torch.view_as_real(dg).cpu().numpy(), rtol=1e-5, atol_rms=1e-5)   # atomics: order varies
+    assert_close(torch.view_as_real(dg2).cpu().numpy(), torch.view_as_real(dg).cpu().numpy(), rtol=1e-5, atol_rms=1e-5)   # Stockham path: atomics, order varies
 
 
 def test_bf16_backward():
