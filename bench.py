@@ -154,6 +154,21 @@ def main():
             variants[name] = {"tokens_per_s": B * N / (ms * 1e-3), "kernel_ms": ms, "achieved_GBps": byt / ms / 1e6,
                               "roofline_frac": byt / ms / 1e6 / HBM_PEAK_GBS}
             del Vv, ov
+        # backward of the same op (row N1), informational: dV = the forward kernels with conj(gate); dgate = gate-gradient kernel
+        from fft_amd import spectral_mix_backward
+        dout = torch.randn(B, N, D, device=dev).to(dt)
+        for name, kw in (("backward_dV", dict(need_dv=True, need_dgate=False)), ("backward_dgate", dict(need_dv=False, need_dgate=True))):
+            spectral_mix_backward(V, gate, dout, N, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                spectral_mix_backward(V, gate, dout, N, **kw)
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 3
+            byt = 2 * B * N * D * V.element_size()     # dV: read dOut, write dV; dgate: read V and dOut
+            variants[name] = {"tokens_per_s": B * N / (ms * 1e-3), "kernel_ms": ms, "achieved_GBps": byt / ms / 1e6,
+                              "roofline_frac": byt / ms / 1e6 / HBM_PEAK_GBS}
+        del dout
 
     if rank == 0:
         es = V.element_size()
