@@ -1,0 +1,225 @@
+// kernel_regtile_mixed.h — register-resident spectral mix for smooth non-power-of-two n_fft = RF * RS (3000 = 60 x 50).
+//
+// Same two-pass plan, tile shape (16 channels x all rows, 64-byte fp32 row segments), packing (z = x_c + i x_{c+1}),
+// LDS plane exchanges and XCD-contiguous tile order as kernel_regtile.h (which see, including the reference lines it
+// replaces: /root/reference/spectre.py:506, :542-553); what changes is
+//   * RF and RS are arbitrary products of 2, 3, 4, 5, 8 handled by the compile-time mixed-radix engine of
+//     fft_regs_mixed.h (maps instead of data movement for the digit reversals),
+//   * RF != RS in general, so a column team has max(RF, RS) threads: the first RS of them own a residue class of rows
+//     (loads, F1, twiddles, I2, stores), the first RF own a residue class of bins (F2, gate, I1),
+//   * the Hermitian half of a bin is decided at run time per value (k1 is a lane quantity).
+// Replaces the LDS Stockham path for these lengths (2.7x faster at n_fft = 3000).
+#pragma once
+#include "kernel_regtile.h"
+#include "fft_regs_mixed.h"
+
+namespace sfft {
+
+template <int RF, int RS> constexpr int mixed_team() { return RF > RS ? RF : RS; }
+template <int RF, int RS> constexpr int mixed_threads() { return kPC * mixed_team<RF, RS>(); }
+// image row = one slot per source thread x 8 columns; the row stride / 8 is kept odd so that the 4 rows read by a
+// 32-lane group start in different banks
+constexpr int mixed_row(int slots) { return kPC * ((slots & 1) ? slots : slots + 1); }
+template <int RF, int RS> constexpr int mixed_image_bytes() {
+  return (RF * mixed_row(RS) > RS * mixed_row(RF) ? RF * mixed_row(RS) : RS * mixed_row(RF)) * 4;
+}
+template <int RF, int RS> constexpr int mixed_lds_total() { return mixed_image_bytes<RF, RS>() + (RF * RS / 2 + 1) * 8; }
+
+// MODE as in kernel_regtile.h: 0 fast (no predicates, gate staged in LDS), 1 general, 2 general + memory_fft
+template <int RF, int RS, bool IN_BF16, bool OUT_BF16, int MODE>
+__global__ void __launch_bounds__(kPC * (RF > RS ? RF : RS)) spectre_mix_regtile_mixed(const RegtileArgs a) {
+  constexpr bool GENERAL = MODE != 0, WITH_MEM = MODE == 2, GATE_LDS = MODE == 0;
+  constexpr int N = RF * RS, NZ = mixed_team<RF, RS>(), NT = mixed_threads<RF, RS>();
+  static_assert(N % 2 == 0, "even n_fft");
+  constexpr int RAF = Split<RF>::RA, RBF = Split<RF>::RB;
+  static_assert(RBF > 1, "RF must be composite");
+  constexpr int ROW1 = mixed_row(RS), ROW2 = mixed_row(RF);
+  constexpr int ES_IN = IN_BF16 ? 2 : 4, ES_OUT = OUT_BF16 ? 2 : 4;
+  constexpr float inv_n = 1.0f / (float)N;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* img = reinterpret_cast<float*>(smem);
+  float2* glds = reinterpret_cast<float2*>(smem + mixed_image_bytes<RF, RS>());
+
+  const int tid = threadIdx.x;
+  const int p = tid & (kPC - 1);
+  const int u = tid / kPC;                 // team index: row class n2 (< RS) and bin class k1 (< RF)
+  const bool rows = u < RS, bins = u < RF;
+
+  const int tile = xcd_contiguous(blockIdx.x, a.n_wg);
+  if (tile >= a.n_tiles) return;           // workgroup-uniform
+  const int b = tile / a.tiles_per_row;
+  const int ct = tile - b * a.tiles_per_row;
+  const int c = ct * (2 * kPC) + 2 * p;
+
+  auto load_twiddle_bases = [&](float2 (&wa)[RAF], float2 (&wb)[RBF]) {   // W_N^(u ka), W_N^(u RAF kb)
+    static_for<1, RAF>([&](auto jc) { constexpr int j = decltype(jc)::value; wa[j] = a.tw[u * j]; });
+    static_for<1, RBF>([&](auto jc) { constexpr int j = decltype(jc)::value; wb[j] = a.tw[u * RAF * j]; });
+  };
+
+  if constexpr (GATE_LDS) {                // half-spectrum gate, pre-scaled by 1/N, Im(DC) = Im(Nyquist) = 0
+    const float2* gp = a.gate + ((size_t)b * a.G + (ct * (2 * kPC)) / a.d_g) * a.F;
+    for (int k = tid; k <= N / 2; k += NT) {
+      float2 g = gp[k];
+      if (k == 0 || k == N / 2) g.y = 0.f;
+      if (a.conj_gate) g.y = -g.y;
+      glds[k] = make_float2(g.x * inv_n, g.y * inv_n);
+    }
+  }
+
+  float2 z[NZ];
+
+  // ---- rows u + RS*q, q < RF: load, F1 over q, W_N^(u k1) ------------------------------------------------------
+  if (rows) {
+    const char* vb = reinterpret_cast<const char*>(a.v) + ((size_t)b * a.v_sb + (size_t)ct * (2 * kPC)) * ES_IN;
+    const uint32_t voff = (uint32_t)(((long long)u * a.v_sn + 2 * p) * ES_IN);
+    static_for<0, RF>([&](auto ic) {
+      constexpr int q = (decltype(ic)::value / RAF) + RBF * (decltype(ic)::value % RAF);   // order of use in stage 1
+      const char* ptr = vb + (size_t)q * RS * a.v_sn * ES_IN + voff;
+      bool ok = true;
+      if constexpr (GENERAL) {
+        ok = (u + RS * q) < a.N_in;
+        ptr = ok ? ptr : vb + voff - (size_t)u * a.v_sn * ES_IN;
+      }
+      float2 val;
+      if constexpr (IN_BF16) {
+        const uint32_t wv = *reinterpret_cast<const uint32_t*>(ptr);
+        val = make_float2(__uint_as_float(wv << 16), __uint_as_float(wv & 0xffff0000u));
+      } else {
+        val = *reinterpret_cast<const float2*>(ptr);
+      }
+      z[q] = ok ? val : make_float2(0.f, 0.f);
+    });
+    fft_ct<RF, false, IdentityMap, NZ>(z);
+    float2 wa[RAF], wb[RBF];
+    load_twiddle_bases(wa, wb);
+    static_for<1, RF>([&](auto kc) {
+      constexpr int k1 = decltype(kc)::value, ka = k1 % RAF, kb = k1 / RAF, pos = out_pos<RF>(k1);
+      if constexpr (ka > 0) z[pos] = cmul(z[pos], wa[ka]);
+      if constexpr (kb > 0) z[pos] = cmul(z[pos], wb[kb]);
+    });
+  }
+
+  // ---- E1: bin k1 of row class u -> image row k1, slot u; bin-class thread s = u reads row s (slots n2).
+  //      One float plane at a time (see kernel_regtile.h): the real parts are replaced first, the outgoing imaginary
+  //      parts are still in their registers when the second round writes them.
+  if (rows) static_for<0, RF>([&](auto kc) { constexpr int k1 = decltype(kc)::value; img[k1 * ROW1 + u * kPC + p] = z[out_pos<RF>(k1)].x; });
+  __syncthreads();
+  if (bins) static_for<0, RS>([&](auto nc) { constexpr int n2 = decltype(nc)::value; z[n2].x = img[u * ROW1 + n2 * kPC + p]; });
+  __syncthreads();
+  if (rows) static_for<0, RF>([&](auto kc) { constexpr int k1 = decltype(kc)::value; img[k1 * ROW1 + u * kPC + p] = z[out_pos<RF>(k1)].y; });
+  __syncthreads();
+  if (bins) static_for<0, RS>([&](auto nc) { constexpr int n2 = decltype(nc)::value; z[n2].y = img[u * ROW1 + n2 * kPC + p]; });
+  __syncthreads();
+
+  // ---- bins k = u + RF*k2: F2 over n2, gate (+ memory), I1 over k2 -----------------------------------------------
+  using BinMap = OutPosMap<RS>;            // bin k2 lives at z[out_pos<RS>(k2)]
+  if (bins) {
+    fft_ct<RS, false, IdentityMap, NZ>(z);
+    const int grp = c / a.d_g;
+    const float2* gp = a.gate + ((size_t)b * a.G + grp) * a.F;
+    static_for<0, RS>([&](auto kc) {
+      constexpr int k2 = decltype(kc)::value, pos = BinMap::at(k2);
+      const int k = u + RF * k2;
+      const bool upper = 2 * k > N;                       // Hermitian extension: conj(g[N - k])
+      const int idx = upper ? N - k : k;
+      float2 g;
+      if constexpr (GATE_LDS) {
+        g = glds[idx];
+      } else {
+        g = gp[idx];
+        if (a.conj_gate) g.y = -g.y;
+        if (k == 0 || 2 * k == N) g.y = 0.f;              // irfft ignores Im(DC), Im(Nyquist)
+        g.x *= inv_n; g.y *= inv_n;
+      }
+      if (upper) g.y = -g.y;
+      z[pos] = cmul(z[pos], g);
+      if constexpr (WITH_MEM) {                           // spectre.py:548-549
+        const float4 m = *reinterpret_cast<const float4*>(a.mem + ((size_t)idx * a.D + c) * 2);
+        float2 add;
+        if (k == 0 || 2 * k == N) add = make_float2(m.x, m.z);
+        else if (upper)           add = make_float2(m.x + m.w, m.z - m.y);
+        else                      add = make_float2(m.x - m.w, m.y + m.z);
+        z[pos].x += add.x * inv_n; z[pos].y += add.y * inv_n;
+      }
+    });
+    fft_ct<RS, true, BinMap, NZ>(z);                      // n2 lives at z[BinMap::at(out_pos<RS>(n2))]
+  }
+
+  // ---- E2: value n2 of bin class s -> image row n2, slot s; row-class thread u reads row u (slots k1) --------------
+  if (bins) static_for<0, RS>([&](auto nc) { constexpr int n2 = decltype(nc)::value; img[n2 * ROW2 + u * kPC + p] = z[BinMap::at(out_pos<RS>(n2))].x; });
+  __syncthreads();
+  if (rows) static_for<0, RF>([&](auto kc) { constexpr int k1 = decltype(kc)::value; z[k1].x = img[u * ROW2 + k1 * kPC + p]; });
+  __syncthreads();
+  if (bins) static_for<0, RS>([&](auto nc) { constexpr int n2 = decltype(nc)::value; img[n2 * ROW2 + u * kPC + p] = z[BinMap::at(out_pos<RS>(n2))].y; });
+  __syncthreads();
+  if (rows) static_for<0, RF>([&](auto kc) { constexpr int k1 = decltype(kc)::value; z[k1].y = img[u * ROW2 + k1 * kPC + p]; });
+
+  // ---- conj twiddle, I2 over k1, store rows u + RS*n1 (spectre.py:553) ----------------------------------------------
+  if (rows) {
+    float2 wa[RAF], wb[RBF];
+    load_twiddle_bases(wa, wb);
+    static_for<1, RF>([&](auto kc) {
+      constexpr int k1 = decltype(kc)::value, ka = k1 % RAF, kb = k1 / RAF;
+      if constexpr (ka > 0) z[k1] = cmulc(z[k1], wa[ka]);
+      if constexpr (kb > 0) z[k1] = cmulc(z[k1], wb[kb]);
+    });
+    fft_ct<RF, true, IdentityMap, NZ>(z);
+    char* ob = reinterpret_cast<char*>(a.out) + ((size_t)b * a.out_sb + (size_t)ct * (2 * kPC)) * ES_OUT;
+    const uint32_t ooff = (uint32_t)(((long long)u * a.out_sn + 2 * p) * ES_OUT);
+    static_for<0, RF>([&](auto nc) {
+      constexpr int n1 = decltype(nc)::value, pos = out_pos<RF>(n1);
+      char* ptr = ob + (size_t)n1 * RS * a.out_sn * ES_OUT + ooff;
+      bool ok = true;
+      if constexpr (GENERAL) ok = (u + RS * n1) < a.N_in;
+      if (ok) {
+        if constexpr (OUT_BF16) {
+          *reinterpret_cast<uint32_t*>(ptr) = f32_to_bf16_rne(z[pos].x) | (f32_to_bf16_rne(z[pos].y) << 16);
+        } else {
+          *reinterpret_cast<float2*>(ptr) = z[pos];
+        }
+      }
+    });
+  }
+}
+
+template <int RF, int RS>
+hipError_t launch_regtile_mixed(const RegtileArgs& a, bool in_bf16, bool out_bf16, int mode, hipStream_t stream);
+
+#define SFFT_DEFINE_REGTILE_MIXED_LAUNCHER(RF_, RS_)                                                         \
+  template <>                                                                                                \
+  hipError_t launch_regtile_mixed<RF_, RS_>(const RegtileArgs& a, bool in_bf16, bool out_bf16, int mode,     \
+                                            hipStream_t stream) {                                            \
+    const dim3 grid(a.n_wg), block(mixed_threads<RF_, RS_>());                                               \
+    const size_t lds = mixed_lds_total<RF_, RS_>();                                                          \
+    const int key = (in_bf16 ? 8 : 0) | (out_bf16 ? 4 : 0) | mode;                                           \
+    static bool lds_opt_in[16][16] = {};                                                                     \
+    auto go = [&](auto kern) -> hipError_t {                                                                 \
+      int dev = 0;                                                                                           \
+      (void)hipGetDevice(&dev);                                                                              \
+      if (dev < 0 || dev >= 16 || !lds_opt_in[dev][key]) {                                                   \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                              \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
+        if (e != hipSuccess) return e;                                                                       \
+        if (dev >= 0 && dev < 16) lds_opt_in[dev][key] = true;                                               \
+      }                                                                                                      \
+      hipLaunchKernelGGL(kern, grid, block, lds, stream, a);                                                 \
+      return hipGetLastError();                                                                              \
+    };                                                                                                       \
+    switch (key) {                                                                                           \
+      case 0: return go(spectre_mix_regtile_mixed<RF_, RS_, false, false, 0>);                               \
+      case 1: return go(spectre_mix_regtile_mixed<RF_, RS_, false, false, 1>);                               \
+      case 2: return go(spectre_mix_regtile_mixed<RF_, RS_, false, false, 2>);                               \
+      case 4: return go(spectre_mix_regtile_mixed<RF_, RS_, false, true, 0>);                                \
+      case 5: return go(spectre_mix_regtile_mixed<RF_, RS_, false, true, 1>);                                \
+      case 6: return go(spectre_mix_regtile_mixed<RF_, RS_, false, true, 2>);                                \
+      case 8: return go(spectre_mix_regtile_mixed<RF_, RS_, true, false, 0>);                                \
+      case 9: return go(spectre_mix_regtile_mixed<RF_, RS_, true, false, 1>);                                \
+      case 10: return go(spectre_mix_regtile_mixed<RF_, RS_, true, false, 2>);                               \
+      case 12: return go(spectre_mix_regtile_mixed<RF_, RS_, true, true, 0>);                                \
+      case 13: return go(spectre_mix_regtile_mixed<RF_, RS_, true, true, 1>);                                \
+      case 14: return go(spectre_mix_regtile_mixed<RF_, RS_, true, true, 2>);                                \
+      default: return hipErrorInvalidValue;                                                                  \
+    }                                                                                                        \
+  }
+
+}  // namespace sfft

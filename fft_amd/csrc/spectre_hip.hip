@@ -18,6 +18,7 @@
 
 #include "../../include/spectre_hip.h"
 #include "kernel_regtile_grad.h"
+#include "kernel_regtile_mixed.h"
 #include "kernel_stockham.h"
 
 namespace sfft {
@@ -171,6 +172,7 @@ int get_plan(int device, int64_t n, Plan** out) {
 
 struct Choice {
   bool regtile = false;
+  bool mixed = false;      // regtile with the mixed-radix kernel (kernel_regtile_mixed.h)
   int RF = 0, RS = 0;      // n_fft = RF * RS
   int mode = 0;            // 0 fast, 1 general (row predicates / gate from global), 2 general + memory_fft
   // stockham
@@ -208,10 +210,11 @@ int choose(const SpectreMixArgs* a, const Plan* plan, Choice* c) {
     case 1024: RF = 32; RS = 32; break;
     case 2048: RF = 64; RS = 32; break;
     case 4096: RF = 64; RS = 64; break;
+    case 3000: RF = 60; RS = 50; c->mixed = true; break;
     default: break;
   }
   const char* why = "";
-  if (!RF) why = "n_fft is not 256/512/1024/2048/4096";
+  if (!RF) why = "n_fft is not 256/512/1024/2048/3000/4096";
   else if (D % 16) why = "D % 16 != 0";
   else if (d_g % 2) why = "odd group width";
   else if ((reinterpret_cast<uintptr_t>(a->v) % (2 * es_in)) || (a->v_sn % 2) || (a->v_sb % 2)) why = "v not pair-aligned";
@@ -291,7 +294,8 @@ int launch(const SpectreMixArgs* a, const Plan* plan, const Choice& c, bool conj
     k.tpw = tiles_per_workgroup(k.n_tiles);
     k.n_wg = 2 * ((k.n_tiles + 2 * k.tpw - 1) / (2 * k.tpw));
     const bool ib = a->in_dtype == SPECTRE_BF16, ob = a->out_dtype == SPECTRE_BF16;
-    if (c.RF == 16) e = sfft::launch_regtile<16, 16>(k, ib, ob, c.mode, stream);
+    if (c.mixed) { k.tpw = 1; k.n_wg = 2 * ((k.n_tiles + 1) / 2); e = sfft::launch_regtile_mixed<60, 50>(k, ib, ob, c.mode, stream); }
+    else if (c.RF == 16) e = sfft::launch_regtile<16, 16>(k, ib, ob, c.mode, stream);
     else if (c.RF == 32 && c.RS == 16) e = sfft::launch_regtile<32, 16>(k, ib, ob, c.mode, stream);
     else if (c.RF == 32) e = sfft::launch_regtile<32, 32>(k, ib, ob, c.mode, stream);
     else if (c.RS == 32) e = sfft::launch_regtile<64, 32>(k, ib, ob, c.mode, stream);
@@ -386,7 +390,7 @@ int spectre_mix_describe(const SpectreMixArgs* a, char* buf, size_t cap) {
   const char* in = a->in_dtype == SPECTRE_BF16 ? "bf16" : "f32";
   const char* out = a->out_dtype == SPECTRE_BF16 ? "bf16" : "f32";
   if (c.regtile) {
-    snprintf(buf, cap, "regtile %dx%d in=%s out=%s mode=%d tiles=%lld", c.RF, c.RS, in, out, c.mode,
+    snprintf(buf, cap, "regtile%s %dx%d in=%s out=%s mode=%d tiles=%lld", c.mixed ? "-mixed" : "", c.RF, c.RS, in, out, c.mode,
              (long long)(a->B * (a->D / 16)));
   } else {
     std::string r;

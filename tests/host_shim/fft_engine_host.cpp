@@ -1,0 +1,38 @@
+// Runs the compile-time in-register FFTs of fft_amd/csrc/fft_regs_mixed.h on the host (g++), one length per call.
+#include "fft_regs_mixed.h"
+using namespace sfft;
+
+template <int R, bool INV>
+static void run(float* d) {
+  float2 z[R];
+  for (int i = 0; i < R; ++i) z[i] = make_float2(d[2 * i], d[2 * i + 1]);
+  fft_ct<R, INV, IdentityMap, R>(z);
+  static_for<0, R>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    d[2 * k] = z[out_pos<R>(k)].x;
+    d[2 * k + 1] = z[out_pos<R>(k)].y;
+  });
+}
+// forward transform, then inverse consuming the bins where they lie (OutPosMap): returns R * input in natural order
+template <int R>
+static void round_trip(float* d) {
+  float2 z[R];
+  for (int i = 0; i < R; ++i) z[i] = make_float2(d[2 * i], d[2 * i + 1]);
+  fft_ct<R, false, IdentityMap, R>(z);
+  fft_ct<R, true, OutPosMap<R>, R>(z);
+  static_for<0, R>([&](auto nc) {
+    constexpr int n = decltype(nc)::value;
+    constexpr int pos = OutPosMap<R>::at(out_pos<R>(n));
+    d[2 * n] = z[pos].x;
+    d[2 * n + 1] = z[pos].y;
+  });
+}
+
+#define CASE(R_) case R_: if (mode == 2) round_trip<R_>(d); else if (mode == 1) run<R_, true>(d); else run<R_, false>(d); return 0;
+extern "C" int fft_engine_run(int R, int mode, float* d) {
+  switch (R) {
+    CASE(2) CASE(3) CASE(4) CASE(5) CASE(8) CASE(6) CASE(10) CASE(12) CASE(15) CASE(16) CASE(20) CASE(24) CASE(25)
+    CASE(30) CASE(32) CASE(40) CASE(48) CASE(50) CASE(60) CASE(64)
+    default: return -1;
+  }
+}

@@ -59,6 +59,8 @@ def test_native_library_is_the_thing_that_runs():
     for n, tag in ((256, "16x16"), (512, "32x16"), (1024, "32x32"), (2048, "64x32")):
         Vn, gn, _ = _problem(0, 1, n, 16, 1, n)
         assert _describe(Vn.to(DEV), gn.to(DEV)).startswith("regtile " + tag)
+    Vn, gn, _ = _problem(0, 1, 3000, 16, 1, 3000)
+    assert _describe(Vn.to(DEV), gn.to(DEV)).startswith("regtile-mixed 60x50")
 
 
 @pytest.mark.parametrize("algo", ["auto", "stockham"])
@@ -76,7 +78,8 @@ SHAPES = [  # (B, N, D, G, n_fft)
     (3, 4096, 64, 4, 4096), (2, 1024, 48, 3, 1024), (3, 256, 32, 2, 256),          # register-tile sizes, square
     (2, 2048, 32, 2, 2048), (2, 512, 32, 4, 512), (3, 2048, 64, 2, 2048), (3, 512, 48, 3, 512),   # 2*RS*RS
     (2, 1500, 32, 2, 2048), (2, 300, 32, 2, 512), (2, 3000, 32, 2, 2048),          # pad / truncate on those
-    (2, 3000, 64, 4, 3000), (2, 1536, 32, 2, 1536), (2, 640, 32, 4, 640),          # Stockham, smooth
+    (2, 3000, 64, 4, 3000), (2, 2000, 32, 2, 3000), (2, 3500, 32, 2, 3000), (2, 3000, 48, 2, 3000),   # mixed-radix register tile (60 x 50)
+    (2, 1536, 32, 2, 1536), (2, 640, 32, 4, 640),                                   # Stockham, smooth
     (2, 1000, 32, 2, 1024), (2, 5000, 32, 2, 4096), (1, 100, 16, 2, 128),          # pad / truncate
     (2, 97, 12, 2, 97), (2, 331, 8, 2, 331), (1, 2039, 8, 1, 2039),                # primes: Bluestein
     (2, 60, 6, 2, 60), (2, 64, 10, 2, 64), (2, 256, 24, 8, 256),                   # odd d_g (solo), D%16 != 0
