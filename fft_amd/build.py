@@ -20,7 +20,8 @@ OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libspectre_hip.so")
 
 SOURCES = ["spectre_hip.hip", "regtile_n4096.hip", "regtile_n2048.hip", "regtile_n1024.hip", "regtile_n512.hip",
-           "regtile_n256.hip", "regtile_n3000.hip"]
+           "regtile_n256.hip", "regtile_n3000.hip", "regtile_n768.hip", "regtile_n1536.hip",
+           "regtile_n3072.hip", "regtile_n1000.hip", "regtile_n2000.hip", "regtile_n1280.hip", "regtile_n2560.hip", "regtile_n3840.hip"]
 HEADERS = ["fft_regs.h", "fft_regs_mixed.h", "fft_tables_mixed.h", "kernel_regtile.h", "kernel_regtile_grad.h", "kernel_regtile_mixed.h", "kernel_stockham.h", os.path.join("..", "..", "include", "spectre_hip.h")]
 
 # -fno-slp-vectorize: SLP packs the butterflies into v_pk_*_f32 (no faster than two scalar ops on gfx950)
@@ -65,7 +66,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             print(r.stderr, file=sys.stderr)
         return obj
 
-    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
     cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB + ".tmp", *objs]
     r = subprocess.run(cmd, capture_output=True, text=True)

@@ -222,4 +222,37 @@ hipError_t launch_regtile_mixed(const RegtileArgs& a, bool in_bf16, bool out_bf1
     }                                                                                                        \
   }
 
+// Reduced set for the secondary lengths: f32 -> f32 and bf16 -> bf16 only (mixed storage dtypes take the Stockham path)
+#define SFFT_DEFINE_REGTILE_MIXED_LAUNCHER_SAME_DTYPE(RF_, RS_)                                              \
+  template <>                                                                                                \
+  hipError_t launch_regtile_mixed<RF_, RS_>(const RegtileArgs& a, bool in_bf16, bool out_bf16, int mode,     \
+                                            hipStream_t stream) {                                            \
+    const dim3 grid(a.n_wg), block(mixed_threads<RF_, RS_>());                                               \
+    const size_t lds = mixed_lds_total<RF_, RS_>();                                                          \
+    if (in_bf16 != out_bf16) return hipErrorInvalidValue;                                                    \
+    const int key = (in_bf16 ? 4 : 0) | mode;                                                                \
+    static bool lds_opt_in[16][8] = {};                                                                      \
+    auto go = [&](auto kern) -> hipError_t {                                                                 \
+      int dev = 0;                                                                                           \
+      (void)hipGetDevice(&dev);                                                                              \
+      if (dev < 0 || dev >= 16 || !lds_opt_in[dev][key]) {                                                   \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                              \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
+        if (e != hipSuccess) return e;                                                                       \
+        if (dev >= 0 && dev < 16) lds_opt_in[dev][key] = true;                                               \
+      }                                                                                                      \
+      hipLaunchKernelGGL(kern, grid, block, lds, stream, a);                                                 \
+      return hipGetLastError();                                                                              \
+    };                                                                                                       \
+    switch (key) {                                                                                           \
+      case 0: return go(spectre_mix_regtile_mixed<RF_, RS_, false, false, 0>);                               \
+      case 1: return go(spectre_mix_regtile_mixed<RF_, RS_, false, false, 1>);                               \
+      case 2: return go(spectre_mix_regtile_mixed<RF_, RS_, false, false, 2>);                               \
+      case 4: return go(spectre_mix_regtile_mixed<RF_, RS_, true, true, 0>);                                 \
+      case 5: return go(spectre_mix_regtile_mixed<RF_, RS_, true, true, 1>);                                 \
+      case 6: return go(spectre_mix_regtile_mixed<RF_, RS_, true, true, 2>);                                 \
+      default: return hipErrorInvalidValue;                                                                  \
+    }                                                                                                        \
+  }
+
 }  // namespace sfft

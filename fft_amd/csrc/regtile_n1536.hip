@@ -1,0 +1,3 @@
+// regtile_n1536.hip — n_fft = 1536 (= 48 x 32) instantiations of the mixed-radix register-resident kernel (own TU)
+#include "kernel_regtile_mixed.h"
+namespace sfft { SFFT_DEFINE_REGTILE_MIXED_LAUNCHER_SAME_DTYPE(48, 32) }

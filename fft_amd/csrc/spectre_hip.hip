@@ -22,15 +22,54 @@
 #include "kernel_stockham.h"
 
 namespace sfft {
-// defined in regtile_n256.hip ... regtile_n4096.hip
+// defined in regtile_n*.hip (one translation unit per length)
 template <> hipError_t launch_regtile<16, 16>(const RegtileArgs&, bool, bool, int, hipStream_t);
 template <> hipError_t launch_regtile<32, 16>(const RegtileArgs&, bool, bool, int, hipStream_t);
 template <> hipError_t launch_regtile<32, 32>(const RegtileArgs&, bool, bool, int, hipStream_t);
 template <> hipError_t launch_regtile<64, 32>(const RegtileArgs&, bool, bool, int, hipStream_t);
 template <> hipError_t launch_regtile<64, 64>(const RegtileArgs&, bool, bool, int, hipStream_t);
+template <> hipError_t launch_regtile_mixed<60, 50>(const RegtileArgs&, bool, bool, int, hipStream_t);
+template <> hipError_t launch_regtile_mixed<32, 24>(const RegtileArgs&, bool, bool, int, hipStream_t);
+template <> hipError_t launch_regtile_mixed<48, 32>(const RegtileArgs&, bool, bool, int, hipStream_t);
+template <> hipError_t launch_regtile_mixed<64, 48>(const RegtileArgs&, bool, bool, int, hipStream_t);
+template <> hipError_t launch_regtile_mixed<40, 25>(const RegtileArgs&, bool, bool, int, hipStream_t);
+template <> hipError_t launch_regtile_mixed<50, 40>(const RegtileArgs&, bool, bool, int, hipStream_t);
+template <> hipError_t launch_regtile_mixed<40, 32>(const RegtileArgs&, bool, bool, int, hipStream_t);
+template <> hipError_t launch_regtile_mixed<64, 40>(const RegtileArgs&, bool, bool, int, hipStream_t);
+template <> hipError_t launch_regtile_mixed<64, 60>(const RegtileArgs&, bool, bool, int, hipStream_t);
 }  // namespace sfft
 
 namespace {
+
+// register-resident kernels: n_fft = RF * RS
+using TileLauncher = hipError_t (*)(const sfft::RegtileArgs&, bool, bool, int, hipStream_t);
+struct TileSize {
+  int n, RF, RS;
+  bool mixed;        // kernel_regtile_mixed.h (arbitrary 2/3/5-smooth factors) instead of kernel_regtile.h
+  bool same_dtype;   // built for f32->f32 and bf16->bf16 only
+  TileLauncher launch;
+};
+const TileSize kTileSizes[] = {
+    {256, 16, 16, false, false, &sfft::launch_regtile<16, 16>},
+    {512, 32, 16, false, false, &sfft::launch_regtile<32, 16>},
+    {1024, 32, 32, false, false, &sfft::launch_regtile<32, 32>},
+    {2048, 64, 32, false, false, &sfft::launch_regtile<64, 32>},
+    {4096, 64, 64, false, false, &sfft::launch_regtile<64, 64>},
+    {3000, 60, 50, true, false, &sfft::launch_regtile_mixed<60, 50>},
+    {768, 32, 24, true, true, &sfft::launch_regtile_mixed<32, 24>},
+    {1536, 48, 32, true, true, &sfft::launch_regtile_mixed<48, 32>},
+    {3072, 64, 48, true, true, &sfft::launch_regtile_mixed<64, 48>},
+    {1000, 40, 25, true, true, &sfft::launch_regtile_mixed<40, 25>},
+    {2000, 50, 40, true, true, &sfft::launch_regtile_mixed<50, 40>},
+    {1280, 40, 32, true, true, &sfft::launch_regtile_mixed<40, 32>},
+    {2560, 64, 40, true, true, &sfft::launch_regtile_mixed<64, 40>},
+    {3840, 64, 60, true, true, &sfft::launch_regtile_mixed<64, 60>},
+};
+const TileSize* find_tile_size(int64_t n) {
+  for (const TileSize& t : kTileSizes)
+    if (t.n == n) return &t;
+  return nullptr;
+}
 
 thread_local std::string g_err;
 
@@ -172,7 +211,7 @@ int get_plan(int device, int64_t n, Plan** out) {
 
 struct Choice {
   bool regtile = false;
-  bool mixed = false;      // regtile with the mixed-radix kernel (kernel_regtile_mixed.h)
+  const TileSize* tile = nullptr;
   int RF = 0, RS = 0;      // n_fft = RF * RS
   int mode = 0;            // 0 fast, 1 general (row predicates / gate from global), 2 general + memory_fft
   // stockham
@@ -203,18 +242,10 @@ int validate(const SpectreMixArgs* a) {
 int choose(const SpectreMixArgs* a, const Plan* plan, Choice* c) {
   const int64_t n = a->n_fft, D = a->D, d_g = D / a->G_tot;
   const int es_in = a->in_dtype == SPECTRE_BF16 ? 2 : 4, es_out = a->out_dtype == SPECTRE_BF16 ? 2 : 4;
-  int RF = 0, RS = 0;
-  switch (n) {
-    case 256: RF = 16; RS = 16; break;
-    case 512: RF = 32; RS = 16; break;
-    case 1024: RF = 32; RS = 32; break;
-    case 2048: RF = 64; RS = 32; break;
-    case 4096: RF = 64; RS = 64; break;
-    case 3000: RF = 60; RS = 50; c->mixed = true; break;
-    default: break;
-  }
+  const TileSize* ts = find_tile_size(n);
   const char* why = "";
-  if (!RF) why = "n_fft is not 256/512/1024/2048/3000/4096";
+  if (!ts) why = "no register-tile kernel for this n_fft";
+  else if (ts->same_dtype && a->in_dtype != a->out_dtype) why = "storage dtypes differ (not built for this n_fft)";
   else if (D % 16) why = "D % 16 != 0";
   else if (d_g % 2) why = "odd group width";
   else if ((reinterpret_cast<uintptr_t>(a->v) % (2 * es_in)) || (a->v_sn % 2) || (a->v_sb % 2)) why = "v not pair-aligned";
@@ -230,7 +261,7 @@ int choose(const SpectreMixArgs* a, const Plan* plan, Choice* c) {
                 "register-tile kernel not applicable: %s", why);
   if (can_regtile && a->algo != SPECTRE_ALGO_STOCKHAM) {
     c->regtile = true;
-    c->RF = RF; c->RS = RS;
+    c->tile = ts; c->RF = ts->RF; c->RS = ts->RS;
     c->mode = a->mem ? 2 : ((a->N_in < a->n_fft) || (d_g % 16 != 0)) ? 1 : 0;
     return SPECTRE_OK;
   }
@@ -294,12 +325,8 @@ int launch(const SpectreMixArgs* a, const Plan* plan, const Choice& c, bool conj
     k.tpw = tiles_per_workgroup(k.n_tiles);
     k.n_wg = 2 * ((k.n_tiles + 2 * k.tpw - 1) / (2 * k.tpw));
     const bool ib = a->in_dtype == SPECTRE_BF16, ob = a->out_dtype == SPECTRE_BF16;
-    if (c.mixed) { k.tpw = 1; k.n_wg = 2 * ((k.n_tiles + 1) / 2); e = sfft::launch_regtile_mixed<60, 50>(k, ib, ob, c.mode, stream); }
-    else if (c.RF == 16) e = sfft::launch_regtile<16, 16>(k, ib, ob, c.mode, stream);
-    else if (c.RF == 32 && c.RS == 16) e = sfft::launch_regtile<32, 16>(k, ib, ob, c.mode, stream);
-    else if (c.RF == 32) e = sfft::launch_regtile<32, 32>(k, ib, ob, c.mode, stream);
-    else if (c.RS == 32) e = sfft::launch_regtile<64, 32>(k, ib, ob, c.mode, stream);
-    else e = sfft::launch_regtile<64, 64>(k, ib, ob, c.mode, stream);
+    if (c.tile->mixed) { k.tpw = 1; k.n_wg = 2 * ((k.n_tiles + 1) / 2); }
+    e = c.tile->launch(k, ib, ob, c.mode, stream);
   } else {
     sfft::StockhamArgs k{};
     k.v = a->v; k.gate = reinterpret_cast<const float2*>(a->gate); k.mem = reinterpret_cast<const float*>(a->mem); k.out = a->out;
@@ -390,7 +417,7 @@ int spectre_mix_describe(const SpectreMixArgs* a, char* buf, size_t cap) {
   const char* in = a->in_dtype == SPECTRE_BF16 ? "bf16" : "f32";
   const char* out = a->out_dtype == SPECTRE_BF16 ? "bf16" : "f32";
   if (c.regtile) {
-    snprintf(buf, cap, "regtile%s %dx%d in=%s out=%s mode=%d tiles=%lld", c.mixed ? "-mixed" : "", c.RF, c.RS, in, out, c.mode,
+    snprintf(buf, cap, "regtile%s %dx%d in=%s out=%s mode=%d tiles=%lld", c.tile->mixed ? "-mixed" : "", c.RF, c.RS, in, out, c.mode,
              (long long)(a->B * (a->D / 16)));
   } else {
     std::string r;

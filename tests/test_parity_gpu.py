@@ -59,8 +59,12 @@ def test_native_library_is_the_thing_that_runs():
     for n, tag in ((256, "16x16"), (512, "32x16"), (1024, "32x32"), (2048, "64x32")):
         Vn, gn, _ = _problem(0, 1, n, 16, 1, n)
         assert _describe(Vn.to(DEV), gn.to(DEV)).startswith("regtile " + tag)
-    Vn, gn, _ = _problem(0, 1, 3000, 16, 1, 3000)
-    assert _describe(Vn.to(DEV), gn.to(DEV)).startswith("regtile-mixed 60x50")
+    for n, tag in ((3000, "60x50"), (768, "32x24"), (1536, "48x32"), (3072, "64x48"), (1000, "40x25"), (2000, "50x40"),
+                   (1280, "40x32"), (2560, "64x40"), (3840, "64x60")):
+        Vn, gn, _ = _problem(0, 1, n, 16, 1, n)
+        assert _describe(Vn.to(DEV), gn.to(DEV)).startswith("regtile-mixed " + tag)
+    Vn, gn, _ = _problem(0, 1, 768, 16, 1, 768)      # secondary lengths are built for equal storage dtypes only
+    assert _describe(Vn.to(DEV).bfloat16(), gn.to(DEV), out_dtype=torch.float32).startswith("stockham")
 
 
 @pytest.mark.parametrize("algo", ["auto", "stockham"])
@@ -79,7 +83,11 @@ SHAPES = [  # (B, N, D, G, n_fft)
     (2, 2048, 32, 2, 2048), (2, 512, 32, 4, 512), (3, 2048, 64, 2, 2048), (3, 512, 48, 3, 512),   # 2*RS*RS
     (2, 1500, 32, 2, 2048), (2, 300, 32, 2, 512), (2, 3000, 32, 2, 2048),          # pad / truncate on those
     (2, 3000, 64, 4, 3000), (2, 2000, 32, 2, 3000), (2, 3500, 32, 2, 3000), (2, 3000, 48, 2, 3000),   # mixed-radix register tile (60 x 50)
-    (2, 1536, 32, 2, 1536), (2, 640, 32, 4, 640),                                   # Stockham, smooth
+    (2, 768, 32, 2, 768), (2, 1536, 32, 2, 1536), (2, 3072, 32, 2, 3072), (2, 1000, 32, 2, 1000), (2, 2000, 32, 2, 2000),
+    (2, 1280, 32, 2, 1280), (2, 2560, 32, 2, 2560), (2, 3840, 32, 2, 3840),         # the other mixed-radix register-tile lengths
+    (2, 700, 32, 2, 768), (2, 1111, 48, 2, 1536), (2, 4000, 32, 2, 3072), (2, 999, 16, 2, 1000), (1, 1999, 48, 2, 2000),
+    (2, 1279, 32, 4, 1280), (2, 2000, 48, 2, 2560), (2, 3000, 32, 2, 3840),         # ... with row predicates / narrow groups
+    (2, 640, 32, 4, 640), (2, 1200, 32, 2, 1200),                                   # Stockham, smooth
     (2, 1000, 32, 2, 1024), (2, 5000, 32, 2, 4096), (1, 100, 16, 2, 128),          # pad / truncate
     (2, 97, 12, 2, 97), (2, 331, 8, 2, 331), (1, 2039, 8, 1, 2039),                # primes: Bluestein
     (2, 60, 6, 2, 60), (2, 64, 10, 2, 64), (2, 256, 24, 8, 256),                   # odd d_g (solo), D%16 != 0
@@ -99,7 +107,7 @@ def test_random_vs_fp64_oracle(shape, mem):
         assert err < 2e-5
 
 
-@pytest.mark.parametrize("n_fft", [256, 512, 1024, 2048, 4096, 3000, 97])
+@pytest.mark.parametrize("n_fft", [256, 512, 1024, 2048, 4096, 3000, 97, 1536, 2000])
 @pytest.mark.parametrize("io", ["bf16->bf16", "bf16->f32", "f32->bf16"])
 def test_bf16_io(n_fft, io):
     src, dst = io.split("->")
@@ -112,7 +120,10 @@ def test_bf16_io(n_fft, io):
     y = _mix(V.to(DEV), gate.to(DEV), None, n_fft, out_dtype=tout)
     assert y.dtype == tout
     if tout == torch.bfloat16:
-        assert torch.equal(y, y32.bfloat16())                 # RNE of the kernel's own fp32 result, bit exact
+        same_kernel = _describe(V.to(DEV), gate.to(DEV), None, n_fft, out_dtype=torch.float32).split(" in=")[0] == \
+            _describe(V.to(DEV), gate.to(DEV), None, n_fft, out_dtype=tout).split(" in=")[0]
+        if same_kernel:                                        # (secondary lengths: mixed storage dtypes run on Stockham)
+            assert torch.equal(y, y32.bfloat16())             # RNE of the kernel's own fp32 result, bit exact
         yb = y.float().cpu().numpy()
         rb = bf16_round(ref.astype(np.float32))
         ulp = np.maximum(np.abs(rb), 1e-30) * 2.0 ** -7       # 1 bf16 ulp (8-bit significand)
