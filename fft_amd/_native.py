@@ -14,14 +14,14 @@ import torch  # noqa: F401  — must be imported first: the library binds to the
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPECTRE_HIP_LIB") or os.path.join(_HERE, "lib", "libspectre_hip.so")   # env: A/B builds
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 F32, BF16 = 0, 1
 ALGO = {"auto": 0, "stockham": 1, "regtile": 2}
 
 # every symbol include/spectre_hip.h declares
 EXPORTS = ("spectre_version", "spectre_last_error", "spectre_mix_fwd", "spectre_mix_describe",
            "spectre_plan_create", "spectre_plan_destroy", "spectre_mix_time", "spectre_mix_bwd",
-           "spectre_mix_bwd_workspace_bytes")
+           "spectre_mix_bwd_workspace_bytes", "spectre_gate_fwd")
 
 
 class SpectreMixArgs(ctypes.Structure):
@@ -32,6 +32,14 @@ class SpectreMixArgs(ctypes.Structure):
         ("v_sb", ctypes.c_int64), ("v_sn", ctypes.c_int64), ("out_sb", ctypes.c_int64), ("out_sn", ctypes.c_int64),
         ("in_dtype", ctypes.c_int32), ("out_dtype", ctypes.c_int32), ("algo", ctypes.c_int32), ("device", ctypes.c_int32),
         ("stream", ctypes.c_void_p),
+    ]
+
+
+class SpectreGateArgs(ctypes.Structure):
+    _fields_ = [
+        ("anchors", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("phase", ctypes.c_void_p), ("gate", ctypes.c_void_p),
+        ("B", ctypes.c_int64), ("G", ctypes.c_int64), ("K", ctypes.c_int64), ("F", ctypes.c_int64),
+        ("phase_sb", ctypes.c_int64), ("eps", ctypes.c_float), ("device", ctypes.c_int32), ("stream", ctypes.c_void_p),
     ]
 
 
@@ -88,6 +96,8 @@ def load():
         lib.spectre_mix_bwd.restype = ctypes.c_int
         lib.spectre_mix_bwd_workspace_bytes.argtypes = [ctypes.c_int64] * 3
         lib.spectre_mix_bwd_workspace_bytes.restype = ctypes.c_int64
+        lib.spectre_gate_fwd.argtypes = [ctypes.POINTER(SpectreGateArgs)]
+        lib.spectre_gate_fwd.restype = ctypes.c_int
         ver = lib.spectre_version()
         if ver != ABI_VERSION:
             raise NativeLibraryError(f"ABI mismatch: library {ver}, binding {ABI_VERSION}")

@@ -20,6 +20,7 @@
 #include "kernel_regtile_grad.h"
 #include "kernel_regtile_mixed.h"
 #include "kernel_stockham.h"
+#include "kernel_gate.h"
 
 namespace sfft {
 // defined in regtile_n*.hip (one translation unit per length)
@@ -577,6 +578,28 @@ int spectre_mix_bwd(const SpectreMixBwdArgs* a) {
                        (int)(n / 2 + 1));
     if ((e = hipGetLastError()) != hipSuccess) return fail(SPECTRE_E_HIP, "gate-gradient launch failed: %s", hipGetErrorString(e));
   }
+  return SPECTRE_OK;
+}
+
+int spectre_gate_fwd(const SpectreGateArgs* a) {
+  if (!a) return fail(SPECTRE_E_INVALID, "args is NULL");
+  if (a->B < 0 || a->G < 1 || a->K < 1 || a->F < 1) return fail(SPECTRE_E_INVALID, "bad sizes");
+  if (a->phase_sb != 0 && a->phase_sb != a->F) return fail(SPECTRE_E_INVALID, "phase_sb must be 0 or F");
+  if (a->B == 0) return SPECTRE_OK;
+  if (!a->anchors || !a->bias || !a->gate) return fail(SPECTRE_E_INVALID, "anchors, bias and gate must be non-NULL device pointers");
+  if (a->B * a->G * a->F >= ((int64_t)1 << 40) || a->K >= ((int64_t)1 << 24) || a->F >= ((int64_t)1 << 24))
+    return fail(SPECTRE_E_UNSUPPORTED, "gate tensor too large");
+  DeviceGuard g(a->device);
+  if (!g.ok) return fail(SPECTRE_E_HIP, "cannot select device %d", a->device);
+  sfft::GateArgs k{};
+  k.anchors = reinterpret_cast<const float2*>(a->anchors); k.bias = reinterpret_cast<const float*>(a->bias);
+  k.phase = reinterpret_cast<const float2*>(a->phase); k.gate = reinterpret_cast<float2*>(a->gate);
+  k.B = (int)a->B; k.G = (int)a->G; k.K = (int)a->K; k.F = (int)a->F; k.phase_sb = a->phase_sb; k.eps = a->eps;
+  const int64_t total = a->B * a->G * a->F;
+  hipLaunchKernelGGL(sfft::spectre_gate_producer, dim3((unsigned)std::min<int64_t>(8192, (total + 255) / 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(a->stream), k);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(SPECTRE_E_HIP, "gate producer launch failed: %s", hipGetErrorString(e));
   return SPECTRE_OK;
 }
 

@@ -167,3 +167,43 @@ def time_kernel(V, gate, memory_fft=None, n_fft=None, *, out_dtype=None, out=Non
     _native.check(lib.spectre_mix_time(ctypes.byref(a), warmup, iters, ctypes.byref(ms)), "spectre_mix_time")
     del keep
     return float(ms.value)
+
+
+def spectral_gate_fused(anchors: torch.Tensor, bias: torch.Tensor, eps: float, size: int,
+                        pos_phase: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Cubic resample of (B, G, K) complex anchors to `size` bins -> complex modReLU -> optional positional phase,
+    one HIP launch (C ABI `spectre_gate_fwd`; replaces /root/reference/spectre.py:518-524, :530-531, :534-536).
+
+    bias: ComplexModReLU.bias, (G * size,) float32.  pos_phase: (size,), (1, size) or (B, size) complex.
+    Forward only: no autograd graph is recorded (training keeps the PyTorch ops)."""
+    lib = _native.load()
+    if not anchors.is_cuda:
+        raise RuntimeError("spectral_gate_fused runs on a HIP device only (no CPU path)")
+    if anchors.dim() != 3 or anchors.dtype != torch.complex64:
+        raise ValueError(f"anchors must be (B, G, K) complex64, got {tuple(anchors.shape)} {anchors.dtype}")
+    B, G, K = anchors.shape
+    if bias.dtype != torch.float32 or bias.numel() != G * size or bias.device != anchors.device:
+        raise ValueError(f"bias must be ({G * size},) float32 on {anchors.device}")
+    anchors = anchors.contiguous()
+    bias = bias.contiguous()
+    phase, phase_sb = None, 0
+    if pos_phase is not None:
+        phase = pos_phase.to(torch.complex64)
+        if phase.device != anchors.device:
+            raise RuntimeError("pos_phase must be on the same device as the anchors")
+        if phase.dim() == 1 and phase.shape[0] == size:
+            pass
+        elif phase.dim() == 2 and phase.shape[1] == size and phase.shape[0] in (1, B):
+            phase_sb = size if (phase.shape[0] == B and B > 1) else 0
+        else:
+            raise ValueError(f"pos_phase must be ({size},), (1, {size}) or ({B}, {size}), got {tuple(pos_phase.shape)}")
+        phase = phase.contiguous()
+    gate = torch.empty(B, G, size, dtype=torch.complex64, device=anchors.device)
+    a = _native.SpectreGateArgs()
+    a.anchors, a.bias, a.gate = anchors.data_ptr(), bias.data_ptr(), gate.data_ptr()
+    a.phase = phase.data_ptr() if phase is not None else None
+    a.B, a.G, a.K, a.F, a.phase_sb, a.eps = B, G, K, size, phase_sb, float(eps)
+    a.device = anchors.device.index if anchors.device.index is not None else torch.cuda.current_device()
+    a.stream = torch.cuda.current_stream(anchors.device).cuda_stream
+    _native.check(lib.spectre_gate_fwd(ctypes.byref(a)), "spectre_gate_fwd")
+    return gate

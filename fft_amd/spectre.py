@@ -6,9 +6,10 @@ keywords, attribute / parameter / buffer names, `forward` signature and return c
 
 What runs where
 ---------------
-* projections `W_q`, `W_v` (spectre.py:502-503) and the gate producer (pool -> LayerNorm -> MLP -> cubic
-  resample -> modReLU -> positional phase, spectre.py:511-536): stock PyTorch-ROCm ops — O(B*G*F) work,
-  <1 % of the layer's memory traffic.  Exposed as `spectral_gate()`.
+* projections `W_q`, `W_v` (spectre.py:502-503), pooling, LayerNorm and the gate MLP (spectre.py:511-516): stock
+  PyTorch-ROCm ops (GEMMs and O(B*d) work).  The tail of the gate producer — cubic resample -> modReLU ->
+  positional phase (spectre.py:518-536) — is one HIP launch in inference (`spectral_gate_fused`, SURVEY.md
+  section 8(f) row N2) and the same PyTorch ops as the reference under autograd.  Exposed as `spectral_gate()`.
 * rfft -> gate multiply -> (+memory) -> irfft -> slice (spectre.py:506, :542-553): `fft_amd.functional.
   spectral_mix`, one fused gfx950 kernel through the C ABI.  HIP device only; CPU tensors raise.
 
@@ -25,7 +26,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .functional import spectral_mix, spectral_mix_backward
+from .functional import spectral_gate_fused, spectral_mix, spectral_mix_backward
 
 try:  # optional, exactly as the reference treats it (spectre.py:10-14)
     import torch_dct as _dct
@@ -65,6 +66,11 @@ class ComplexModReLU(nn.Module):
         super().__init__()
         self.bias = nn.Parameter(torch.full((num_features,), -0.1))
         self.register_buffer("eps", torch.tensor(1e-4))
+        self.eps_value = 1e-4          # host copy for the fused gate kernel (reading the buffer would synchronise)
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+        self.eps_value = float(self.eps)
 
     def forward(self, z: torch.Tensor) -> torch.Tensor:
         mag = torch.abs(z)
@@ -182,6 +188,9 @@ class SpectreHead(nn.Module):
         V = self.W_v(x)
         q_pool = self.q_norm(self.pooling(Q))
         anchors = torch.view_as_complex(self.gate_mlp(q_pool).view(Bsz, self.G, self.B, 2))
+        if x.is_cuda and anchors.dtype == torch.complex64 and not (torch.is_grad_enabled() and anchors.requires_grad):
+            # inference: resample -> modReLU -> phase as one HIP launch (row N2); training keeps the ops autograd sees
+            return V, spectral_gate_fused(anchors, self.modrelu.bias.detach(), self.modrelu.eps_value, self.F_half, pos_phase), q_pool
         gate = resample_complex(anchors, self.F_half, mode="cubic")
         gate = self.modrelu(gate.reshape(Bsz, -1)).view_as(gate)
         if pos_phase is not None:

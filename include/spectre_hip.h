@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SPECTRE_ABI_VERSION 2
+#define SPECTRE_ABI_VERSION 3
 
 enum {
   SPECTRE_OK = 0,
@@ -118,6 +118,29 @@ int spectre_mix_bwd(const SpectreMixBwdArgs* args);
  * arguments on args->stream, bracketed by HIP events recorded on that stream, and returns the average
  * per-launch time in milliseconds.  (Synchronises the stream; not part of the data path.) */
 int spectre_mix_time(const SpectreMixArgs* args, int warmup, int iters, float* ms_per_launch);
+
+/* Gate producer tail: replaces spectre.py:518-524 (complex_interp, mode="cubic":
+ * grid_sample bicubic / border / align_corners=True on a height-1 image), :530-531 (ComplexModReLU, spectre.py:109-121)
+ * and :534-536 (positional phase) — about a dozen ATen launches — with one launch.
+ *   anchors (B, G, K)  complex64 contiguous: the gate MLP output viewed as complex (spectre.py:515-516)
+ *   bias    (G * F)    f32: ComplexModReLU.bias, indexed g * F + k (the reference flattens (G, F) per batch element)
+ *   phase   (F) or (B, F) complex64 or NULL; phase_sb = 0 (shared) or F (per batch element)
+ *   gate    (B, G, F)  complex64 out — the tensor spectre_mix_fwd consumes
+ * Forward only (inference); training keeps the PyTorch ops so that autograd sees them.
+ */
+typedef struct SpectreGateArgs {
+  const void* anchors;
+  const void* bias;
+  const void* phase;
+  void* gate;
+  int64_t B, G, K, F;
+  int64_t phase_sb;
+  float eps;          /* ComplexModReLU.eps buffer (1e-4 in the reference) */
+  int32_t device;
+  void* stream;
+} SpectreGateArgs;
+
+int spectre_gate_fwd(const SpectreGateArgs* args);
 
 #ifdef __cplusplus
 }
