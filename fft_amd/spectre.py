@@ -145,6 +145,8 @@ class _SpectralMixFn(torch.autograd.Function):
 class SpectreHead(nn.Module):
     """Frequency-domain token mixer for one head — same surface as spectre.py:400-557."""
 
+    fold_mean_pooling = True       # on HIP devices, pool x before W_q when the pooling is the plain mean (see spectral_gate)
+
     def __init__(self, embed_dim: int, fft_size: int, *, num_groups: int = 4, num_buckets: Optional[int] = None,
                  d_gate: int = 256, use_toeplitz: bool = False, toeplitz_bw: int = 4, dropout_p: float = 0.0,
                  pooling_type: str = "dct"):
@@ -184,9 +186,14 @@ class SpectreHead(nn.Module):
         """Returns (V (B,N,d), gate (B,G,F_half) complex64, q_pool (B,d))."""
         Bsz, N, d = x.shape
         assert d == self.d
-        Q = self.W_q(x)
         V = self.W_v(x)
-        q_pool = self.q_norm(self.pooling(Q))
+        if self.fold_mean_pooling and x.is_cuda and isinstance(self.pooling, MeanPool):
+            # mean_n(W_q x_n) = W_q(mean_n x_n): W_q has no bias and Q feeds nothing but the pooling (spectre.py:502,
+            # :511-512), so the (B,N,d) x (d,d) GEMM and the pass over Q collapse into a row mean and a (B,d) GEMM —
+            # half of the layer's GEMM time.  Same value up to fp32 summation order.
+            q_pool = self.q_norm(self.W_q(x.mean(dim=1)))
+        else:
+            q_pool = self.q_norm(self.pooling(self.W_q(x)))
         anchors = torch.view_as_complex(self.gate_mlp(q_pool).view(Bsz, self.G, self.B, 2))
         if x.is_cuda and anchors.dtype == torch.complex64 and not (torch.is_grad_enabled() and anchors.requires_grad):
             # inference: resample -> modReLU -> phase as one HIP launch (row N2); training keeps the ops autograd sees

@@ -34,3 +34,17 @@ def test_memory_fft_gradient_is_refused_not_silently_dropped():
     with pytest.raises(NotImplementedError, match="memory_fft"):
         head(x, memory_fft=mem)
     head(x, memory_fft=mem.detach()).sum().backward()               # frozen memory (as in the reference) trains fine
+
+
+def test_mean_pooling_fold_is_the_same_layer():
+    """mean_n(W_q x) == W_q(mean_n x): folding the query GEMM into the pooled vector changes nothing but rounding."""
+    from fft_amd import SpectreHead
+    torch.manual_seed(1)
+    head = SpectreHead(64, 512, num_groups=4, pooling_type="mean").to("cuda:0").eval()
+    x = torch.randn(3, 512, 64, device="cuda:0")
+    with torch.no_grad():
+        y1, q1 = head(x, return_q_pool=True)
+        head.fold_mean_pooling = False
+        y0, q0 = head(x, return_q_pool=True)
+    assert float((q1 - q0).abs().max()) <= 2e-5 * float(q0.abs().max())
+    assert_close(y1.cpu().numpy(), y0.cpu().numpy(), rtol=1e-4, atol_rms=1e-4, what="folded vs unfolded")
