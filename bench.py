@@ -154,6 +154,16 @@ def main():
             variants[name] = {"tokens_per_s": B * N / (ms * 1e-3), "kernel_ms": ms, "achieved_GBps": byt / ms / 1e6,
                               "roofline_frac": byt / ms / 1e6 / HBM_PEAK_GBS}
             del Vv, ov
+        # the other single-GPU configurations of BASELINE.json / SURVEY.md section 8(d), informational (C1 and C4)
+        for name, (Bc, Nc, Dc) in (("C1_f32_256x1024x768", (256, 1024, 768)), ("C4_f32_256x3000x768", (256, 3000, 768))):
+            Vc = torch.randn(Bc, Nc, Dc, device=dev)
+            gc = torch.randn(Bc, G, Nc // 2 + 1, dtype=torch.complex64, device=dev) * 0.3
+            oc = torch.empty_like(Vc)
+            ms = time_kernel(Vc, gc, None, Nc, out=oc, warmup=2, iters=max(3, a.steps // 2))
+            byt = algorithmic_bytes(Bc, Nc, Nc, Dc, G, 4, 4)
+            variants[name] = {"tokens_per_s": Bc * Nc / (ms * 1e-3), "kernel_ms": ms, "achieved_GBps": byt / ms / 1e6,
+                              "roofline_frac": byt / ms / 1e6 / HBM_PEAK_GBS, "kernel": describe(Vc, gc, None, Nc)}
+            del Vc, gc, oc
         # backward of the same op (row N1), informational: dV = the forward kernels with conj(gate); dgate = gate-gradient kernel
         from fft_amd import spectral_mix_backward
         dout = torch.randn(B, N, D, device=dev).to(dt)

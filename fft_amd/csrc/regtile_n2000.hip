@@ -1,3 +1,3 @@
 // regtile_n2000.hip — n_fft = 2000 (= 50 x 40) instantiations of the mixed-radix register-resident kernel (own TU)
-#include "kernel_regtile_mixed.h"
-namespace sfft { SFFT_DEFINE_REGTILE_MIXED_LAUNCHER_SAME_DTYPE(50, 40) }
+#include "kernel_regtile_mixed_grad.h"
+namespace sfft { SFFT_DEFINE_REGTILE_MIXED_LAUNCHER_SAME_DTYPE(50, 40) SFFT_DEFINE_GATE_GRAD_MIXED_LAUNCHER(50, 40) }

@@ -18,7 +18,7 @@
 
 #include "../../include/spectre_hip.h"
 #include "kernel_regtile_grad.h"
-#include "kernel_regtile_mixed.h"
+#include "kernel_regtile_mixed_grad.h"
 #include "kernel_stockham.h"
 #include "kernel_gate.h"
 
@@ -38,33 +38,48 @@ template <> hipError_t launch_regtile_mixed<50, 40>(const RegtileArgs&, bool, bo
 template <> hipError_t launch_regtile_mixed<40, 32>(const RegtileArgs&, bool, bool, int, hipStream_t);
 template <> hipError_t launch_regtile_mixed<64, 40>(const RegtileArgs&, bool, bool, int, hipStream_t);
 template <> hipError_t launch_regtile_mixed<64, 60>(const RegtileArgs&, bool, bool, int, hipStream_t);
+template <> hipError_t launch_gate_grad_regtile<16, 16>(const GateGradArgs&, bool, bool, hipStream_t);
+template <> hipError_t launch_gate_grad_regtile<32, 16>(const GateGradArgs&, bool, bool, hipStream_t);
+template <> hipError_t launch_gate_grad_regtile<32, 32>(const GateGradArgs&, bool, bool, hipStream_t);
+template <> hipError_t launch_gate_grad_regtile<64, 32>(const GateGradArgs&, bool, bool, hipStream_t);
+template <> hipError_t launch_gate_grad_regtile<64, 64>(const GateGradArgs&, bool, bool, hipStream_t);
+template <> hipError_t launch_gate_grad_mixed<60, 50>(const GateGradArgs&, bool, bool, hipStream_t);
+template <> hipError_t launch_gate_grad_mixed<32, 24>(const GateGradArgs&, bool, bool, hipStream_t);
+template <> hipError_t launch_gate_grad_mixed<48, 32>(const GateGradArgs&, bool, bool, hipStream_t);
+template <> hipError_t launch_gate_grad_mixed<64, 48>(const GateGradArgs&, bool, bool, hipStream_t);
+template <> hipError_t launch_gate_grad_mixed<50, 40>(const GateGradArgs&, bool, bool, hipStream_t);
+template <> hipError_t launch_gate_grad_mixed<40, 32>(const GateGradArgs&, bool, bool, hipStream_t);
+template <> hipError_t launch_gate_grad_mixed<64, 40>(const GateGradArgs&, bool, bool, hipStream_t);
+template <> hipError_t launch_gate_grad_mixed<64, 60>(const GateGradArgs&, bool, bool, hipStream_t);
 }  // namespace sfft
 
 namespace {
 
 // register-resident kernels: n_fft = RF * RS
 using TileLauncher = hipError_t (*)(const sfft::RegtileArgs&, bool, bool, int, hipStream_t);
+using GradLauncher = hipError_t (*)(const sfft::GateGradArgs&, bool, bool, hipStream_t);
 struct TileSize {
   int n, RF, RS;
   bool mixed;        // kernel_regtile_mixed.h (arbitrary 2/3/5-smooth factors) instead of kernel_regtile.h
   bool same_dtype;   // built for f32->f32 and bf16->bf16 only
   TileLauncher launch;
+  GradLauncher grad;   // register-resident gate gradient, or nullptr (LDS Stockham path)
 };
 const TileSize kTileSizes[] = {
-    {256, 16, 16, false, false, &sfft::launch_regtile<16, 16>},
-    {512, 32, 16, false, false, &sfft::launch_regtile<32, 16>},
-    {1024, 32, 32, false, false, &sfft::launch_regtile<32, 32>},
-    {2048, 64, 32, false, false, &sfft::launch_regtile<64, 32>},
-    {4096, 64, 64, false, false, &sfft::launch_regtile<64, 64>},
-    {3000, 60, 50, true, false, &sfft::launch_regtile_mixed<60, 50>},
-    {768, 32, 24, true, true, &sfft::launch_regtile_mixed<32, 24>},
-    {1536, 48, 32, true, true, &sfft::launch_regtile_mixed<48, 32>},
-    {3072, 64, 48, true, true, &sfft::launch_regtile_mixed<64, 48>},
-    {1000, 40, 25, true, true, &sfft::launch_regtile_mixed<40, 25>},
-    {2000, 50, 40, true, true, &sfft::launch_regtile_mixed<50, 40>},
-    {1280, 40, 32, true, true, &sfft::launch_regtile_mixed<40, 32>},
-    {2560, 64, 40, true, true, &sfft::launch_regtile_mixed<64, 40>},
-    {3840, 64, 60, true, true, &sfft::launch_regtile_mixed<64, 60>},
+    {256, 16, 16, false, false, &sfft::launch_regtile<16, 16>, &sfft::launch_gate_grad_regtile<16, 16>},
+    {512, 32, 16, false, false, &sfft::launch_regtile<32, 16>, &sfft::launch_gate_grad_regtile<32, 16>},
+    {1024, 32, 32, false, false, &sfft::launch_regtile<32, 32>, &sfft::launch_gate_grad_regtile<32, 32>},
+    {2048, 64, 32, false, false, &sfft::launch_regtile<64, 32>, &sfft::launch_gate_grad_regtile<64, 32>},
+    {4096, 64, 64, false, false, &sfft::launch_regtile<64, 64>, &sfft::launch_gate_grad_regtile<64, 64>},
+    {3000, 60, 50, true, false, &sfft::launch_regtile_mixed<60, 50>, &sfft::launch_gate_grad_mixed<60, 50>},
+    {768, 32, 24, true, true, &sfft::launch_regtile_mixed<32, 24>, &sfft::launch_gate_grad_mixed<32, 24>},
+    {1536, 48, 32, true, true, &sfft::launch_regtile_mixed<48, 32>, &sfft::launch_gate_grad_mixed<48, 32>},
+    {3072, 64, 48, true, true, &sfft::launch_regtile_mixed<64, 48>, &sfft::launch_gate_grad_mixed<64, 48>},
+    {1000, 40, 25, true, true, &sfft::launch_regtile_mixed<40, 25>, nullptr},
+    {2000, 50, 40, true, true, &sfft::launch_regtile_mixed<50, 40>, &sfft::launch_gate_grad_mixed<50, 40>},
+    {1280, 40, 32, true, true, &sfft::launch_regtile_mixed<40, 32>, &sfft::launch_gate_grad_mixed<40, 32>},
+    {2560, 64, 40, true, true, &sfft::launch_regtile_mixed<64, 40>, &sfft::launch_gate_grad_mixed<64, 40>},
+    {3840, 64, 60, true, true, &sfft::launch_regtile_mixed<64, 60>, &sfft::launch_gate_grad_mixed<64, 60>},
 };
 const TileSize* find_tile_size(int64_t n) {
   for (const TileSize& t : kTileSizes)
@@ -501,19 +516,12 @@ int spectre_mix_bwd(const SpectreMixBwdArgs* a) {
     Plan* plan = nullptr;
     if ((rc = get_plan(a->device, a->n_fft, &plan))) return rc;
     const int64_t n = a->n_fft, D = a->D, d_g = D / a->G_tot;
-    int RF = 0, RS = 0;
-    switch (n) {
-      case 256: RF = 16; RS = 16; break;
-      case 512: RF = 32; RS = 16; break;
-      case 1024: RF = 32; RS = 32; break;
-      case 2048: RF = 64; RS = 32; break;
-      case 4096: RF = 64; RS = 64; break;
-      default: break;
-    }
+    const TileSize* ts = find_tile_size(n);
     static const bool force_stockham = [] { const char* e = getenv("SPECTRE_GATE_GRAD"); return e && !strcmp(e, "stockham"); }();
-    if (RF && !force_stockham && a->v_sn * 64 * 4 < ((int64_t)1 << 31) && a->dout_sn * 64 * 4 < ((int64_t)1 << 31) &&
+    if (ts && ts->grad && !force_stockham && a->v_sn * 64 * 4 < ((int64_t)1 << 31) && a->dout_sn * 64 * 4 < ((int64_t)1 << 31) &&
         a->B * a->G_tot * 8 < ((int64_t)1 << 31)) {
-      // register-tile gate gradient (kernel_regtile_grad.h): 8-channel tiles, S workgroups per (batch, group)
+      // register-tile gate gradient (kernel_regtile_grad.h / kernel_regtile_mixed_grad.h): 8-channel tiles, S workgroups
+      // per (batch, group)
       sfft::GateGradArgs k{};
       k.v = a->v; k.dout = a->dout; k.part = reinterpret_cast<float2*>(a->workspace); k.tw = plan->tw_n;
       k.B = (int)a->B; k.N_in = (int)std::min<int64_t>(a->N_in, (int64_t)1 << 30); k.D = (int)D; k.G = (int)a->G_tot;
@@ -524,12 +532,7 @@ int spectre_mix_bwd(const SpectreMixBwdArgs* a) {
       k.S = S; k.n_wg = (int)(a->B * a->G_tot * S);
       k.v_sb = a->v_sb; k.v_sn = a->v_sn; k.dout_sb = a->dout_sb; k.dout_sn = a->dout_sn;
       const bool bf = a->io_dtype == SPECTRE_BF16, general = (a->N_in < n) || (d_g % 8 != 0);
-      hipError_t e;
-      if (RF == 16) e = sfft::launch_gate_grad_regtile<16, 16>(k, bf, general, stream);
-      else if (RF == 32 && RS == 16) e = sfft::launch_gate_grad_regtile<32, 16>(k, bf, general, stream);
-      else if (RF == 32) e = sfft::launch_gate_grad_regtile<32, 32>(k, bf, general, stream);
-      else if (RS == 32) e = sfft::launch_gate_grad_regtile<64, 32>(k, bf, general, stream);
-      else e = sfft::launch_gate_grad_regtile<64, 64>(k, bf, general, stream);
+      hipError_t e = ts->grad(k, bf, general, stream);
       if (e != hipSuccess) return fail(SPECTRE_E_HIP, "gate-gradient launch failed: %s", hipGetErrorString(e));
       const int64_t total = a->B * a->G_tot * (n / 2 + 1);
       hipLaunchKernelGGL(sfft::spectre_gate_grad_regtile_finish<0>, dim3((unsigned)std::min<int64_t>(4096, (total + 255) / 256)), dim3(256), 0,
