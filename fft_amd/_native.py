@@ -14,14 +14,15 @@ import torch  # noqa: F401  — must be imported first: the library binds to the
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPECTRE_HIP_LIB") or os.path.join(_HERE, "lib", "libspectre_hip.so")   # env: A/B builds
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 F32, BF16 = 0, 1
 ALGO = {"auto": 0, "stockham": 1, "regtile": 2}
 
 # every symbol include/spectre_hip.h declares
 EXPORTS = ("spectre_version", "spectre_last_error", "spectre_mix_fwd", "spectre_mix_describe",
            "spectre_plan_create", "spectre_plan_destroy", "spectre_mix_time", "spectre_mix_bwd",
-           "spectre_mix_bwd_workspace_bytes", "spectre_gate_fwd")
+           "spectre_mix_bwd_workspace_bytes", "spectre_gate_fwd", "spectre_rfft_fwd", "spectre_decode_workspace_bytes",
+           "spectre_decode_step")
 
 
 class SpectreMixArgs(ctypes.Structure):
@@ -40,6 +41,24 @@ class SpectreGateArgs(ctypes.Structure):
         ("anchors", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("phase", ctypes.c_void_p), ("gate", ctypes.c_void_p),
         ("B", ctypes.c_int64), ("G", ctypes.c_int64), ("K", ctypes.c_int64), ("F", ctypes.c_int64),
         ("phase_sb", ctypes.c_int64), ("eps", ctypes.c_float), ("device", ctypes.c_int32), ("stream", ctypes.c_void_p),
+    ]
+
+
+class SpectreRfftArgs(ctypes.Structure):
+    _fields_ = [
+        ("v", ctypes.c_void_p), ("spec", ctypes.c_void_p),
+        ("B", ctypes.c_int64), ("N_in", ctypes.c_int64), ("n_fft", ctypes.c_int64), ("D", ctypes.c_int64),
+        ("v_sb", ctypes.c_int64), ("v_sn", ctypes.c_int64),
+        ("in_dtype", ctypes.c_int32), ("device", ctypes.c_int32), ("stream", ctypes.c_void_p),
+    ]
+
+
+class SpectreDecodeArgs(ctypes.Structure):
+    _fields_ = [
+        ("prefix", ctypes.c_void_p), ("v_old", ctypes.c_void_p), ("v_new", ctypes.c_void_p), ("gate", ctypes.c_void_p),
+        ("out", ctypes.c_void_p), ("workspace", ctypes.c_void_p),
+        ("n_fft", ctypes.c_int64), ("d", ctypes.c_int64), ("G", ctypes.c_int64), ("t", ctypes.c_int64),
+        ("device", ctypes.c_int32), ("stream", ctypes.c_void_p),
     ]
 
 
@@ -98,6 +117,12 @@ def load():
         lib.spectre_mix_bwd_workspace_bytes.restype = ctypes.c_int64
         lib.spectre_gate_fwd.argtypes = [ctypes.POINTER(SpectreGateArgs)]
         lib.spectre_gate_fwd.restype = ctypes.c_int
+        lib.spectre_rfft_fwd.argtypes = [ctypes.POINTER(SpectreRfftArgs)]
+        lib.spectre_rfft_fwd.restype = ctypes.c_int
+        lib.spectre_decode_workspace_bytes.argtypes = [ctypes.c_int64] * 2
+        lib.spectre_decode_workspace_bytes.restype = ctypes.c_int64
+        lib.spectre_decode_step.argtypes = [ctypes.POINTER(SpectreDecodeArgs)]
+        lib.spectre_decode_step.restype = ctypes.c_int
         ver = lib.spectre_version()
         if ver != ABI_VERSION:
             raise NativeLibraryError(f"ABI mismatch: library {ver}, binding {ABI_VERSION}")

@@ -21,6 +21,7 @@
 #include "kernel_regtile_mixed_grad.h"
 #include "kernel_stockham.h"
 #include "kernel_gate.h"
+#include "kernel_decode.h"
 
 namespace sfft {
 // defined in regtile_n*.hip (one translation unit per length)
@@ -603,6 +604,85 @@ int spectre_gate_fwd(const SpectreGateArgs* a) {
                      reinterpret_cast<hipStream_t>(a->stream), k);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(SPECTRE_E_HIP, "gate producer launch failed: %s", hipGetErrorString(e));
+  return SPECTRE_OK;
+}
+
+int spectre_rfft_fwd(const SpectreRfftArgs* a) {
+  if (!a) return fail(SPECTRE_E_INVALID, "args is NULL");
+  if (a->B < 0 || a->N_in < 1 || a->n_fft < 1 || a->D < 1) return fail(SPECTRE_E_INVALID, "bad sizes");
+  if (a->in_dtype != SPECTRE_F32 && a->in_dtype != SPECTRE_BF16) return fail(SPECTRE_E_UNSUPPORTED, "bad in_dtype");
+  if (a->B == 0) return SPECTRE_OK;
+  if (!a->v || !a->spec) return fail(SPECTRE_E_INVALID, "v and spec must be non-NULL device pointers");
+  DeviceGuard g(a->device);
+  if (!g.ok) return fail(SPECTRE_E_HIP, "cannot select device %d", a->device);
+  // slot geometry of the general LDS kernel: one gate channel per batch element stands in for "no filter"
+  SpectreMixArgs f{};
+  f.v = a->v; f.gate = a->spec; f.mem = nullptr; f.out = a->spec;
+  f.B = a->B; f.N_in = a->N_in; f.n_fft = a->n_fft; f.D = a->D; f.G_tot = (a->D % 2) ? a->D : 1;
+  f.v_sb = a->v_sb; f.v_sn = a->v_sn; f.out_sb = 0; f.out_sn = a->D;
+  f.in_dtype = a->in_dtype; f.out_dtype = SPECTRE_F32; f.algo = SPECTRE_ALGO_STOCKHAM; f.device = a->device; f.stream = a->stream;
+  Plan* plan = nullptr;
+  Choice c;
+  int rc = prepare(&f, &plan, &c);
+  if (rc) return rc;
+  sfft::StockhamArgs k{};
+  k.v = a->v; k.out = a->spec;
+  k.B = (int)a->B; k.N_in = (int)std::min<int64_t>(a->N_in, (int64_t)1 << 30); k.N = (int)a->n_fft; k.D = (int)a->D;
+  k.G = 1; k.d_g = (int)a->D; k.F = (int)(a->n_fft / 2 + 1);
+  k.P = c.P; k.S = c.S; k.solo = c.solo; k.groups_per_batch = (c.S + c.P - 1) / c.P;
+  k.in_bf16 = a->in_dtype == SPECTRE_BF16;
+  k.v_sb = a->v_sb; k.v_sn = a->v_sn;
+  const std::vector<int>& rad = plan->bluestein ? plan->radix_m : plan->radix_n;
+  k.L = (int)(plan->bluestein ? plan->m : a->n_fft);
+  k.n_pass = (int)rad.size();
+  if (k.n_pass > sfft::kMaxPasses) return fail(SPECTRE_E_UNSUPPORTED, "too many Stockham passes (%d)", k.n_pass);
+  for (int i = 0; i < k.n_pass; ++i) k.radix_packed[i / 8] |= (unsigned long long)rad[(size_t)i] << (8 * (i % 8));
+  k.tw = plan->bluestein ? plan->tw_m : plan->tw_n;
+  k.bluestein = plan->bluestein ? 1 : 0; k.chirp = plan->chirp; k.bhat = plan->bhat;
+  const size_t lds = (size_t)k.L * k.P * sizeof(float2);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sfft::spectre_rfft_stockham),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return fail(SPECTRE_E_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+  int64_t need = ((int64_t)k.L * k.P + 7) / 8;
+  for (int i = 0; i < k.n_pass; ++i) {
+    const int r = rad[(size_t)i];
+    need = std::max<int64_t>(need, (((int64_t)k.L / r) * k.P + sfft::stockham_kmax(r) - 1) / sfft::stockham_kmax(r));
+  }
+  const int threads = (int)std::min<int64_t>(sfft::kStockhamMaxThreads, std::max<int64_t>(64, (need + 63) / 64 * 64));
+  hipLaunchKernelGGL(sfft::spectre_rfft_stockham, dim3((unsigned)(a->B * k.groups_per_batch)), dim3(threads), lds,
+                     reinterpret_cast<hipStream_t>(a->stream), k);
+  if ((e = hipGetLastError()) != hipSuccess) return fail(SPECTRE_E_HIP, "rfft launch failed: %s", hipGetErrorString(e));
+  return SPECTRE_OK;
+}
+
+int64_t spectre_decode_workspace_bytes(int64_t n_fft, int64_t d) {
+  if (n_fft < 1 || d < 1) return 0;
+  const int64_t F = n_fft / 2 + 1;
+  return ((F + sfft::kDecodeChunk - 1) / sfft::kDecodeChunk) * d * (int64_t)sizeof(float);
+}
+
+int spectre_decode_step(const SpectreDecodeArgs* a) {
+  if (!a) return fail(SPECTRE_E_INVALID, "args is NULL");
+  if (a->n_fft < 1 || a->d < 1 || a->t < 0 || a->t >= ((int64_t)1 << 24)) return fail(SPECTRE_E_INVALID, "bad sizes (t must be < 2^24)");
+  if (!a->prefix || !a->v_old || !a->v_new) return fail(SPECTRE_E_INVALID, "prefix, v_old and v_new must be non-NULL device pointers");
+  if (a->gate && (a->G < 1 || a->d % a->G || !a->out || !a->workspace)) return fail(SPECTRE_E_INVALID, "gate given: need G | d, out and workspace");
+  if (a->n_fft >= ((int64_t)1 << 24) || a->d >= ((int64_t)1 << 24)) return fail(SPECTRE_E_UNSUPPORTED, "sizes too large");
+  DeviceGuard g(a->device);
+  if (!g.ok) return fail(SPECTRE_E_HIP, "cannot select device %d", a->device);
+  hipStream_t stream = reinterpret_cast<hipStream_t>(a->stream);
+  sfft::DecodeArgs k{};
+  k.prefix = reinterpret_cast<float2*>(a->prefix); k.v_old = reinterpret_cast<const float*>(a->v_old);
+  k.v_new = reinterpret_cast<const float*>(a->v_new); k.gate = reinterpret_cast<const float2*>(a->gate);
+  k.partial = reinterpret_cast<float*>(a->workspace);
+  k.n = (int)a->n_fft; k.F = (int)(a->n_fft / 2 + 1); k.d = (int)a->d; k.d_g = a->gate ? (int)(a->d / a->G) : (int)a->d;
+  k.t = (int)a->t; k.j = (int)(a->t % a->n_fft); k.evict = a->t >= a->n_fft ? 1 : 0; k.chunk = sfft::kDecodeChunk;
+  const int chunks = (k.F + k.chunk - 1) / k.chunk;
+  hipLaunchKernelGGL(sfft::spectre_decode_step, dim3((unsigned)chunks, (unsigned)((k.d + 63) / 64)), dim3(256), 0, stream, k);
+  if (a->gate)
+    hipLaunchKernelGGL(sfft::spectre_decode_finish, dim3((unsigned)((k.d + 255) / 256)), dim3(256), 0, stream, k.partial,
+                       reinterpret_cast<float*>(a->out), chunks, k.d, k.n);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(SPECTRE_E_HIP, "decode launch failed: %s", hipGetErrorString(e));
   return SPECTRE_OK;
 }
 

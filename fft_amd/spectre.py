@@ -218,3 +218,10 @@ class SpectreHead(nn.Module):
         if return_q_pool:
             return result, q_pool
         return result
+
+    @torch.no_grad()
+    def decode_step(self, q_t: torch.Tensor, v_t: torch.Tensor, cache) -> torch.Tensor:
+        """Incremental generation update for one head, batch size 1 (spectre.py:564-611): q_t, v_t (d,) and a
+        `fft_amd.PrefixFFTCache`; returns the mixed vector (d,) of the current time step."""
+        from .decode import head_decode_step
+        return head_decode_step(self, q_t, v_t, cache)

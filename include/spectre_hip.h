@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SPECTRE_ABI_VERSION 3
+#define SPECTRE_ABI_VERSION 4
 
 enum {
   SPECTRE_OK = 0,
@@ -141,6 +141,49 @@ typedef struct SpectreGateArgs {
 } SpectreGateArgs;
 
 int spectre_gate_fwd(const SpectreGateArgs* args);
+
+/* Prefill: replaces PrefixFFTCache.prefill's `torch.fft.rfft(F.pad(V, ...), dim=0)`
+ * (spectre.py:775-776), batched: spec[b, k, c] = sum_n v[b, n, c] exp(-2 pi i k n / n_fft), k <= n_fft/2, rows beyond N_in
+ * read as zero.
+ *   v     (B, N_in, D)  f32|bf16, last dim unit stride, element strides v_sb, v_sn
+ *   spec  (B, F, D)     complex64 contiguous out, F = n_fft/2 + 1
+ */
+typedef struct SpectreRfftArgs {
+  const void* v;
+  void* spec;
+  int64_t B, N_in, n_fft, D;
+  int64_t v_sb, v_sn;
+  int32_t in_dtype;
+  int32_t device;
+  void* stream;
+} SpectreRfftArgs;
+
+int spectre_rfft_fwd(const SpectreRfftArgs* args);
+
+/* One decode step of one head (batch 1): replaces PrefixFFTCache.decode_step's spectrum update (spectre.py:794-805:
+ * evict the token that leaves the ring, add the new one) and, when `gate` is given, SpectreHead.decode_step's
+ * `gate_broadcast * prefix_fft` (:597-603) and `pruned_irfft_single` (:614-655) in the same pass over the spectrum.
+ *   prefix  (F, d)  complex64, updated in place          v_old (d) f32: V_buf[t % n_fft] before this step
+ *   v_new   (d) f32                                       gate  (G, F) complex64 or NULL (state update only)
+ *   out     (d) f32 (ignored when gate is NULL)           workspace: spectre_decode_workspace_bytes(n_fft, d) bytes
+ *   t       absolute position of the new token (cache.t after the increment); eviction happens when t >= n_fft
+ * The ring buffers and the running query sum stay with the caller (a few d-element copies).
+ */
+typedef struct SpectreDecodeArgs {
+  void* prefix;
+  const void* v_old;
+  const void* v_new;
+  const void* gate;
+  void* out;
+  void* workspace;
+  int64_t n_fft, d, G;
+  int64_t t;
+  int32_t device;
+  void* stream;
+} SpectreDecodeArgs;
+
+int64_t spectre_decode_workspace_bytes(int64_t n_fft, int64_t d);
+int spectre_decode_step(const SpectreDecodeArgs* args);
 
 #ifdef __cplusplus
 }

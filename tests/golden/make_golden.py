@@ -179,6 +179,32 @@ def case_backward(name, B, N, d, n_fft, G, seed):
     print(f"{name:28s} backward x{tuple(x.shape)} dV{tuple(V.grad.shape)} dgate{(B, G, head.F_half)}  {os.path.getsize(path) / 1e3:.0f} kB")
 
 
+def case_decode(name, d, n_fft, G, seed, L, T, *, with_mem=False):
+    """Prefill + T single-token decode steps of one head (spectre.py:731-814 `PrefixFFTCache`, :564-611 `decode_step`,
+    :614-655 `pruned_irfft_single`): row N4 of SURVEY.md section 8(f).  Inputs and everything the reference returned."""
+    head = _head(d, n_fft, G, seed)
+    g = torch.Generator().manual_seed(seed + 4000)
+    Qp, Vp = torch.randn(L, d, generator=g), torch.randn(L, d, generator=g)
+    q_seq, v_seq = torch.randn(T, d, generator=g), torch.randn(T, d, generator=g)
+    cache = ref.PrefixFFTCache(n_fft, d, device=torch.device("cpu"))
+    cache.prefill(Qp, Vp)
+    extra = {"prefix_after_prefill": cache.prefix_fft.clone().numpy()}
+    if with_mem:
+        mem = torch.complex(torch.randn(n_fft // 2 + 1, d, generator=g), torch.randn(n_fft // 2 + 1, d, generator=g)) * 0.5
+        cache.prefix_fft += mem                      # the usage the reference documents (spectre.py:736-741)
+        extra["mem"] = mem.numpy()
+    outs = torch.stack([head.decode_step(q_seq[i], v_seq[i], cache) for i in range(T)])
+    d_out = {"Qp": Qp.numpy(), "Vp": Vp.numpy(), "q_seq": q_seq.numpy(), "v_seq": v_seq.numpy(), "outs": outs.numpy(),
+             "prefix_final": cache.prefix_fft.numpy(), "sum_q_final": cache.sum_q.numpy(), "t_final": np.int64(cache.t),
+             "n_fft": np.int64(n_fft), "G": np.int64(G)}
+    d_out.update(extra)
+    for k, v in head.state_dict().items():
+        d_out["sd/" + k] = v.numpy()
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **d_out)
+    print(f"{name:28s} decode L={L} T={T} d={d} n_fft={n_fft}  {os.path.getsize(path) / 1e3:.0f} kB")
+
+
 def g_random(scale=0.3, zero_frac=0.18):
     def f(B, G, F, gen):
         z = torch.complex(torch.randn(B, G, F, generator=gen), torch.randn(B, G, F, generator=gen)) * scale
@@ -244,10 +270,23 @@ def main():
     case_backward("g9_bwd_trunc_n80_fft64", 2, 80, 16, 64, 2, 27)
     case_backward("g9_bwd_n60", 2, 60, 12, 60, 2, 28)
     case_backward("g9_bwd_n1024", 1, 1024, 16, 1024, 2, 29)
+    # G10 — prefill + autoregressive decode (ring buffer wrap, eviction, non-power-of-two and odd n_fft, memory)
+    case_decode("g10_decode_n64", 32, 64, 2, 30, L=40, T=60)
+    case_decode("g10_decode_n256_full", 64, 256, 4, 31, L=256, T=20)
+    case_decode("g10_decode_n60", 16, 60, 2, 32, L=10, T=70)
+    case_decode("g10_decode_n15_odd", 8, 15, 2, 33, L=5, T=25)
+    case_decode("g10_decode_n128_mem", 32, 128, 4, 34, L=100, T=40, with_mem=True)
     # G8 — bf16 input values; oracle = reference on x_bf16.float(); bf16 rounding of the result stored
     case_fixed_gate("g8_bf16_n1024", 1, 1024, 16, 1024, 4, 22, g_random(), bf16=True)
     case_fixed_gate("g8_bf16_n4096", 1, 4096, 16, 4096, 4, 23, g_random(), bf16=True)
 
 
 if __name__ == "__main__":
+    # optional name prefixes: `python make_golden.py g10` regenerates only the matching cases
+    if len(sys.argv) > 1:
+        _only = tuple(sys.argv[1:])
+        for _fn in ("case_module", "case_fixed_gate", "case_backward", "case_decode"):
+            def _wrap(f):
+                return lambda name, *a, **k: f(name, *a, **k) if name.startswith(_only) else None
+            globals()[_fn] = _wrap(globals()[_fn])
     main()

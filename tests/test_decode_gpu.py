@@ -1,0 +1,85 @@
+"""Row N4 on a real GPU: prefill (spectre_rfft_fwd) and decode (spectre_decode_step + spectre_gate_fwd) through the C ABI
+against what the reference produced (fixtures g10_decode_*) and against the CPU oracle at the benchmark width."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle.decode_oracle import PrefixFFTCacheOracle, decode_step_oracle
+from oracle.spectral_mix_oracle import assert_close
+from test_decode_cpu import DECODE, IDS
+from test_module_cpu import _build
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("path", DECODE, ids=IDS)
+def test_decode_matches_reference_fixtures(path):
+    from fft_amd import PrefixFFTCache
+    d = load_golden(path)
+    head = _build(d).to(DEV)
+    n_fft, dim = int(d["n_fft"]), d["Vp"].shape[1]
+    cache = PrefixFFTCache(n_fft, dim, device=torch.device(DEV))
+    cache.prefill(torch.from_numpy(d["Qp"]).to(DEV), torch.from_numpy(d["Vp"]).to(DEV))
+    ref = d["prefix_after_prefill"]
+    assert_close(torch.view_as_real(cache.prefix_fft).cpu().numpy(), ref.view(np.float32).reshape(*ref.shape, 2), what="prefill")
+    if "mem" in d:
+        cache.prefix_fft += torch.from_numpy(d["mem"]).to(DEV)      # usage documented at spectre.py:736-741
+    q, v = torch.from_numpy(d["q_seq"]).to(DEV), torch.from_numpy(d["v_seq"]).to(DEV)
+    outs = torch.stack([head.decode_step(q[i], v[i], cache) for i in range(q.shape[0])])
+    torch.cuda.synchronize()
+    for i in range(q.shape[0]):                               # every step on its own scale
+        assert_close(outs[i].cpu().numpy(), d["outs"][i], what=f"step {i}")
+    pf = d["prefix_final"]
+    assert_close(torch.view_as_real(cache.prefix_fft).cpu().numpy(), pf.view(np.float32).reshape(*pf.shape, 2), what="final spectrum")
+    assert_close(cache.sum_q.cpu().numpy(), d["sum_q_final"], what="sum_q")
+    assert cache.t == int(d["t_final"])
+
+
+@pytest.mark.parametrize("shape", [(4096, 768, 4), (3000, 96, 2), (1024, 64, 4), (97, 10, 2)], ids=lambda s: "n%d_d%d_G%d" % s)
+def test_decode_matches_oracle_at_size(shape):
+    from fft_amd import PrefixFFTCache, SpectreHead
+    n_fft, dim, G = shape
+    torch.manual_seed(n_fft)
+    head = SpectreHead(dim, n_fft, num_groups=G, pooling_type="mean").eval()
+    L, T = n_fft - 3, 8                                      # wraps after three steps
+    Qp, Vp = torch.randn(L, dim), torch.randn(L, dim)
+    q, v = torch.randn(T, dim), torch.randn(T, dim)
+    oc = PrefixFFTCacheOracle(n_fft, dim)
+    oc.prefill(Qp, Vp)
+    want = torch.stack([decode_step_oracle(head, q[i], v[i], oc) for i in range(T)])
+    head = head.to(DEV)
+    cache = PrefixFFTCache(n_fft, dim, device=torch.device(DEV))
+    cache.prefill(Qp.to(DEV), Vp.to(DEV))
+    got = torch.stack([head.decode_step(q[i].to(DEV), v[i].to(DEV), cache) for i in range(T)])
+    torch.cuda.synchronize()
+    for i in range(T):
+        assert_close(got[i].cpu().numpy(), want[i].numpy(), rtol=1e-4, atol_rms=2e-4, what=f"step {i}")
+    assert_close(torch.view_as_real(cache.prefix_fft).cpu().numpy(), torch.view_as_real(oc.prefix_fft).numpy(), what="spectrum")
+
+
+def test_state_only_decode_step_and_prefill_shapes():
+    from fft_amd import PrefixFFTCache, rfft_prefill
+    torch.manual_seed(3)
+    V = torch.randn(3, 200, 24, device=DEV)
+    for n in (256, 200, 128, 210):
+        spec = rfft_prefill(V, n)
+        ref = torch.fft.rfft(V.cpu().double(), n=n, dim=1)
+        assert_close(torch.view_as_real(spec).cpu().numpy(), torch.view_as_real(ref).numpy(), what=f"rfft n={n}")
+    spec = rfft_prefill(V[0, :, :7].bfloat16(), 256)         # (N, D) input, odd D, bf16 storage
+    ref = torch.fft.rfft(V[0, :, :7].bfloat16().double().cpu(), n=256, dim=0)
+    assert_close(torch.view_as_real(spec).cpu().numpy(), torch.view_as_real(ref).numpy(), what="rfft 2-D bf16")
+    c = PrefixFFTCache(64, 8, device=torch.device(DEV))
+    oc = PrefixFFTCacheOracle(64, 8)
+    Q, Vp = torch.randn(64, 8), torch.randn(64, 8)
+    c.prefill(Q.to(DEV), Vp.to(DEV))
+    oc.prefill(Q, Vp)
+    for i in range(5):
+        qt, vt = torch.randn(8), torch.randn(8)
+        pf, sq = c.decode_step(qt.to(DEV), vt.to(DEV))
+        opf, osq = oc.decode_step(qt, vt)
+    assert pf is c.prefix_fft
+    assert_close(torch.view_as_real(pf).cpu().numpy(), torch.view_as_real(opf).numpy(), what="state-only spectrum")
+    assert_close(sq.cpu().numpy(), osq.numpy(), what="sum_q")
+    assert torch.equal(c.V_buf.cpu(), oc.V_buf) and torch.equal(c.Q_buf.cpu(), oc.Q_buf)

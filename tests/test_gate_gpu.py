@@ -75,7 +75,7 @@ def test_module_uses_the_fused_gate_in_inference_and_torch_ops_under_autograd():
         _, g_fused, _ = head.spectral_gate(x, pp)
     _, g_ops, _ = head.spectral_gate(x, pp)               # grad enabled: the ops autograd can differentiate
     assert g_ops.requires_grad and not g_fused.requires_grad
-    assert float((g_fused - g_ops.detach()).abs().max()) <= 4e-5 * float(g_ops.abs().max())
+    assert float((g_fused - g_ops.detach()).abs().max()) <= 4e-5 * float(g_ops.detach().abs().max())
 
 
 def test_bad_arguments_fail_loudly():
