@@ -225,3 +225,58 @@ class SpectreHead(nn.Module):
         `fft_amd.PrefixFFTCache`; returns the mixed vector (d,) of the current time step."""
         from .decode import head_decode_step
         return head_decode_step(self, q_t, v_t, cache)
+
+
+# --------------------------------------------------------------------------------------------------
+# multi-head wrapper (SURVEY.md section 8(f), row N3)
+# --------------------------------------------------------------------------------------------------
+class _WaveletRefinementParams(nn.Module):
+    """Holds the parameters of the reference's `WaveletRefinement` (spectre.py:819-832) so that its state_dict loads;
+    the refinement itself is out of scope (stochastic per batch element) and is only accepted
+    switched off."""
+
+    def __init__(self, embed_dim: int, on_rate: float):
+        super().__init__()
+        self.on_rate = on_rate
+        self.gate_mlp = nn.Sequential(nn.Linear(embed_dim, embed_dim), nn.SiLU(), nn.Linear(embed_dim, embed_dim), nn.Sigmoid())
+
+
+class SpectreMultiHead(nn.Module):
+    """Several SpectreHeads side by side plus the output projection — same surface as spectre.py:660-726.
+
+    The reference loops over heads and concatenates their outputs (`:712-719`); here every head's fused mix writes
+    straight into its channel slice of one (B, N, embed_dim) buffer (strided output views of the C ABI), so the
+    concatenation pass over the activations disappears.  `wavelet_on_rate` must be 0 (see `_WaveletRefinementParams`).
+    """
+
+    def __init__(self, embed_dim: int, num_heads: int, n_fft: int, d_gate: int = 256, use_toeplitz: bool = False,
+                 dropout_p: float = 0.0, pooling_type: str = "dct", num_groups: int = 4,
+                 num_buckets: Optional[int] = None, wavelet_on_rate: float = 0.1):
+        super().__init__()
+        assert embed_dim % num_heads == 0
+        if wavelet_on_rate != 0.0:
+            raise NotImplementedError("fft_amd.SpectreMultiHead: the stochastic WaveletRefinement (spectre.py:819-878) is not "
+                                      "implemented; construct with wavelet_on_rate=0.0")
+        self.num_heads = num_heads
+        self.head_dim = embed_dim // num_heads
+        self.heads = nn.ModuleList([
+            SpectreHead(self.head_dim, fft_size=n_fft, d_gate=d_gate, use_toeplitz=use_toeplitz, dropout_p=dropout_p,
+                        pooling_type=pooling_type, num_groups=num_groups, num_buckets=num_buckets)
+            for _ in range(num_heads)])
+        self.out_proj = nn.Linear(embed_dim, embed_dim, bias=False)
+        self.wavelet_refinement = _WaveletRefinementParams(embed_dim, wavelet_on_rate)
+
+    def forward(self, x: torch.Tensor, pos_phase: Optional[torch.Tensor] = None, memory_fft: Optional[torch.Tensor] = None):
+        chunks = torch.chunk(x, self.num_heads, dim=-1)
+        mems = torch.chunk(memory_fft, self.num_heads, dim=-1) if memory_fft is not None else [None] * self.num_heads
+        needs_graph = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if needs_graph or any(not isinstance(h.dropout, nn.Identity) for h in self.heads):
+            mixed = torch.cat([h(c, pos_phase, memory_fft=m) for h, c, m in zip(self.heads, chunks, mems)], dim=-1)
+            return self.out_proj(mixed)
+        n_out = min(x.shape[1], self.heads[0].n_fft)
+        mixed = torch.empty(x.shape[0], n_out, x.shape[2], dtype=x.dtype, device=x.device)
+        for i, (h, c, m) in enumerate(zip(self.heads, chunks, mems)):
+            V, gate, _ = h.spectral_gate(c, pos_phase)
+            spectral_mix(V, gate.to(torch.complex64), None if m is None else m.to(torch.complex64), h.n_fft,
+                         out=mixed[:, :, i * self.head_dim:(i + 1) * self.head_dim])
+        return self.out_proj(mixed)

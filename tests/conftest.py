@@ -17,8 +17,8 @@ def pytest_configure(config):
 
 
 def golden_files():
-    """Forward / backward fixtures of the spectral mix (the decode fixtures g10_* have their own tests)."""
-    return sorted(f for f in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")) if not os.path.basename(f).startswith("g10_decode"))
+    """Forward / backward fixtures of the spectral mix (the decode and multi-head fixtures g10_*, g11_* have their own tests)."""
+    return sorted(f for f in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")) if not os.path.basename(f).startswith(("g10_decode", "g11_multihead")))
 
 
 def golden_ids():

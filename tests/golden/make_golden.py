@@ -205,6 +205,30 @@ def case_decode(name, d, n_fft, G, seed, L, T, *, with_mem=False):
     print(f"{name:28s} decode L={L} T={T} d={d} n_fft={n_fft}  {os.path.getsize(path) / 1e3:.0f} kB")
 
 
+def case_multihead(name, B, N, E, H, n_fft, G, seed, *, with_mem=False, with_phase=False):
+    """SpectreMultiHead.forward (spectre.py:660-726) with the stochastic wavelet refinement switched off: row N3."""
+    torch.manual_seed(seed)
+    mh = ref.SpectreMultiHead(E, H, n_fft, pooling_type="mean", num_groups=G, wavelet_on_rate=0.0).eval()
+    g = torch.Generator().manual_seed(seed + 5000)
+    x = torch.randn(B, N, E, generator=g)
+    F = n_fft // 2 + 1
+    d_out = {"x": x.numpy(), "n_fft": np.int64(n_fft), "G": np.int64(G), "H": np.int64(H)}
+    mem = pp = None
+    if with_mem:
+        mem = torch.complex(torch.randn(F, E, generator=g), torch.randn(F, E, generator=g)) * 0.5
+        d_out["mem"] = mem.numpy()
+    if with_phase:
+        pp = torch.exp(1j * 2 * np.pi * torch.arange(F, dtype=torch.float32) * 2.0 / n_fft).to(torch.complex64)
+        d_out["pos_phase"] = pp.numpy()
+    with torch.no_grad():
+        d_out["out"] = mh(x, pos_phase=pp, memory_fft=mem).numpy()
+    for k, v in mh.state_dict().items():
+        d_out["sd/" + k] = v.numpy()
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **d_out)
+    print(f"{name:28s} multihead x{tuple(x.shape)} H={H}  {os.path.getsize(path) / 1e3:.0f} kB")
+
+
 def g_random(scale=0.3, zero_frac=0.18):
     def f(B, G, F, gen):
         z = torch.complex(torch.randn(B, G, F, generator=gen), torch.randn(B, G, F, generator=gen)) * scale
@@ -276,6 +300,9 @@ def main():
     case_decode("g10_decode_n60", 16, 60, 2, 32, L=10, T=70)
     case_decode("g10_decode_n15_odd", 8, 15, 2, 33, L=5, T=25)
     case_decode("g10_decode_n128_mem", 32, 128, 4, 34, L=100, T=40, with_mem=True)
+    # G11 — the multi-head wrapper (wavelet refinement off)
+    case_multihead("g11_multihead_h2", 2, 64, 32, 2, 64, 2, 40)
+    case_multihead("g11_multihead_h4_mem_phase", 2, 48, 64, 4, 64, 2, 41, with_mem=True, with_phase=True)
     # G8 — bf16 input values; oracle = reference on x_bf16.float(); bf16 rounding of the result stored
     case_fixed_gate("g8_bf16_n1024", 1, 1024, 16, 1024, 4, 22, g_random(), bf16=True)
     case_fixed_gate("g8_bf16_n4096", 1, 4096, 16, 4096, 4, 23, g_random(), bf16=True)
@@ -285,7 +312,7 @@ if __name__ == "__main__":
     # optional name prefixes: `python make_golden.py g10` regenerates only the matching cases
     if len(sys.argv) > 1:
         _only = tuple(sys.argv[1:])
-        for _fn in ("case_module", "case_fixed_gate", "case_backward", "case_decode"):
+        for _fn in ("case_module", "case_fixed_gate", "case_backward", "case_decode", "case_multihead"):
             def _wrap(f):
                 return lambda name, *a, **k: f(name, *a, **k) if name.startswith(_only) else None
             globals()[_fn] = _wrap(globals()[_fn])

@@ -1,0 +1,55 @@
+"""Row N3: the multi-head wrapper.  CPU: surface + reference state_dict; GPU: reference outputs (fixtures g11_*)."""
+import glob
+import inspect
+import os
+
+import pytest
+import torch
+
+from conftest import GOLDEN_DIR, load_golden
+from oracle.spectral_mix_oracle import assert_close
+
+MH = sorted(glob.glob(os.path.join(GOLDEN_DIR, "g11_multihead_*.npz")))
+
+
+def _build(d):
+    from fft_amd import SpectreMultiHead
+    sd = {k[3:]: torch.from_numpy(v) for k, v in d.items() if k.startswith("sd/")}
+    E = sd["out_proj.weight"].shape[0]
+    mh = SpectreMultiHead(E, int(d["H"]), int(d["n_fft"]), pooling_type="mean", num_groups=int(d["G"]), wavelet_on_rate=0.0).eval()
+    missing, unexpected = mh.load_state_dict(sd, strict=True)        # incl. the (unused) wavelet_refinement parameters
+    assert not missing and not unexpected
+    return mh
+
+
+def test_surface_and_reference_state_dict():
+    from fft_amd import SpectreMultiHead
+    names = list(inspect.signature(SpectreMultiHead.__init__).parameters)
+    assert names == ["self", "embed_dim", "num_heads", "n_fft", "d_gate", "use_toeplitz", "dropout_p", "pooling_type",
+                     "num_groups", "num_buckets", "wavelet_on_rate"]                    # spectre.py:664-676
+    assert list(inspect.signature(SpectreMultiHead.forward).parameters) == ["self", "x", "pos_phase", "memory_fft"]
+    with pytest.raises(NotImplementedError, match="wavelet_on_rate"):
+        SpectreMultiHead(32, 2, 64)                                                     # reference default 0.1: refused loudly
+    assert len(MH) >= 2
+    for p in MH:
+        mh = _build(load_golden(p))
+        assert mh.num_heads == len(mh.heads) and mh.head_dim * mh.num_heads == mh.out_proj.in_features
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", MH, ids=[os.path.basename(p)[:-4] for p in MH])
+def test_forward_matches_reference(path):
+    d = load_golden(path)
+    mh = _build(d).to("cuda:0")
+    x = torch.from_numpy(d["x"]).to("cuda:0")
+    pp = torch.from_numpy(d["pos_phase"]).to("cuda:0") if "pos_phase" in d else None
+    mem = torch.from_numpy(d["mem"]).to("cuda:0") if "mem" in d else None
+    with torch.no_grad():
+        y = mh(x, pos_phase=pp, memory_fft=mem)                     # slice-writing path
+    y_graph = mh(x, pos_phase=pp, memory_fft=mem)                   # autograd path (per-head modules + cat)
+    torch.cuda.synchronize()
+    assert tuple(y.shape) == d["out"].shape
+    assert_close(y.cpu().numpy(), d["out"], rtol=1e-4, atol_rms=2e-4, what="multi-head forward")
+    assert_close(y_graph.detach().cpu().numpy(), d["out"], rtol=1e-4, atol_rms=2e-4, what="multi-head forward (autograd path)")
+    y_graph.sum().backward()
+    assert all(p.grad is not None for n, p in mh.named_parameters() if not n.startswith("wavelet_refinement"))
