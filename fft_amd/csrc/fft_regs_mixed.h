@@ -1,7 +1,7 @@
 // fft_regs_mixed.h — compile-time mixed-radix FFTs on register arrays (one transform per lane), gfx950.
 //
 // Generalises fft_regs.h's two-factor "type A" transform to any length R = RA * RB * ... built from the primitive
-// butterflies 2, 3, 4, 5, 8 (e.g. 60 = 4 x (3 x 5), 50 = 2 x (5 x 5)).  Every register index is a compile-time
+// butterflies 2, 3, 4, 5, 7, 8 (e.g. 60 = 4 x (3 x 5), 50 = 2 x (5 x 5)).  Every register index is a compile-time
 // constant: the data never moves to undo a digit reversal; instead a transform takes a MAP (logical index ->
 // physical register) for its input and publishes out_pos<R>(k), the logical slot where output k is left:
 //
@@ -17,10 +17,11 @@
 namespace sfft {
 
 // ---- factorisation: R = RA * RB with RA primitive; RB == 1 marks a primitive length ---------------------------------
-template <int R> struct Split { static constexpr int RA = R, RB = 1; static_assert(R == 2 || R == 3 || R == 4 || R == 5 || R == 8, "primitive"); };
+template <int R> struct Split { static constexpr int RA = R, RB = 1; static_assert(R == 2 || R == 3 || R == 4 || R == 5 || R == 7 || R == 8, "primitive"); };
 template <> struct Split<6>  { static constexpr int RA = 2, RB = 3; };
 template <> struct Split<10> { static constexpr int RA = 2, RB = 5; };
 template <> struct Split<12> { static constexpr int RA = 4, RB = 3; };
+template <> struct Split<14> { static constexpr int RA = 2, RB = 7; };
 template <> struct Split<15> { static constexpr int RA = 3, RB = 5; };
 template <> struct Split<16> { static constexpr int RA = 4, RB = 4; };
 template <> struct Split<20> { static constexpr int RA = 4, RB = 5; };
@@ -76,6 +77,27 @@ __device__ __forceinline__ void bfly5(float2& v0, float2& v1, float2& v2, float2
   v3 = csub(m2, q2);
 }
 
+template <bool INV>
+__device__ __forceinline__ void bfly7(float2& v0, float2& v1, float2& v2, float2& v3, float2& v4, float2& v5, float2& v6) {
+  constexpr float c1 = 0.62348980185873353f, c2 = -0.22252093395631440f, c3 = -0.90096886790241913f;   // cos(2 pi j / 7)
+  constexpr float sg = INV ? -1.f : 1.f;
+  constexpr float s1 = sg * 0.78183148246802981f, s2 = sg * 0.97492791218182361f, s3 = sg * 0.43388373911755812f;
+  const float2 a1 = cadd(v1, v6), b1 = csub(v1, v6);
+  const float2 a2 = cadd(v2, v5), b2 = csub(v2, v5);
+  const float2 a3 = cadd(v3, v4), b3 = csub(v3, v4);
+  // X_k = m_k - i q_k, X_{7-k} = m_k + i q_k with m_k = x0 + sum_j a_j cos(2 pi jk/7), q_k = sum_j b_j sin(2 pi jk/7)
+  const float2 m1 = make_float2(v0.x + c1 * a1.x + c2 * a2.x + c3 * a3.x, v0.y + c1 * a1.y + c2 * a2.y + c3 * a3.y);
+  const float2 m2 = make_float2(v0.x + c2 * a1.x + c3 * a2.x + c1 * a3.x, v0.y + c2 * a1.y + c3 * a2.y + c1 * a3.y);
+  const float2 m3 = make_float2(v0.x + c3 * a1.x + c1 * a2.x + c2 * a3.x, v0.y + c3 * a1.y + c1 * a2.y + c2 * a3.y);
+  const float2 q1 = make_float2(s1 * b1.x + s2 * b2.x + s3 * b3.x, s1 * b1.y + s2 * b2.y + s3 * b3.y);
+  const float2 q2 = make_float2(s2 * b1.x - s3 * b2.x - s1 * b3.x, s2 * b1.y - s3 * b2.y - s1 * b3.y);
+  const float2 q3 = make_float2(s3 * b1.x - s1 * b2.x + s2 * b3.x, s3 * b1.y - s1 * b2.y + s2 * b3.y);
+  v0 = make_float2(v0.x + a1.x + a2.x + a3.x, v0.y + a1.y + a2.y + a3.y);
+  v1 = make_float2(m1.x + q1.y, m1.y - q1.x);   v6 = make_float2(m1.x - q1.y, m1.y + q1.x);
+  v2 = make_float2(m2.x + q2.y, m2.y - q2.x);   v5 = make_float2(m2.x - q2.y, m2.y + q2.x);
+  v3 = make_float2(m3.x + q3.y, m3.y - q3.x);   v4 = make_float2(m3.x - q3.y, m3.y + q3.x);
+}
+
 // a * W_R^M (forward) or a * conj(W_R^M) (INV), literal constants
 template <int R, int M, bool INV>
 __device__ __forceinline__ float2 twid_ct(float2 a) {
@@ -110,6 +132,7 @@ __device__ __forceinline__ void fft_ct(float2 (&z)[NTOT]) {
     else if constexpr (R == 3) bfly3<INV>(z[Map::at(0)], z[Map::at(1)], z[Map::at(2)]);
     else if constexpr (R == 4) bfly4<INV>(z[Map::at(0)], z[Map::at(1)], z[Map::at(2)], z[Map::at(3)]);
     else if constexpr (R == 5) bfly5<INV>(z[Map::at(0)], z[Map::at(1)], z[Map::at(2)], z[Map::at(3)], z[Map::at(4)]);
+    else if constexpr (R == 7) bfly7<INV>(z[Map::at(0)], z[Map::at(1)], z[Map::at(2)], z[Map::at(3)], z[Map::at(4)], z[Map::at(5)], z[Map::at(6)]);
     else bfly8<INV>(z[Map::at(0)], z[Map::at(1)], z[Map::at(2)], z[Map::at(3)], z[Map::at(4)], z[Map::at(5)], z[Map::at(6)], z[Map::at(7)]);
   } else {
     // input q = RB*q1 + q0.  Stage 1: radix RA over q1 for every q0 (bin ka replaces q1 = ka), times W_R^(q0 ka)

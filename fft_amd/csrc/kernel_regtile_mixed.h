@@ -32,7 +32,6 @@ __global__ void __launch_bounds__(kPC * (RF > RS ? RF : RS)) spectre_mix_regtile
   constexpr int N = RF * RS, NZ = mixed_team<RF, RS>(), NT = mixed_threads<RF, RS>();
   static_assert(N % 2 == 0, "even n_fft");
   constexpr int RAF = Split<RF>::RA, RBF = Split<RF>::RB;
-  static_assert(RBF > 1, "RF must be composite");
   constexpr int ROW1 = mixed_row(RS), ROW2 = mixed_row(RF);
   constexpr int ES_IN = IN_BF16 ? 2 : 4, ES_OUT = OUT_BF16 ? 2 : 4;
   constexpr float inv_n = 1.0f / (float)N;

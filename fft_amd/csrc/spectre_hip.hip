@@ -39,6 +39,26 @@ template <> hipError_t launch_regtile_mixed<50, 40>(const RegtileArgs&, bool, bo
 template <> hipError_t launch_regtile_mixed<40, 32>(const RegtileArgs&, bool, bool, int, hipStream_t);
 template <> hipError_t launch_regtile_mixed<64, 40>(const RegtileArgs&, bool, bool, int, hipStream_t);
 template <> hipError_t launch_regtile_mixed<64, 60>(const RegtileArgs&, bool, bool, int, hipStream_t);
+template <> hipError_t launch_regtile_mixed<8, 8>(const RegtileArgs&, bool, bool, int, hipStream_t);
+template <> hipError_t launch_regtile_mixed<16, 8>(const RegtileArgs&, bool, bool, int, hipStream_t);
+template <> hipError_t launch_regtile_mixed<14, 14>(const RegtileArgs&, bool, bool, int, hipStream_t);
+template <> hipError_t launch_regtile_mixed<24, 16>(const RegtileArgs&, bool, bool, int, hipStream_t);
+template <> hipError_t launch_regtile_mixed<32, 20>(const RegtileArgs&, bool, bool, int, hipStream_t);
+template <> hipError_t launch_regtile_mixed<32, 30>(const RegtileArgs&, bool, bool, int, hipStream_t);
+template <> hipError_t launch_regtile_mixed<40, 30>(const RegtileArgs&, bool, bool, int, hipStream_t);
+template <> hipError_t launch_regtile_mixed<48, 40>(const RegtileArgs&, bool, bool, int, hipStream_t);
+template <> hipError_t launch_regtile_mixed<60, 40>(const RegtileArgs&, bool, bool, int, hipStream_t);
+template <> hipError_t launch_regtile_mixed<60, 60>(const RegtileArgs&, bool, bool, int, hipStream_t);
+template <> hipError_t launch_gate_grad_mixed<8, 8>(const GateGradArgs&, bool, bool, hipStream_t);
+template <> hipError_t launch_gate_grad_mixed<16, 8>(const GateGradArgs&, bool, bool, hipStream_t);
+template <> hipError_t launch_gate_grad_mixed<14, 14>(const GateGradArgs&, bool, bool, hipStream_t);
+template <> hipError_t launch_gate_grad_mixed<24, 16>(const GateGradArgs&, bool, bool, hipStream_t);
+template <> hipError_t launch_gate_grad_mixed<32, 20>(const GateGradArgs&, bool, bool, hipStream_t);
+template <> hipError_t launch_gate_grad_mixed<32, 30>(const GateGradArgs&, bool, bool, hipStream_t);
+template <> hipError_t launch_gate_grad_mixed<40, 30>(const GateGradArgs&, bool, bool, hipStream_t);
+template <> hipError_t launch_gate_grad_mixed<48, 40>(const GateGradArgs&, bool, bool, hipStream_t);
+template <> hipError_t launch_gate_grad_mixed<60, 40>(const GateGradArgs&, bool, bool, hipStream_t);
+template <> hipError_t launch_gate_grad_mixed<60, 60>(const GateGradArgs&, bool, bool, hipStream_t);
 template <> hipError_t launch_gate_grad_regtile<16, 16>(const GateGradArgs&, bool, bool, hipStream_t);
 template <> hipError_t launch_gate_grad_regtile<32, 16>(const GateGradArgs&, bool, bool, hipStream_t);
 template <> hipError_t launch_gate_grad_regtile<32, 32>(const GateGradArgs&, bool, bool, hipStream_t);
@@ -81,6 +101,16 @@ const TileSize kTileSizes[] = {
     {1280, 40, 32, true, true, &sfft::launch_regtile_mixed<40, 32>, &sfft::launch_gate_grad_mixed<40, 32>},
     {2560, 64, 40, true, true, &sfft::launch_regtile_mixed<64, 40>, &sfft::launch_gate_grad_mixed<64, 40>},
     {3840, 64, 60, true, true, &sfft::launch_regtile_mixed<64, 60>, &sfft::launch_gate_grad_mixed<64, 60>},
+    {64, 8, 8, true, true, &sfft::launch_regtile_mixed<8, 8>, &sfft::launch_gate_grad_mixed<8, 8>},
+    {128, 16, 8, true, true, &sfft::launch_regtile_mixed<16, 8>, &sfft::launch_gate_grad_mixed<16, 8>},
+    {196, 14, 14, true, true, &sfft::launch_regtile_mixed<14, 14>, &sfft::launch_gate_grad_mixed<14, 14>},
+    {384, 24, 16, true, true, &sfft::launch_regtile_mixed<24, 16>, &sfft::launch_gate_grad_mixed<24, 16>},
+    {640, 32, 20, true, true, &sfft::launch_regtile_mixed<32, 20>, &sfft::launch_gate_grad_mixed<32, 20>},
+    {960, 32, 30, true, true, &sfft::launch_regtile_mixed<32, 30>, &sfft::launch_gate_grad_mixed<32, 30>},
+    {1200, 40, 30, true, true, &sfft::launch_regtile_mixed<40, 30>, &sfft::launch_gate_grad_mixed<40, 30>},
+    {1920, 48, 40, true, true, &sfft::launch_regtile_mixed<48, 40>, &sfft::launch_gate_grad_mixed<48, 40>},
+    {2400, 60, 40, true, true, &sfft::launch_regtile_mixed<60, 40>, &sfft::launch_gate_grad_mixed<60, 40>},
+    {3600, 60, 60, true, true, &sfft::launch_regtile_mixed<60, 60>, &sfft::launch_gate_grad_mixed<60, 60>},
 };
 const TileSize* find_tile_size(int64_t n) {
   for (const TileSize& t : kTileSizes)

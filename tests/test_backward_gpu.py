@@ -38,7 +38,9 @@ SHAPES = [(2, 4096, 64, 4, 4096), (2, 2048, 32, 2, 2048), (3, 1024, 48, 3, 1024)
           (2, 256, 12, 2, 256), (2, 512, 15, 3, 512), (3, 1024, 40, 2, 1024), (1, 2048, 200, 1, 2048), (2, 100, 24, 1, 256),
           # mixed-radix register-tile gate gradient (RS even); 1000 = 40 x 25 stays on the Stockham path
           (2, 3000, 64, 4, 3000), (2, 2500, 24, 2, 3000), (2, 768, 32, 2, 768), (2, 1536, 40, 2, 1536), (1, 3072, 32, 2, 3072),
-          (2, 2000, 32, 4, 2000), (2, 1280, 32, 2, 1280), (1, 2560, 48, 2, 2560), (1, 3840, 32, 2, 3840), (2, 1000, 32, 2, 1000)]
+          (2, 2000, 32, 4, 2000), (2, 1280, 32, 2, 1280), (1, 2560, 48, 2, 2560), (1, 3840, 32, 2, 3840), (2, 1000, 32, 2, 1000),
+          (3, 64, 32, 2, 64), (2, 128, 24, 2, 128), (2, 196, 32, 2, 196), (2, 384, 32, 2, 384), (2, 640, 32, 2, 640), (2, 960, 20, 2, 960),
+          (2, 1200, 32, 2, 1200), (1, 1920, 32, 2, 1920), (1, 2400, 32, 2, 2400), (1, 3600, 32, 2, 3600), (2, 150, 32, 2, 196)]
 
 
 @pytest.mark.parametrize("shape", SHAPES, ids=[f"B{s[0]}_N{s[1]}_D{s[2]}_G{s[3]}_fft{s[4]}" for s in SHAPES])

@@ -60,7 +60,8 @@ def test_native_library_is_the_thing_that_runs():
         Vn, gn, _ = _problem(0, 1, n, 16, 1, n)
         assert _describe(Vn.to(DEV), gn.to(DEV)).startswith("regtile " + tag)
     for n, tag in ((3000, "60x50"), (768, "32x24"), (1536, "48x32"), (3072, "64x48"), (1000, "40x25"), (2000, "50x40"),
-                   (1280, "40x32"), (2560, "64x40"), (3840, "64x60")):
+                   (1280, "40x32"), (2560, "64x40"), (3840, "64x60"), (64, "8x8"), (128, "16x8"), (196, "14x14"), (384, "24x16"),
+                   (640, "32x20"), (960, "32x30"), (1200, "40x30"), (1920, "48x40"), (2400, "60x40"), (3600, "60x60")):
         Vn, gn, _ = _problem(0, 1, n, 16, 1, n)
         assert _describe(Vn.to(DEV), gn.to(DEV)).startswith("regtile-mixed " + tag)
     Vn, gn, _ = _problem(0, 1, 768, 16, 1, 768)      # secondary lengths are built for equal storage dtypes only
@@ -87,7 +88,10 @@ SHAPES = [  # (B, N, D, G, n_fft)
     (2, 1280, 32, 2, 1280), (2, 2560, 32, 2, 2560), (2, 3840, 32, 2, 3840),         # the other mixed-radix register-tile lengths
     (2, 700, 32, 2, 768), (2, 1111, 48, 2, 1536), (2, 4000, 32, 2, 3072), (2, 999, 16, 2, 1000), (1, 1999, 48, 2, 2000),
     (2, 1279, 32, 4, 1280), (2, 2000, 48, 2, 2560), (2, 3000, 32, 2, 3840),         # ... with row predicates / narrow groups
-    (2, 640, 32, 4, 640), (2, 1200, 32, 2, 1200),                                   # Stockham, smooth
+    (3, 64, 32, 2, 64), (3, 128, 32, 2, 128), (3, 196, 32, 2, 196), (2, 384, 32, 2, 384), (2, 640, 32, 4, 640), (2, 960, 32, 2, 960),
+    (2, 1200, 32, 2, 1200), (2, 1920, 32, 2, 1920), (2, 2400, 32, 2, 2400), (1, 3600, 32, 2, 3600),   # ... incl. radix 7 (196 = 14 x 14)
+    (3, 50, 48, 2, 64), (3, 150, 24, 2, 196), (2, 500, 32, 2, 384), (2, 2000, 48, 2, 2400), (1, 4000, 32, 2, 3600),
+    (2, 1500, 32, 4, 1500), (2, 2304, 32, 2, 2304),                                 # Stockham, smooth
     (2, 1000, 32, 2, 1024), (2, 5000, 32, 2, 4096), (1, 100, 16, 2, 128),          # pad / truncate
     (2, 97, 12, 2, 97), (2, 331, 8, 2, 331), (1, 2039, 8, 1, 2039),                # primes: Bluestein
     (2, 60, 6, 2, 60), (2, 64, 10, 2, 64), (2, 256, 24, 8, 256),                   # odd d_g (solo), D%16 != 0
