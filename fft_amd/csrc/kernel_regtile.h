@@ -181,6 +181,8 @@ __global__ void __launch_bounds__(kPC * RS) spectre_mix_regtile(const RegtileArg
   const int b = tile / a.tiles_per_row;
   const int ct = tile - b * a.tiles_per_row;
   const int c = ct * (2 * kPC) + 2 * p;          // first channel of this lane's pair
+  bool cvalid = true;                            // the last tile of a row is ragged when D % 16 != 0 (general modes only)
+  if constexpr (GENERAL) cvalid = c < a.D;
 
   // per-thread twiddle bases W_N^(u*ka), W_N^(u*RAF*kb): products give W_N^(u*k1) for any k1 < RF.  They are
   // (re)loaded from the L1/L2-resident table where they are used, twice per tile: holding 2*(RAF+RBF-2) registers
@@ -217,8 +219,8 @@ __global__ void __launch_bounds__(kPC * RS) spectre_mix_regtile(const RegtileArg
       const char* ptr = vb + (size_t)q * RS * v_sn * ES_IN + voff;
       bool ok = true;
       if constexpr (GENERAL) {                     // rows >= N_in read as zero (rfft's zero padding), branch-free:
-        ok = (u + RS * q) < a.N_in;                // load a row that exists, then select
-        ptr = ok ? ptr : vb + voff - (size_t)u * v_sn * ES_IN;
+        ok = cvalid && (u + RS * q) < a.N_in;      // load an address that exists, then select
+        ptr = ok ? ptr : vb;
       }
       if constexpr (NO_IO) {
         z[q] = make_float2(1.0f + q + u, 0.5f * p - q);
@@ -272,7 +274,8 @@ __global__ void __launch_bounds__(kPC * RS) spectre_mix_regtile(const RegtileArg
   //      then I1 stage 2.  Bin of register (ka, kb) of set t: k = k1 + RF*k2, k2 = ka + RAS*kb.  k2 >= RS/2 means
   //      k > N/2 (or k == N/2 when k1 == 0): the Hermitian extension reads conj(g[N - k]).
   if constexpr (!NO_MATH) {
-    const int grp = c / a.d_g;
+    const int cg = cvalid ? c : 0;               // lanes beyond D compute on zeros; keep their addresses in range
+    const int grp = cg / a.d_g;
     const float2* gp = a.gate + ((size_t)b * a.G + grp) * a.F;
     static_for<0, NS>([&](auto tc) {
       constexpr int t = decltype(tc)::value;
@@ -317,7 +320,7 @@ __global__ void __launch_bounds__(kPC * RS) spectre_mix_regtile(const RegtileArg
           z[j] = cmul(z[j], gcur[kb]);
           if constexpr (WITH_MEM) {                  // spectre.py:548-549
             const int idx = gate_index(k2);
-            const float4 m = *reinterpret_cast<const float4*>(a.mem + ((size_t)idx * a.D + c) * 2);
+            const float4 m = *reinterpret_cast<const float4*>(a.mem + ((size_t)idx * a.D + cg) * 2);
             float2 add;
             if (edge && k1 == 0) add = make_float2(m.x, m.z);
             else if (upper)      add = make_float2(m.x + m.w, m.z - m.y);
@@ -380,7 +383,7 @@ __global__ void __launch_bounds__(kPC * RS) spectre_mix_regtile(const RegtileArg
       constexpr int n1 = (j / RBF) + RAF * (j % RBF);
       char* ptr = ob + (size_t)n1 * RS * out_sn * ES_OUT + ooff;
       bool ok = true;
-      if constexpr (GENERAL) ok = (u + RS * n1) < a.N_in;
+      if constexpr (GENERAL) ok = cvalid && (u + RS * n1) < a.N_in;
       if constexpr (NO_IO) ok = (z[j].x == 1.2345e-30f);   // keeps the math alive, never true
       if (ok) {
         if constexpr (OUT_BF16) {

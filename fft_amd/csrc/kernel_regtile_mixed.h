@@ -49,6 +49,8 @@ __global__ void __launch_bounds__(kPC * (RF > RS ? RF : RS)) spectre_mix_regtile
   const int b = tile / a.tiles_per_row;
   const int ct = tile - b * a.tiles_per_row;
   const int c = ct * (2 * kPC) + 2 * p;
+  bool cvalid = true;                      // ragged last tile when D % 16 != 0 (general modes only)
+  if constexpr (GENERAL) cvalid = c < a.D;
 
   auto load_twiddle_bases = [&](float2 (&wa)[RAF], float2 (&wb)[RBF]) {   // W_N^(u ka), W_N^(u RAF kb)
     static_for<1, RAF>([&](auto jc) { constexpr int j = decltype(jc)::value; wa[j] = a.tw[u * j]; });
@@ -76,8 +78,8 @@ __global__ void __launch_bounds__(kPC * (RF > RS ? RF : RS)) spectre_mix_regtile
       const char* ptr = vb + (size_t)q * RS * a.v_sn * ES_IN + voff;
       bool ok = true;
       if constexpr (GENERAL) {
-        ok = (u + RS * q) < a.N_in;
-        ptr = ok ? ptr : vb + voff - (size_t)u * a.v_sn * ES_IN;
+        ok = cvalid && (u + RS * q) < a.N_in;
+        ptr = ok ? ptr : vb;
       }
       float2 val;
       if constexpr (IN_BF16) {
@@ -114,7 +116,8 @@ __global__ void __launch_bounds__(kPC * (RF > RS ? RF : RS)) spectre_mix_regtile
   using BinMap = OutPosMap<RS>;            // bin k2 lives at z[out_pos<RS>(k2)]
   if (bins) {
     fft_ct<RS, false, IdentityMap, NZ>(z);
-    const int grp = c / a.d_g;
+    const int cg = cvalid ? c : 0;
+    const int grp = cg / a.d_g;
     const float2* gp = a.gate + ((size_t)b * a.G + grp) * a.F;
     static_for<0, RS>([&](auto kc) {
       constexpr int k2 = decltype(kc)::value, pos = BinMap::at(k2);
@@ -133,7 +136,7 @@ __global__ void __launch_bounds__(kPC * (RF > RS ? RF : RS)) spectre_mix_regtile
       if (upper) g.y = -g.y;
       z[pos] = cmul(z[pos], g);
       if constexpr (WITH_MEM) {                           // spectre.py:548-549
-        const float4 m = *reinterpret_cast<const float4*>(a.mem + ((size_t)idx * a.D + c) * 2);
+        const float4 m = *reinterpret_cast<const float4*>(a.mem + ((size_t)idx * a.D + cg) * 2);
         float2 add;
         if (k == 0 || 2 * k == N) add = make_float2(m.x, m.z);
         else if (upper)           add = make_float2(m.x + m.w, m.z - m.y);
@@ -169,7 +172,7 @@ __global__ void __launch_bounds__(kPC * (RF > RS ? RF : RS)) spectre_mix_regtile
       constexpr int n1 = decltype(nc)::value, pos = out_pos<RF>(n1);
       char* ptr = ob + (size_t)n1 * RS * a.out_sn * ES_OUT + ooff;
       bool ok = true;
-      if constexpr (GENERAL) ok = (u + RS * n1) < a.N_in;
+      if constexpr (GENERAL) ok = cvalid && (u + RS * n1) < a.N_in;
       if (ok) {
         if constexpr (OUT_BF16) {
           *reinterpret_cast<uint32_t*>(ptr) = f32_to_bf16_rne(z[pos].x) | (f32_to_bf16_rne(z[pos].y) << 16);

@@ -293,14 +293,13 @@ int choose(const SpectreMixArgs* a, const Plan* plan, Choice* c) {
   const char* why = "";
   if (!ts) why = "no register-tile kernel for this n_fft";
   else if (ts->same_dtype && a->in_dtype != a->out_dtype) why = "storage dtypes differ (not built for this n_fft)";
-  else if (D % 16) why = "D % 16 != 0";
   else if (d_g % 2) why = "odd group width";
   else if ((reinterpret_cast<uintptr_t>(a->v) % (2 * es_in)) || (a->v_sn % 2) || (a->v_sb % 2)) why = "v not pair-aligned";
   else if ((reinterpret_cast<uintptr_t>(a->out) % (2 * es_out)) || (a->out_sn % 2) || (a->out_sb % 2)) why = "out not pair-aligned";
   else if (a->mem && (reinterpret_cast<uintptr_t>(a->mem) % 16)) why = "mem not 16-byte aligned";
   else if (reinterpret_cast<uintptr_t>(a->gate) % 8) why = "gate not 8-byte aligned";
   else if (a->v_sn * 63 * 4 + 64 >= ((int64_t)1 << 31) || a->out_sn * 63 * 4 + 64 >= ((int64_t)1 << 31)) why = "row stride too large";
-  else if (a->B * (D / 16) >= ((int64_t)1 << 31)) why = "too many tiles";
+  else if (a->B * ((D + 15) / 16) >= ((int64_t)1 << 31)) why = "too many tiles";
   c->why_not_regtile = why;
   const bool can_regtile = why[0] == 0;
   if (a->algo == SPECTRE_ALGO_REGTILE && !can_regtile)
@@ -366,7 +365,7 @@ int launch(const SpectreMixArgs* a, const Plan* plan, const Choice& c, bool conj
     k.out = a->out; k.tw = plan->tw_n;
     k.B = (int)a->B; k.N_in = (int)std::min<int64_t>(a->N_in, (int64_t)1 << 30); k.D = (int)a->D; k.G = (int)a->G_tot;
     k.d_g = (int)(a->D / a->G_tot); k.F = (int)(a->n_fft / 2 + 1);
-    k.tiles_per_row = (int)(a->D / 16); k.n_tiles = (int)(a->B * (a->D / 16));
+    k.tiles_per_row = (int)((a->D + 15) / 16); k.n_tiles = (int)(a->B * ((a->D + 15) / 16));
     k.v_sb = a->v_sb; k.v_sn = a->v_sn; k.out_sb = a->out_sb; k.out_sn = a->out_sn;
     k.conj_gate = conj_gate ? 1 : 0;
     k.tpw = tiles_per_workgroup(k.n_tiles);
@@ -465,7 +464,7 @@ int spectre_mix_describe(const SpectreMixArgs* a, char* buf, size_t cap) {
   const char* out = a->out_dtype == SPECTRE_BF16 ? "bf16" : "f32";
   if (c.regtile) {
     snprintf(buf, cap, "regtile%s %dx%d in=%s out=%s mode=%d tiles=%lld", c.tile->mixed ? "-mixed" : "", c.RF, c.RS, in, out, c.mode,
-             (long long)(a->B * (a->D / 16)));
+             (long long)(a->B * ((a->D + 15) / 16)));
   } else {
     std::string r;
     const std::vector<int>& rad = plan->bluestein ? plan->radix_m : plan->radix_n;

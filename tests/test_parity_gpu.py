@@ -64,6 +64,8 @@ def test_native_library_is_the_thing_that_runs():
                    (640, "32x20"), (960, "32x30"), (1200, "40x30"), (1920, "48x40"), (2400, "60x40"), (3600, "60x60")):
         Vn, gn, _ = _problem(0, 1, n, 16, 1, n)
         assert _describe(Vn.to(DEV), gn.to(DEV)).startswith("regtile-mixed " + tag)
+    Vn, gn, _ = _problem(0, 1, 4096, 24, 2, 4096)    # D % 16 != 0: ragged last tile, general mode of the same kernel
+    assert _describe(Vn.to(DEV), gn.to(DEV)).startswith("regtile 64x64 in=f32 out=f32 mode=1 tiles=2")
     Vn, gn, _ = _problem(0, 1, 768, 16, 1, 768)      # secondary lengths are built for equal storage dtypes only
     assert _describe(Vn.to(DEV).bfloat16(), gn.to(DEV), out_dtype=torch.float32).startswith("stockham")
 
@@ -94,7 +96,8 @@ SHAPES = [  # (B, N, D, G, n_fft)
     (2, 1500, 32, 4, 1500), (2, 2304, 32, 2, 2304),                                 # Stockham, smooth
     (2, 1000, 32, 2, 1024), (2, 5000, 32, 2, 4096), (1, 100, 16, 2, 128),          # pad / truncate
     (2, 97, 12, 2, 97), (2, 331, 8, 2, 331), (1, 2039, 8, 1, 2039),                # primes: Bluestein
-    (2, 60, 6, 2, 60), (2, 64, 10, 2, 64), (2, 256, 24, 8, 256),                   # odd d_g (solo), D%16 != 0
+    (2, 60, 6, 2, 60), (2, 64, 10, 2, 64), (2, 256, 24, 8, 256),                   # odd d_g (solo): Stockham
+    (2, 4096, 24, 2, 4096), (2, 3000, 40, 2, 3000), (3, 1024, 8, 2, 1024), (2, 256, 100, 2, 256), (2, 200, 36, 6, 196),   # ragged last tile (D % 16 != 0)
     (1, 8192, 8, 2, 8192), (1, 6000, 8, 2, 6000), (1, 16384, 4, 1, 16384), (1, 10000, 4, 2, 10000), (1, 5003, 4, 1, 5003), (2, 1, 4, 2, 1), (2, 2, 4, 2, 2), (2, 3, 4, 1, 3),
 ]
 
