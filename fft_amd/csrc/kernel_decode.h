@@ -76,7 +76,7 @@ struct DecodeArgs {
   int chunk;             // bins per workgroup
 };
 
-constexpr int kDecodeChunk = 32;
+constexpr int kDecodeChunk = 64;
 
 #pragma clang fp contract(off)
 __global__ void __launch_bounds__(256) spectre_decode_step(const DecodeArgs a) {
