@@ -54,6 +54,8 @@ enum {
  *   mem   (F, D)            complex64 contiguous, or NULL (spectre.py:548-549)
  *   out   (B, N_out, D)     f32|bf16  N_out = min(N_in, n_fft) (spectre.py:553), strides out_sb, out_sn
  * G_tot gate channels cover D (= G for one head, = H*G for a fused multi-head call); D % G_tot == 0.
+ * `out` may alias `v` (same pointer and strides, N_in <= n_fft): every workgroup reads its whole channel tile before it
+ * writes, and tiles are disjoint.
  */
 typedef struct SpectreMixArgs {
   const void* v;

@@ -242,3 +242,15 @@ def test_full_size_properties(B, N, D, G, dt):
         gsel = gate[idx_b][:, c // d_g:c // d_g + 1].cpu()
         ref = spectral_mix_numpy(Vs[:, :, j:j + 1].numpy(), gsel.numpy(), None, N)
         assert_close(y1[idx_b][:, :, c:c + 1].cpu().numpy(), ref, what=f"column {c}")
+
+
+@pytest.mark.parametrize("n_fft", [4096, 3000, 1024, 300, 97])
+def test_in_place_is_allowed(n_fft):
+    """A workgroup reads every row of its channel tile before it writes any, and tiles are disjoint: out may alias V."""
+    from fft_amd import spectral_mix
+    V, gate, _ = _problem(21, 2, n_fft, 32, 2, n_fft)
+    Vd = V.to(DEV)
+    want = _mix(Vd, gate.to(DEV), None, n_fft)
+    spectral_mix(Vd, gate.to(DEV), None, n_fft, out=Vd)
+    torch.cuda.synchronize()
+    assert torch.equal(Vd, want)
