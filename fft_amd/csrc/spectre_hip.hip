@@ -30,6 +30,7 @@ template <> hipError_t launch_regtile<32, 16>(const RegtileArgs&, bool, bool, in
 template <> hipError_t launch_regtile<32, 32>(const RegtileArgs&, bool, bool, int, hipStream_t);
 template <> hipError_t launch_regtile<64, 32>(const RegtileArgs&, bool, bool, int, hipStream_t);
 template <> hipError_t launch_regtile<64, 64>(const RegtileArgs&, bool, bool, int, hipStream_t);
+hipError_t launch_regtile_long_8192(const RegtileArgs&, bool, bool, int, hipStream_t);   // regtile_n8192.hip
 template <> hipError_t launch_regtile_mixed<60, 50>(const RegtileArgs&, bool, bool, int, hipStream_t);
 template <> hipError_t launch_regtile_mixed<32, 24>(const RegtileArgs&, bool, bool, int, hipStream_t);
 template <> hipError_t launch_regtile_mixed<48, 32>(const RegtileArgs&, bool, bool, int, hipStream_t);
@@ -81,10 +82,11 @@ using TileLauncher = hipError_t (*)(const sfft::RegtileArgs&, bool, bool, int, h
 using GradLauncher = hipError_t (*)(const sfft::GateGradArgs&, bool, bool, hipStream_t);
 struct TileSize {
   int n, RF, RS;
-  bool mixed;        // kernel_regtile_mixed.h (arbitrary 2/3/5-smooth factors) instead of kernel_regtile.h
+  bool mixed;        // one tile per workgroup, plain tile order (kernel_regtile_mixed.h, kernel_regtile_long.h)
   bool same_dtype;   // built for f32->f32 and bf16->bf16 only
   TileLauncher launch;
-  GradLauncher grad;   // register-resident gate gradient, or nullptr (LDS Stockham path)
+  GradLauncher grad;
+  int tile_ch = 16;  // channels per tile (8 for the long kernel)   // register-resident gate gradient, or nullptr (LDS Stockham path)
 };
 const TileSize kTileSizes[] = {
     {256, 16, 16, false, false, &sfft::launch_regtile<16, 16>, &sfft::launch_gate_grad_regtile<16, 16>},
@@ -92,6 +94,7 @@ const TileSize kTileSizes[] = {
     {1024, 32, 32, false, false, &sfft::launch_regtile<32, 32>, &sfft::launch_gate_grad_regtile<32, 32>},
     {2048, 64, 32, false, false, &sfft::launch_regtile<64, 32>, &sfft::launch_gate_grad_regtile<64, 32>},
     {4096, 64, 64, false, false, &sfft::launch_regtile<64, 64>, &sfft::launch_gate_grad_regtile<64, 64>},
+    {8192, 64, 128, true, false, &sfft::launch_regtile_long_8192, nullptr, 8},   // 8-channel tiles, lane-pair 128-point transform
     {3000, 60, 50, true, false, &sfft::launch_regtile_mixed<60, 50>, &sfft::launch_gate_grad_mixed<60, 50>},
     {768, 32, 24, true, true, &sfft::launch_regtile_mixed<32, 24>, &sfft::launch_gate_grad_mixed<32, 24>},
     {1536, 48, 32, true, true, &sfft::launch_regtile_mixed<48, 32>, &sfft::launch_gate_grad_mixed<48, 32>},
@@ -298,8 +301,8 @@ int choose(const SpectreMixArgs* a, const Plan* plan, Choice* c) {
   else if ((reinterpret_cast<uintptr_t>(a->out) % (2 * es_out)) || (a->out_sn % 2) || (a->out_sb % 2)) why = "out not pair-aligned";
   else if (a->mem && (reinterpret_cast<uintptr_t>(a->mem) % 16)) why = "mem not 16-byte aligned";
   else if (reinterpret_cast<uintptr_t>(a->gate) % 8) why = "gate not 8-byte aligned";
-  else if (a->v_sn * 63 * 4 + 64 >= ((int64_t)1 << 31) || a->out_sn * 63 * 4 + 64 >= ((int64_t)1 << 31)) why = "row stride too large";
-  else if (a->B * ((D + 15) / 16) >= ((int64_t)1 << 31)) why = "too many tiles";
+  else if (a->v_sn * 127 * 4 + 64 >= ((int64_t)1 << 31) || a->out_sn * 127 * 4 + 64 >= ((int64_t)1 << 31)) why = "row stride too large";
+  else if (a->B * ((D + 7) / 8) >= ((int64_t)1 << 31)) why = "too many tiles";
   c->why_not_regtile = why;
   const bool can_regtile = why[0] == 0;
   if (a->algo == SPECTRE_ALGO_REGTILE && !can_regtile)
@@ -308,7 +311,8 @@ int choose(const SpectreMixArgs* a, const Plan* plan, Choice* c) {
   if (can_regtile && a->algo != SPECTRE_ALGO_STOCKHAM) {
     c->regtile = true;
     c->tile = ts; c->RF = ts->RF; c->RS = ts->RS;
-    c->mode = a->mem ? 2 : ((a->N_in < a->n_fft) || (d_g % 16 != 0)) ? 1 : 0;
+    if (ts->tile_ch == 8) c->mode = a->mem ? 2 : ((a->N_in < a->n_fft) || (D % 8 != 0)) ? 1 : 0;   // gate always from global
+    else c->mode = a->mem ? 2 : ((a->N_in < a->n_fft) || (d_g % 16 != 0)) ? 1 : 0;
     return SPECTRE_OK;
   }
   // Stockham / Bluestein in LDS: one buffer of L points per slot; P slots per workgroup, limited by the LDS and by
@@ -365,7 +369,8 @@ int launch(const SpectreMixArgs* a, const Plan* plan, const Choice& c, bool conj
     k.out = a->out; k.tw = plan->tw_n;
     k.B = (int)a->B; k.N_in = (int)std::min<int64_t>(a->N_in, (int64_t)1 << 30); k.D = (int)a->D; k.G = (int)a->G_tot;
     k.d_g = (int)(a->D / a->G_tot); k.F = (int)(a->n_fft / 2 + 1);
-    k.tiles_per_row = (int)((a->D + 15) / 16); k.n_tiles = (int)(a->B * ((a->D + 15) / 16));
+    const int64_t tch = c.tile->tile_ch;
+    k.tiles_per_row = (int)((a->D + tch - 1) / tch); k.n_tiles = (int)(a->B * ((a->D + tch - 1) / tch));
     k.v_sb = a->v_sb; k.v_sn = a->v_sn; k.out_sb = a->out_sb; k.out_sn = a->out_sn;
     k.conj_gate = conj_gate ? 1 : 0;
     k.tpw = tiles_per_workgroup(k.n_tiles);
@@ -463,8 +468,8 @@ int spectre_mix_describe(const SpectreMixArgs* a, char* buf, size_t cap) {
   const char* in = a->in_dtype == SPECTRE_BF16 ? "bf16" : "f32";
   const char* out = a->out_dtype == SPECTRE_BF16 ? "bf16" : "f32";
   if (c.regtile) {
-    snprintf(buf, cap, "regtile%s %dx%d in=%s out=%s mode=%d tiles=%lld", c.tile->mixed ? "-mixed" : "", c.RF, c.RS, in, out, c.mode,
-             (long long)(a->B * ((a->D + 15) / 16)));
+    snprintf(buf, cap, "regtile%s %dx%d in=%s out=%s mode=%d tiles=%lld", c.tile->tile_ch == 8 ? "-long" : c.tile->mixed ? "-mixed" : "", c.RF, c.RS,
+             in, out, c.mode, (long long)(a->B * ((a->D + c.tile->tile_ch - 1) / c.tile->tile_ch)));
   } else {
     std::string r;
     const std::vector<int>& rad = plan->bluestein ? plan->radix_m : plan->radix_n;

@@ -66,6 +66,8 @@ def test_native_library_is_the_thing_that_runs():
         assert _describe(Vn.to(DEV), gn.to(DEV)).startswith("regtile-mixed " + tag)
     Vn, gn, _ = _problem(0, 1, 4096, 24, 2, 4096)    # D % 16 != 0: ragged last tile, general mode of the same kernel
     assert _describe(Vn.to(DEV), gn.to(DEV)).startswith("regtile 64x64 in=f32 out=f32 mode=1 tiles=2")
+    Vn, gn, _ = _problem(0, 1, 8192, 8, 1, 8192)
+    assert _describe(Vn.to(DEV), gn.to(DEV)).startswith("regtile-long 64x128 in=f32 out=f32 mode=0 tiles=1")
     Vn, gn, _ = _problem(0, 1, 768, 16, 1, 768)      # secondary lengths are built for equal storage dtypes only
     assert _describe(Vn.to(DEV).bfloat16(), gn.to(DEV), out_dtype=torch.float32).startswith("stockham")
 
@@ -93,6 +95,7 @@ SHAPES = [  # (B, N, D, G, n_fft)
     (3, 64, 32, 2, 64), (3, 128, 32, 2, 128), (3, 196, 32, 2, 196), (2, 384, 32, 2, 384), (2, 640, 32, 4, 640), (2, 960, 32, 2, 960),
     (2, 1200, 32, 2, 1200), (2, 1920, 32, 2, 1920), (2, 2400, 32, 2, 2400), (1, 3600, 32, 2, 3600),   # ... incl. radix 7 (196 = 14 x 14)
     (3, 50, 48, 2, 64), (3, 150, 24, 2, 196), (2, 500, 32, 2, 384), (2, 2000, 48, 2, 2400), (1, 4000, 32, 2, 3600),
+    (2, 8192, 32, 2, 8192), (2, 5000, 24, 2, 8192), (1, 9000, 12, 2, 8192), (1, 8192, 768, 4, 8192),   # 8192: lane-pair kernel
     (2, 1500, 32, 4, 1500), (2, 2304, 32, 2, 2304),                                 # Stockham, smooth
     (2, 1000, 32, 2, 1024), (2, 5000, 32, 2, 4096), (1, 100, 16, 2, 128),          # pad / truncate
     (2, 97, 12, 2, 97), (2, 331, 8, 2, 331), (1, 2039, 8, 1, 2039),                # primes: Bluestein
@@ -114,7 +117,7 @@ def test_random_vs_fp64_oracle(shape, mem):
         assert err < 2e-5
 
 
-@pytest.mark.parametrize("n_fft", [256, 512, 1024, 2048, 4096, 3000, 97, 1536, 2000])
+@pytest.mark.parametrize("n_fft", [256, 512, 1024, 2048, 4096, 3000, 97, 1536, 2000, 8192])
 @pytest.mark.parametrize("io", ["bf16->bf16", "bf16->f32", "f32->bf16"])
 def test_bf16_io(n_fft, io):
     src, dst = io.split("->")
@@ -244,7 +247,7 @@ def test_full_size_properties(B, N, D, G, dt):
         assert_close(y1[idx_b][:, :, c:c + 1].cpu().numpy(), ref, what=f"column {c}")
 
 
-@pytest.mark.parametrize("n_fft", [4096, 3000, 1024, 300, 97])
+@pytest.mark.parametrize("n_fft", [4096, 3000, 1024, 300, 97, 8192])
 def test_in_place_is_allowed(n_fft):
     """A workgroup reads every row of its channel tile before it writes any, and tiles are disjoint: out may alias V."""
     from fft_amd import spectral_mix
