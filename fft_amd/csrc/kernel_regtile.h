@@ -142,11 +142,12 @@ __device__ __forceinline__ void exchange_planes_b128(float2 (&z)[E], float* img,
 
 // MODE 0 (fast): N_in >= n_fft (no row predicates), no memory_fft, every tile inside one gate group (gate staged in LDS).
 // MODE 1 (general): row predicates, any even d_g (gate read from global memory).  MODE 2: general + memory_fft.
+// MODE 3: row predicates only (N_in < n_fft, the padded-sequence case) with the gate still staged in LDS.
 // ABL (ablation switches, tools/ablate_bench.hip only; 0 in the library): bit0 = no global loads/stores,
 // bit1 = no butterflies/twiddles/gate, bit2 = no LDS exchanges, bit3 = constant gate.
 template <int RF, int RS, bool IN_BF16, bool OUT_BF16, int MODE, int ABL = 0, int XV = SFFT_EXCHANGE_B128(RF, RS)>
 __global__ void __launch_bounds__(kPC * RS) spectre_mix_regtile(const RegtileArgs a) {
-  constexpr bool GENERAL = MODE != 0, WITH_MEM = MODE == 2, GATE_LDS = MODE == 0;
+  constexpr bool GENERAL = MODE != 0, WITH_MEM = MODE == 2, GATE_LDS = MODE == 0 || MODE == 3;
   constexpr bool NO_IO = (ABL & 1) != 0, NO_MATH = (ABL & 2) != 0, NO_LDS = (ABL & 4) != 0, NO_GATE = (ABL & 8) != 0;
   static_assert(RF == RS || RF == 2 * RS, "n_fft = RS*RS or 2*RS*RS");
   constexpr int N = RF * RS, NS = RF / RS;                  // NS sets of RS values per thread in the middle phase
@@ -425,15 +426,19 @@ hipError_t launch_regtile(const RegtileArgs& a, bool in_bf16, bool out_bf16, int
       case 0: return go(spectre_mix_regtile<RF_, RS_, false, false, 0>);                                     \
       case 1: return go(spectre_mix_regtile<RF_, RS_, false, false, 1>);                                     \
       case 2: return go(spectre_mix_regtile<RF_, RS_, false, false, 2>);                                     \
+      case 3: return go(spectre_mix_regtile<RF_, RS_, false, false, 3>);                                     \
       case 4: return go(spectre_mix_regtile<RF_, RS_, false, true, 0>);                                      \
       case 5: return go(spectre_mix_regtile<RF_, RS_, false, true, 1>);                                      \
       case 6: return go(spectre_mix_regtile<RF_, RS_, false, true, 2>);                                      \
+      case 7: return go(spectre_mix_regtile<RF_, RS_, false, true, 3>);                                      \
       case 8: return go(spectre_mix_regtile<RF_, RS_, true, false, 0>);                                      \
       case 9: return go(spectre_mix_regtile<RF_, RS_, true, false, 1>);                                      \
       case 10: return go(spectre_mix_regtile<RF_, RS_, true, false, 2>);                                     \
+      case 11: return go(spectre_mix_regtile<RF_, RS_, true, false, 3>);                                     \
       case 12: return go(spectre_mix_regtile<RF_, RS_, true, true, 0>);                                      \
       case 13: return go(spectre_mix_regtile<RF_, RS_, true, true, 1>);                                      \
       case 14: return go(spectre_mix_regtile<RF_, RS_, true, true, 2>);                                      \
+      case 15: return go(spectre_mix_regtile<RF_, RS_, true, true, 3>);                                      \
       default: return hipErrorInvalidValue;                                                                  \
     }                                                                                                        \
   }

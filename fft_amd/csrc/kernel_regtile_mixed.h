@@ -25,10 +25,11 @@ template <int RF, int RS> constexpr int mixed_image_bytes() {
 }
 template <int RF, int RS> constexpr int mixed_lds_total() { return mixed_image_bytes<RF, RS>() + (RF * RS / 2 + 1) * 8; }
 
-// MODE as in kernel_regtile.h: 0 fast (no predicates, gate staged in LDS), 1 general, 2 general + memory_fft
+// MODE as in kernel_regtile.h: 0 fast (no predicates, gate staged in LDS), 1 general, 2 general + memory_fft,
+// 3 row predicates with the gate still in LDS (padded sequences)
 template <int RF, int RS, bool IN_BF16, bool OUT_BF16, int MODE>
 __global__ void __launch_bounds__(kPC * (RF > RS ? RF : RS)) spectre_mix_regtile_mixed(const RegtileArgs a) {
-  constexpr bool GENERAL = MODE != 0, WITH_MEM = MODE == 2, GATE_LDS = MODE == 0;
+  constexpr bool GENERAL = MODE != 0, WITH_MEM = MODE == 2, GATE_LDS = MODE == 0 || MODE == 3;
   constexpr int N = RF * RS, NZ = mixed_team<RF, RS>(), NT = mixed_threads<RF, RS>();
   static_assert(N % 2 == 0, "even n_fft");
   constexpr int RAF = Split<RF>::RA, RBF = Split<RF>::RB;
@@ -211,15 +212,19 @@ hipError_t launch_regtile_mixed(const RegtileArgs& a, bool in_bf16, bool out_bf1
       case 0: return go(spectre_mix_regtile_mixed<RF_, RS_, false, false, 0>);                               \
       case 1: return go(spectre_mix_regtile_mixed<RF_, RS_, false, false, 1>);                               \
       case 2: return go(spectre_mix_regtile_mixed<RF_, RS_, false, false, 2>);                               \
+      case 3: return go(spectre_mix_regtile_mixed<RF_, RS_, false, false, 3>);                               \
       case 4: return go(spectre_mix_regtile_mixed<RF_, RS_, false, true, 0>);                                \
       case 5: return go(spectre_mix_regtile_mixed<RF_, RS_, false, true, 1>);                                \
       case 6: return go(spectre_mix_regtile_mixed<RF_, RS_, false, true, 2>);                                \
+      case 7: return go(spectre_mix_regtile_mixed<RF_, RS_, false, true, 3>);                                \
       case 8: return go(spectre_mix_regtile_mixed<RF_, RS_, true, false, 0>);                                \
       case 9: return go(spectre_mix_regtile_mixed<RF_, RS_, true, false, 1>);                                \
       case 10: return go(spectre_mix_regtile_mixed<RF_, RS_, true, false, 2>);                               \
+      case 11: return go(spectre_mix_regtile_mixed<RF_, RS_, true, false, 3>);                               \
       case 12: return go(spectre_mix_regtile_mixed<RF_, RS_, true, true, 0>);                                \
       case 13: return go(spectre_mix_regtile_mixed<RF_, RS_, true, true, 1>);                                \
       case 14: return go(spectre_mix_regtile_mixed<RF_, RS_, true, true, 2>);                                \
+      case 15: return go(spectre_mix_regtile_mixed<RF_, RS_, true, true, 3>);                                \
       default: return hipErrorInvalidValue;                                                                  \
     }                                                                                                        \
   }
@@ -250,9 +255,11 @@ hipError_t launch_regtile_mixed(const RegtileArgs& a, bool in_bf16, bool out_bf1
       case 0: return go(spectre_mix_regtile_mixed<RF_, RS_, false, false, 0>);                               \
       case 1: return go(spectre_mix_regtile_mixed<RF_, RS_, false, false, 1>);                               \
       case 2: return go(spectre_mix_regtile_mixed<RF_, RS_, false, false, 2>);                               \
+      case 3: return go(spectre_mix_regtile_mixed<RF_, RS_, false, false, 3>);                               \
       case 4: return go(spectre_mix_regtile_mixed<RF_, RS_, true, true, 0>);                                 \
       case 5: return go(spectre_mix_regtile_mixed<RF_, RS_, true, true, 1>);                                 \
       case 6: return go(spectre_mix_regtile_mixed<RF_, RS_, true, true, 2>);                                 \
+      case 7: return go(spectre_mix_regtile_mixed<RF_, RS_, true, true, 3>);                                 \
       default: return hipErrorInvalidValue;                                                                  \
     }                                                                                                        \
   }

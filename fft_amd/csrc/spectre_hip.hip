@@ -263,7 +263,7 @@ struct Choice {
   bool regtile = false;
   const TileSize* tile = nullptr;
   int RF = 0, RS = 0;      // n_fft = RF * RS
-  int mode = 0;            // 0 fast, 1 general (row predicates / gate from global), 2 general + memory_fft
+  int mode = 0;            // 0 fast, 1 general (row predicates / gate from global), 2 general + memory_fft, 3 row predicates only
   // stockham
   int P = 0, S = 0, solo = 0;
   const char* why_not_regtile = "";
@@ -312,7 +312,7 @@ int choose(const SpectreMixArgs* a, const Plan* plan, Choice* c) {
     c->regtile = true;
     c->tile = ts; c->RF = ts->RF; c->RS = ts->RS;
     if (ts->tile_ch == 8) c->mode = a->mem ? 2 : ((a->N_in < a->n_fft) || (D % 8 != 0)) ? 1 : 0;   // gate always from global
-    else c->mode = a->mem ? 2 : ((a->N_in < a->n_fft) || (d_g % 16 != 0)) ? 1 : 0;
+    else c->mode = a->mem ? 2 : (d_g % 16 != 0) ? 1 : (a->N_in < a->n_fft) ? 3 : 0;   // 3: row predicates, gate still in LDS
     return SPECTRE_OK;
   }
   // Stockham / Bluestein in LDS: one buffer of L points per slot; P slots per workgroup, limited by the LDS and by

@@ -66,6 +66,8 @@ def test_native_library_is_the_thing_that_runs():
         assert _describe(Vn.to(DEV), gn.to(DEV)).startswith("regtile-mixed " + tag)
     Vn, gn, _ = _problem(0, 1, 4096, 24, 2, 4096)    # D % 16 != 0: ragged last tile, general mode of the same kernel
     assert _describe(Vn.to(DEV), gn.to(DEV)).startswith("regtile 64x64 in=f32 out=f32 mode=1 tiles=2")
+    Vn, gn, _ = _problem(0, 1, 4000, 32, 2, 4096)    # padded sequence: row predicates, gate still staged in LDS
+    assert "mode=3" in _describe(Vn.to(DEV), gn.to(DEV), None, 4096)
     Vn, gn, _ = _problem(0, 1, 8192, 8, 1, 8192)
     assert _describe(Vn.to(DEV), gn.to(DEV)).startswith("regtile-long 64x128 in=f32 out=f32 mode=0 tiles=1")
     Vn, gn, _ = _problem(0, 1, 768, 16, 1, 768)      # secondary lengths are built for equal storage dtypes only
