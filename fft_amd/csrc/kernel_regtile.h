@@ -143,11 +143,12 @@ __device__ __forceinline__ void exchange_planes_b128(float2 (&z)[E], float* img,
 // MODE 0 (fast): N_in >= n_fft (no row predicates), no memory_fft, every tile inside one gate group (gate staged in LDS).
 // MODE 1 (general): row predicates, any even d_g (gate read from global memory).  MODE 2: general + memory_fft.
 // MODE 3: row predicates only (N_in < n_fft, the padded-sequence case) with the gate still staged in LDS.
+// MODE 4: MODE 3 + memory_fft.
 // ABL (ablation switches, tools/ablate_bench.hip only; 0 in the library): bit0 = no global loads/stores,
 // bit1 = no butterflies/twiddles/gate, bit2 = no LDS exchanges, bit3 = constant gate.
 template <int RF, int RS, bool IN_BF16, bool OUT_BF16, int MODE, int ABL = 0, int XV = SFFT_EXCHANGE_B128(RF, RS)>
 __global__ void __launch_bounds__(kPC * RS) spectre_mix_regtile(const RegtileArgs a) {
-  constexpr bool GENERAL = MODE != 0, WITH_MEM = MODE == 2, GATE_LDS = MODE == 0 || MODE == 3;
+  constexpr bool GENERAL = MODE != 0, WITH_MEM = MODE == 2 || MODE == 4, GATE_LDS = MODE == 0 || MODE == 3 || MODE == 4;
   constexpr bool NO_IO = (ABL & 1) != 0, NO_MATH = (ABL & 2) != 0, NO_LDS = (ABL & 4) != 0, NO_GATE = (ABL & 8) != 0;
   static_assert(RF == RS || RF == 2 * RS, "n_fft = RS*RS or 2*RS*RS");
   constexpr int N = RF * RS, NS = RF / RS;                  // NS sets of RS values per thread in the middle phase
@@ -311,6 +312,13 @@ __global__ void __launch_bounds__(kPC * RS) spectre_mix_regtile(const RegtileArg
             gnxt[decltype(kbc)::value] = fetch_gate(k2n, k2n >= RS / 2, k2n == 0 || k2n == RS / 2);
           });
         }
+        float4 mcur[WITH_MEM ? RBS : 1];
+        if constexpr (WITH_MEM) {                    // memory_fft rows of this group: issued ahead of the butterfly that hides them
+          static_for<0, RBS>([&](auto kbc) {
+            constexpr int kb = decltype(kbc)::value;
+            mcur[kb] = *reinterpret_cast<const float4*>(a.mem + ((size_t)gate_index(ka + RAS * kb) * a.D + cg) * 2);
+          });
+        }
         fftA_stage2_group<RAS, RBS, false, ka, OFF, RF>(z);
         static_for<0, RBS>([&](auto kbc) {
           constexpr int kb = decltype(kbc)::value;
@@ -320,8 +328,7 @@ __global__ void __launch_bounds__(kPC * RS) spectre_mix_regtile(const RegtileArg
           constexpr bool edge = (k2 == 0) || (k2 == RS / 2);
           z[j] = cmul(z[j], gcur[kb]);
           if constexpr (WITH_MEM) {                  // spectre.py:548-549
-            const int idx = gate_index(k2);
-            const float4 m = *reinterpret_cast<const float4*>(a.mem + ((size_t)idx * a.D + cg) * 2);
+            const float4 m = mcur[kb];
             float2 add;
             if (edge && k1 == 0) add = make_float2(m.x, m.z);
             else if (upper)      add = make_float2(m.x + m.w, m.z - m.y);
@@ -408,8 +415,8 @@ hipError_t launch_regtile(const RegtileArgs& a, bool in_bf16, bool out_bf16, int
                                       hipStream_t stream) {                                                  \
     const dim3 grid(a.n_wg), block(regtile_threads<RF_, RS_>());                                             \
     const size_t lds = regtile_lds_total<RF_, RS_>();                                                        \
-    const int key = (in_bf16 ? 8 : 0) | (out_bf16 ? 4 : 0) | mode;                                           \
-    static bool lds_opt_in[16][16] = {};   /* [device][variant]: >64 KiB of dynamic LDS needs a one-time opt-in */ \
+    const int key = (in_bf16 ? 16 : 0) | (out_bf16 ? 8 : 0) | mode;                                          \
+    static bool lds_opt_in[16][32] = {};   /* [device][variant]: >64 KiB of dynamic LDS needs a one-time opt-in */ \
     auto go = [&](auto kern) -> hipError_t {                                                                 \
       int dev = 0;                                                                                           \
       (void)hipGetDevice(&dev);                                                                              \
@@ -427,18 +434,22 @@ hipError_t launch_regtile(const RegtileArgs& a, bool in_bf16, bool out_bf16, int
       case 1: return go(spectre_mix_regtile<RF_, RS_, false, false, 1>);                                     \
       case 2: return go(spectre_mix_regtile<RF_, RS_, false, false, 2>);                                     \
       case 3: return go(spectre_mix_regtile<RF_, RS_, false, false, 3>);                                     \
-      case 4: return go(spectre_mix_regtile<RF_, RS_, false, true, 0>);                                      \
-      case 5: return go(spectre_mix_regtile<RF_, RS_, false, true, 1>);                                      \
-      case 6: return go(spectre_mix_regtile<RF_, RS_, false, true, 2>);                                      \
-      case 7: return go(spectre_mix_regtile<RF_, RS_, false, true, 3>);                                      \
-      case 8: return go(spectre_mix_regtile<RF_, RS_, true, false, 0>);                                      \
-      case 9: return go(spectre_mix_regtile<RF_, RS_, true, false, 1>);                                      \
-      case 10: return go(spectre_mix_regtile<RF_, RS_, true, false, 2>);                                     \
-      case 11: return go(spectre_mix_regtile<RF_, RS_, true, false, 3>);                                     \
-      case 12: return go(spectre_mix_regtile<RF_, RS_, true, true, 0>);                                      \
-      case 13: return go(spectre_mix_regtile<RF_, RS_, true, true, 1>);                                      \
-      case 14: return go(spectre_mix_regtile<RF_, RS_, true, true, 2>);                                      \
-      case 15: return go(spectre_mix_regtile<RF_, RS_, true, true, 3>);                                      \
+      case 4: return go(spectre_mix_regtile<RF_, RS_, false, false, 4>);                                     \
+      case 8: return go(spectre_mix_regtile<RF_, RS_, false, true, 0>);                                      \
+      case 9: return go(spectre_mix_regtile<RF_, RS_, false, true, 1>);                                      \
+      case 10: return go(spectre_mix_regtile<RF_, RS_, false, true, 2>);                                     \
+      case 11: return go(spectre_mix_regtile<RF_, RS_, false, true, 3>);                                     \
+      case 12: return go(spectre_mix_regtile<RF_, RS_, false, true, 4>);                                     \
+      case 16: return go(spectre_mix_regtile<RF_, RS_, true, false, 0>);                                     \
+      case 17: return go(spectre_mix_regtile<RF_, RS_, true, false, 1>);                                     \
+      case 18: return go(spectre_mix_regtile<RF_, RS_, true, false, 2>);                                     \
+      case 19: return go(spectre_mix_regtile<RF_, RS_, true, false, 3>);                                     \
+      case 20: return go(spectre_mix_regtile<RF_, RS_, true, false, 4>);                                     \
+      case 24: return go(spectre_mix_regtile<RF_, RS_, true, true, 0>);                                      \
+      case 25: return go(spectre_mix_regtile<RF_, RS_, true, true, 1>);                                      \
+      case 26: return go(spectre_mix_regtile<RF_, RS_, true, true, 2>);                                      \
+      case 27: return go(spectre_mix_regtile<RF_, RS_, true, true, 3>);                                      \
+      case 28: return go(spectre_mix_regtile<RF_, RS_, true, true, 4>);                                      \
       default: return hipErrorInvalidValue;                                                                  \
     }                                                                                                        \
   }

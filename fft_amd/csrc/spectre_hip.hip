@@ -312,7 +312,8 @@ int choose(const SpectreMixArgs* a, const Plan* plan, Choice* c) {
     c->regtile = true;
     c->tile = ts; c->RF = ts->RF; c->RS = ts->RS;
     if (ts->tile_ch == 8) c->mode = a->mem ? 2 : ((a->N_in < a->n_fft) || (D % 8 != 0)) ? 1 : 0;   // gate always from global
-    else c->mode = a->mem ? 2 : (d_g % 16 != 0) ? 1 : (a->N_in < a->n_fft) ? 3 : 0;   // 3: row predicates, gate still in LDS
+    else if (!ts->mixed) c->mode = (d_g % 16 != 0) ? (a->mem ? 2 : 1) : a->mem ? 4 : (a->N_in < a->n_fft) ? 3 : 0;   // 3, 4: gate still in LDS
+    else c->mode = a->mem ? 2 : (d_g % 16 != 0) ? 1 : (a->N_in < a->n_fft) ? 3 : 0;
     return SPECTRE_OK;
   }
   // Stockham / Bluestein in LDS: one buffer of L points per slot; P slots per workgroup, limited by the LDS and by
