@@ -8,7 +8,7 @@
 //   * RF != RS in general, so a column team has max(RF, RS) threads: the first RS of them own a residue class of rows
 //     (loads, F1, twiddles, I2, stores), the first RF own a residue class of bins (F2, gate, I1),
 //   * the Hermitian half of a bin is decided at run time per value (k1 is a lane quantity).
-// Replaces the LDS Stockham path for these lengths (2.7x faster at n_fft = 3000).
+// Replaces the LDS Stockham path for these lengths (2.9x faster at n_fft = 3000: 4.86 -> 1.67 ms at (256,3000,768)).
 #pragma once
 #include "kernel_regtile.h"
 #include "fft_regs_mixed.h"
