@@ -14,7 +14,7 @@ import torch  # noqa: F401  — must be imported first: the library binds to the
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPECTRE_HIP_LIB") or os.path.join(_HERE, "lib", "libspectre_hip.so")   # env: A/B builds
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 F32, BF16 = 0, 1
 ALGO = {"auto": 0, "stockham": 1, "regtile": 2}
 
@@ -22,7 +22,7 @@ ALGO = {"auto": 0, "stockham": 1, "regtile": 2}
 EXPORTS = ("spectre_version", "spectre_last_error", "spectre_mix_fwd", "spectre_mix_describe",
            "spectre_plan_create", "spectre_plan_destroy", "spectre_mix_time", "spectre_mix_bwd",
            "spectre_mix_bwd_workspace_bytes", "spectre_gate_fwd", "spectre_rfft_fwd", "spectre_decode_workspace_bytes",
-           "spectre_decode_step")
+           "spectre_decode_step", "spectre_decode_head_workspace_bytes", "spectre_decode_head_step")
 
 
 class SpectreMixArgs(ctypes.Structure):
@@ -59,6 +59,18 @@ class SpectreDecodeArgs(ctypes.Structure):
         ("out", ctypes.c_void_p), ("workspace", ctypes.c_void_p),
         ("n_fft", ctypes.c_int64), ("d", ctypes.c_int64), ("G", ctypes.c_int64), ("t", ctypes.c_int64),
         ("device", ctypes.c_int32), ("stream", ctypes.c_void_p),
+    ]
+
+
+class SpectreDecodeHeadArgs(ctypes.Structure):
+    _fields_ = [
+        ("prefix", ctypes.c_void_p), ("V_buf", ctypes.c_void_p), ("Q_buf", ctypes.c_void_p), ("sum_q", ctypes.c_void_p),
+        ("q_t", ctypes.c_void_p), ("v_t", ctypes.c_void_p), ("out", ctypes.c_void_p), ("workspace", ctypes.c_void_p),
+        ("ln_w", ctypes.c_void_p), ("ln_b", ctypes.c_void_p), ("w1", ctypes.c_void_p), ("b1", ctypes.c_void_p),
+        ("w2", ctypes.c_void_p), ("b2", ctypes.c_void_p), ("modrelu_bias", ctypes.c_void_p),
+        ("ln_eps", ctypes.c_float), ("modrelu_eps", ctypes.c_float),
+        ("n_fft", ctypes.c_int64), ("d", ctypes.c_int64), ("G", ctypes.c_int64), ("K", ctypes.c_int64), ("h1", ctypes.c_int64),
+        ("t", ctypes.c_int64), ("device", ctypes.c_int32), ("stream", ctypes.c_void_p),
     ]
 
 
@@ -123,6 +135,10 @@ def load():
         lib.spectre_decode_workspace_bytes.restype = ctypes.c_int64
         lib.spectre_decode_step.argtypes = [ctypes.POINTER(SpectreDecodeArgs)]
         lib.spectre_decode_step.restype = ctypes.c_int
+        lib.spectre_decode_head_workspace_bytes.argtypes = [ctypes.c_int64] * 4
+        lib.spectre_decode_head_workspace_bytes.restype = ctypes.c_int64
+        lib.spectre_decode_head_step.argtypes = [ctypes.POINTER(SpectreDecodeHeadArgs)]
+        lib.spectre_decode_head_step.restype = ctypes.c_int
         ver = lib.spectre_version()
         if ver != ABI_VERSION:
             raise NativeLibraryError(f"ABI mismatch: library {ver}, binding {ABI_VERSION}")

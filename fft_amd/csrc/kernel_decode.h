@@ -132,14 +132,88 @@ __global__ void __launch_bounds__(256) spectre_decode_step(const DecodeArgs a) {
   if (w == 0 && live) a.partial[(size_t)blockIdx.x * a.d + c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
+// sum of the per-chunk partials, 1/n; optionally also the ring-buffer writes V_buf[j] = v_t, Q_buf[j] = q_t (:807-810),
+// which must follow the main kernel's read of the evicted row
 __global__ void __launch_bounds__(256) spectre_decode_finish(const float* __restrict__ partial, float* __restrict__ out, int chunks, int d,
-                                                             int n) {
+                                                             int n, float* v_row, const float* v_new, float* q_row, const float* q_new) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= d) return;
   float s = 0.f;
   for (int i = 0; i < chunks; ++i) s += partial[(size_t)i * d + c];
   out[c] = s / (float)n;
+  if (v_row) v_row[c] = v_new[c];
+  if (q_row) q_row[c] = q_new[c];
 }
 #pragma clang fp contract(fast)
+
+// ---- gate descriptor of a decode step (spectre.py:575-580): running query sum -> LayerNorm -> Linear -> GELU -> Linear ----
+// One workgroup: d and the MLP are small (d x 256 + 256 x 2BG weights, < 1 MB); a wave per output row, lanes along the
+// reduction.  sum_q is updated in place with the reference's own expression (see fft_amd/decode.py on `q_old`).
+struct DecodeMlpArgs {
+  float* sum_q;            // (d) in/out
+  const float* q_t;        // (d)
+  const float *ln_w, *ln_b;
+  const float *w1, *b1;    // (h1, d), (h1)
+  const float *w2, *b2;    // (o, h1), (o)
+  float* anchors;          // (o) = (G, K, 2)
+  int d, h1, o, n, evict;
+  float ln_eps;
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__global__ void __launch_bounds__(1024) spectre_decode_mlp(const DecodeMlpArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* descr = reinterpret_cast<float*>(smem_raw);          // d
+  float* hidden = descr + a.d;                                 // h1
+  __shared__ float red[16];
+  __shared__ float stats[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  // sum_q += q_t - (q_old if evict else 0.0), with q_old read AFTER the ring slot was overwritten in the reference
+  float part = 0.f;
+  for (int c = tid; c < a.d; c += blockDim.x) {
+    const float q = a.q_t[c];
+    const float s = a.sum_q[c] + (a.evict ? (q - q) : (q - 0.0f));
+    a.sum_q[c] = s;
+    const float x = s / (float)a.n;                            // (sum_q / cache.N)
+    descr[c] = x;
+    part += x;
+  }
+  part = wave_sum(part);
+  if (lane == 0) red[wave] = part;
+  __syncthreads();
+  if (tid == 0) { float t = 0.f; for (int i = 0; i < nw; ++i) t += red[i]; stats[0] = t / (float)a.d; }
+  __syncthreads();
+  const float mean = stats[0];
+  part = 0.f;
+  for (int c = tid; c < a.d; c += blockDim.x) { const float dv = descr[c] - mean; part += dv * dv; }
+  part = wave_sum(part);
+  __syncthreads();
+  if (lane == 0) red[wave] = part;
+  __syncthreads();
+  if (tid == 0) { float t = 0.f; for (int i = 0; i < nw; ++i) t += red[i]; stats[1] = 1.0f / sqrtf(t / (float)a.d + a.ln_eps); }
+  __syncthreads();
+  const float rstd = stats[1];
+  for (int c = tid; c < a.d; c += blockDim.x) descr[c] = (descr[c] - mean) * rstd * a.ln_w[c] + a.ln_b[c];
+  __syncthreads();
+  for (int j = wave; j < a.h1; j += nw) {                      // hidden = GELU(W1 descr + b1), exact erf form (nn.GELU())
+    const float* w = a.w1 + (size_t)j * a.d;
+    float acc = 0.f;
+    for (int c = lane; c < a.d; c += 64) acc += w[c] * descr[c];
+    acc = wave_sum(acc);
+    if (lane == 0) { const float x = acc + a.b1[j]; hidden[j] = 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+  }
+  __syncthreads();
+  for (int i = wave; i < a.o; i += nw) {
+    const float* w = a.w2 + (size_t)i * a.h1;
+    float acc = 0.f;
+    for (int c = lane; c < a.h1; c += 64) acc += w[c] * hidden[c];
+    acc = wave_sum(acc);
+    if (lane == 0) a.anchors[i] = acc + a.b2[i];
+  }
+}
 
 }  // namespace sfft

@@ -23,6 +23,8 @@ struct GateArgs {
   int B, G, K, F;
   long long phase_sb;      // 0 or F
   float eps;
+  int decode_m, decode_n;  // decode_m != 0: multiply by exp(1j * 2*pi * k * decode_m / decode_n) evaluated as the reference does in
+                           // float32 (spectre.py:593-596); decode_m = t - t % n_fft
 };
 
 __device__ __forceinline__ float cubic_conv1(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
@@ -64,6 +66,16 @@ __global__ void __launch_bounds__(256) spectre_gate_producer(const GateArgs a) {
       const float2 ph = a.phase[b * a.phase_sb + k];
       const float r2 = re * ph.x - im * ph.y;
       im = re * ph.y + im * ph.x;
+      re = r2;
+    }
+    if (a.decode_m != 0) {
+      // `1j * 2 * math.pi * k * (t - j) / N` on a complex64 tensor: ((float32(2 pi) * k) * m) * float32(1 / N) — ATen's
+      // complex division multiplies by the rounded reciprocal of the real divisor — then cos / sin
+      const float x = ((6.283185307179586f * (float)k) * (float)a.decode_m) * (1.0f / (float)a.decode_n);
+      float sn, cs;
+      sincosf(x, &sn, &cs);
+      const float r2 = re * cs - im * sn;
+      im = re * sn + im * cs;
       re = r2;
     }
     a.gate[i] = make_float2(re, im);

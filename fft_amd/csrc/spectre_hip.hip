@@ -634,6 +634,7 @@ int spectre_gate_fwd(const SpectreGateArgs* a) {
   k.anchors = reinterpret_cast<const float2*>(a->anchors); k.bias = reinterpret_cast<const float*>(a->bias);
   k.phase = reinterpret_cast<const float2*>(a->phase); k.gate = reinterpret_cast<float2*>(a->gate);
   k.B = (int)a->B; k.G = (int)a->G; k.K = (int)a->K; k.F = (int)a->F; k.phase_sb = a->phase_sb; k.eps = a->eps;
+  k.decode_m = 0; k.decode_n = 1;
   const int64_t total = a->B * a->G * a->F;
   hipLaunchKernelGGL(sfft::spectre_gate_producer, dim3((unsigned)std::min<int64_t>(8192, (total + 255) / 256)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(a->stream), k);
@@ -715,7 +716,64 @@ int spectre_decode_step(const SpectreDecodeArgs* a) {
   hipLaunchKernelGGL(sfft::spectre_decode_step, dim3((unsigned)chunks, (unsigned)((k.d + 63) / 64)), dim3(256), 0, stream, k);
   if (a->gate)
     hipLaunchKernelGGL(sfft::spectre_decode_finish, dim3((unsigned)((k.d + 255) / 256)), dim3(256), 0, stream, k.partial,
-                       reinterpret_cast<float*>(a->out), chunks, k.d, k.n);
+                       reinterpret_cast<float*>(a->out), chunks, k.d, k.n, (float*)nullptr, (const float*)nullptr, (float*)nullptr,
+                       (const float*)nullptr);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(SPECTRE_E_HIP, "decode launch failed: %s", hipGetErrorString(e));
+  return SPECTRE_OK;
+}
+
+int64_t spectre_decode_head_workspace_bytes(int64_t n_fft, int64_t d, int64_t G, int64_t K) {
+  if (n_fft < 1 || d < 1 || G < 1 || K < 1) return 0;
+  const int64_t F = n_fft / 2 + 1;
+  return spectre_decode_workspace_bytes(n_fft, d) + ((2 * G * K * 4 + 15) / 16) * 16 + G * F * 8;   // partials | anchors | gate
+}
+
+int spectre_decode_head_step(const SpectreDecodeHeadArgs* a) {
+  if (!a) return fail(SPECTRE_E_INVALID, "args is NULL");
+  if (a->n_fft < 1 || a->d < 1 || a->G < 1 || a->K < 1 || a->h1 < 1 || a->d % a->G || a->t < 0 || a->t >= ((int64_t)1 << 24))
+    return fail(SPECTRE_E_INVALID, "bad sizes (t must be < 2^24)");
+  if (!a->prefix || !a->V_buf || !a->Q_buf || !a->sum_q || !a->q_t || !a->v_t || !a->out || !a->workspace || !a->ln_w || !a->ln_b ||
+      !a->w1 || !a->b1 || !a->w2 || !a->b2 || !a->modrelu_bias)
+    return fail(SPECTRE_E_INVALID, "all pointers must be non-NULL device pointers");
+  if ((a->d + a->h1) * 4 > 60 * 1024) return fail(SPECTRE_E_UNSUPPORTED, "d + d_gate too large for the descriptor kernel");
+  DeviceGuard g(a->device);
+  if (!g.ok) return fail(SPECTRE_E_HIP, "cannot select device %d", a->device);
+  hipStream_t stream = reinterpret_cast<hipStream_t>(a->stream);
+  const int64_t F = a->n_fft / 2 + 1, j = a->t % a->n_fft;
+  const int evict = a->t >= a->n_fft ? 1 : 0;
+  char* ws = reinterpret_cast<char*>(a->workspace);
+  float* partial = reinterpret_cast<float*>(ws);
+  float* anchors = reinterpret_cast<float*>(ws + spectre_decode_workspace_bytes(a->n_fft, a->d));
+  float2* gate = reinterpret_cast<float2*>(reinterpret_cast<char*>(anchors) + ((2 * a->G * a->K * 4 + 15) / 16) * 16);
+  // 1) running query sum, LayerNorm, gate MLP -> anchors (spectre.py:809-813, :578-580)
+  sfft::DecodeMlpArgs m{};
+  m.sum_q = reinterpret_cast<float*>(a->sum_q); m.q_t = reinterpret_cast<const float*>(a->q_t);
+  m.ln_w = reinterpret_cast<const float*>(a->ln_w); m.ln_b = reinterpret_cast<const float*>(a->ln_b);
+  m.w1 = reinterpret_cast<const float*>(a->w1); m.b1 = reinterpret_cast<const float*>(a->b1);
+  m.w2 = reinterpret_cast<const float*>(a->w2); m.b2 = reinterpret_cast<const float*>(a->b2);
+  m.anchors = anchors; m.d = (int)a->d; m.h1 = (int)a->h1; m.o = (int)(2 * a->G * a->K); m.n = (int)a->n_fft; m.evict = evict;
+  m.ln_eps = a->ln_eps;
+  hipLaunchKernelGGL(sfft::spectre_decode_mlp, dim3(1), dim3(1024), (size_t)(a->d + a->h1) * 4, stream, m);
+  // 2) cubic resample -> modReLU -> decode phase (spectre.py:586-596)
+  sfft::GateArgs gk{};
+  gk.anchors = reinterpret_cast<const float2*>(anchors); gk.bias = reinterpret_cast<const float*>(a->modrelu_bias); gk.phase = nullptr;
+  gk.gate = gate; gk.B = 1; gk.G = (int)a->G; gk.K = (int)a->K; gk.F = (int)F; gk.phase_sb = 0; gk.eps = a->modrelu_eps;
+  gk.decode_m = (int)(a->t - j); gk.decode_n = (int)a->n_fft;
+  const int64_t total = a->G * F;
+  hipLaunchKernelGGL(sfft::spectre_gate_producer, dim3((unsigned)std::min<int64_t>(8192, (total + 255) / 256)), dim3(256), 0, stream, gk);
+  // 3) spectrum update + filter + one-row inverse (spectre.py:794-805, :603, :614-655), then the ring writes (:807-810)
+  float* v_row = reinterpret_cast<float*>(a->V_buf) + j * a->d;
+  float* q_row = reinterpret_cast<float*>(a->Q_buf) + j * a->d;
+  sfft::DecodeArgs k{};
+  k.prefix = reinterpret_cast<float2*>(a->prefix); k.v_old = v_row; k.v_new = reinterpret_cast<const float*>(a->v_t);
+  k.gate = gate; k.partial = partial;
+  k.n = (int)a->n_fft; k.F = (int)F; k.d = (int)a->d; k.d_g = (int)(a->d / a->G);
+  k.t = (int)a->t; k.j = (int)j; k.evict = evict; k.chunk = sfft::kDecodeChunk;
+  const int chunks = (k.F + k.chunk - 1) / k.chunk;
+  hipLaunchKernelGGL(sfft::spectre_decode_step, dim3((unsigned)chunks, (unsigned)((k.d + 63) / 64)), dim3(256), 0, stream, k);
+  hipLaunchKernelGGL(sfft::spectre_decode_finish, dim3((unsigned)((k.d + 255) / 256)), dim3(256), 0, stream, k.partial,
+                     reinterpret_cast<float*>(a->out), chunks, k.d, k.n, v_row, k.v_new, q_row, reinterpret_cast<const float*>(a->q_t));
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(SPECTRE_E_HIP, "decode launch failed: %s", hipGetErrorString(e));
   return SPECTRE_OK;

@@ -121,11 +121,56 @@ class PrefixFFTCache:
         return self.prefix_fft, self.sum_q
 
 
+def _fused_head_ok(head) -> bool:
+    """The single-call path needs the reference's stock gate MLP (Linear -> GELU(erf) -> Linear) and LayerNorm in fp32."""
+    import torch.nn as nn
+    mlp = head.gate_mlp
+    return (isinstance(mlp, nn.Sequential) and len(mlp) == 3 and isinstance(mlp[0], nn.Linear) and isinstance(mlp[2], nn.Linear)
+            and isinstance(mlp[1], nn.GELU) and getattr(mlp[1], "approximate", "none") == "none"
+            and isinstance(head.q_norm, nn.LayerNorm) and head.q_norm.elementwise_affine and head.q_norm.bias is not None
+            and all(p.dtype == torch.float32 and p.is_contiguous() for p in list(mlp.parameters()) + list(head.q_norm.parameters())))
+
+
 @torch.no_grad()
 def head_decode_step(head, q_t: torch.Tensor, v_t: torch.Tensor, cache: PrefixFFTCache) -> torch.Tensor:
-    """SpectreHead.decode_step (spectre.py:564-611): mixed vector (d,) for the current time step, batch size 1."""
+    """SpectreHead.decode_step (spectre.py:564-611): mixed vector (d,) for the current time step, batch size 1.
+
+    One C-ABI call (`spectre_decode_head_step`, four launches): running query sum -> LayerNorm -> gate MLP; cubic resample ->
+    modReLU -> decode phase; spectrum update + filter + one-row inverse; partial sums + ring-buffer writes."""
     if head.use_toeplitz:
         raise NotImplementedError("use_toeplitz=True is not supported (the reference itself fails to construct it)")
+    cache._require_hip()
+    if not _fused_head_ok(head):
+        return _head_decode_step_ops(head, q_t, v_t, cache)
+    lib = _native.load()
+    t = cache.t + 1
+    q_t = q_t.to(torch.float32).contiguous()
+    v_t = v_t.to(torch.float32).contiguous()
+    out = torch.empty(cache.d, dtype=torch.float32, device=cache.device)
+    need = lib.spectre_decode_head_workspace_bytes(cache.N, cache.d, head.G, head.B)
+    if cache._ws is None or cache._ws.numel() < need:
+        cache._ws = torch.empty(need, dtype=torch.uint8, device=cache.device)
+    if not cache.sum_q.is_contiguous():
+        cache.sum_q = cache.sum_q.contiguous()
+    a = _native.SpectreDecodeHeadArgs()
+    a.prefix, a.V_buf, a.Q_buf, a.sum_q = cache.prefix_fft.data_ptr(), cache.V_buf.data_ptr(), cache.Q_buf.data_ptr(), cache.sum_q.data_ptr()
+    a.q_t, a.v_t, a.out, a.workspace = q_t.data_ptr(), v_t.data_ptr(), out.data_ptr(), cache._ws.data_ptr()
+    a.ln_w, a.ln_b = head.q_norm.weight.data_ptr(), head.q_norm.bias.data_ptr()
+    a.w1, a.b1 = head.gate_mlp[0].weight.data_ptr(), head.gate_mlp[0].bias.data_ptr()
+    a.w2, a.b2 = head.gate_mlp[2].weight.data_ptr(), head.gate_mlp[2].bias.data_ptr()
+    a.modrelu_bias = head.modrelu.bias.data_ptr()
+    a.ln_eps, a.modrelu_eps = float(head.q_norm.eps), float(head.modrelu.eps_value)
+    a.n_fft, a.d, a.G, a.K, a.h1, a.t = cache.N, cache.d, head.G, head.B, head.gate_mlp[0].out_features, t
+    a.device = cache.device.index if cache.device.index is not None else torch.cuda.current_device()
+    a.stream = torch.cuda.current_stream(cache.device).cuda_stream
+    _native.check(lib.spectre_decode_head_step(ctypes.byref(a)), "spectre_decode_head_step")
+    cache.t = t
+    return out
+
+
+@torch.no_grad()
+def _head_decode_step_ops(head, q_t: torch.Tensor, v_t: torch.Tensor, cache: PrefixFFTCache) -> torch.Tensor:
+    """Same step with the descriptor / MLP as PyTorch ops (non-standard gate MLPs); spectrum work still on the HIP kernels."""
 
     def gate_fn(sum_q, t, j):
         descr = head.q_norm((sum_q / cache.N).unsqueeze(0)).squeeze(0)                       # :578

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SPECTRE_ABI_VERSION 4
+#define SPECTRE_ABI_VERSION 5
 
 enum {
   SPECTRE_OK = 0,
@@ -186,6 +186,35 @@ typedef struct SpectreDecodeArgs {
 
 int64_t spectre_decode_workspace_bytes(int64_t n_fft, int64_t d);
 int spectre_decode_step(const SpectreDecodeArgs* args);
+
+/* One whole SpectreHead.decode_step (spectre.py:564-611, with PrefixFFTCache.decode_step :786-814 inside) as a single
+ * call = four launches: running query sum -> LayerNorm -> gate MLP (Linear, GELU, Linear) -> anchors; cubic resample ->
+ * modReLU -> decode phase; spectrum update + filter + one-row inverse; partial sums and ring-buffer writes.
+ * The cache state lives in the caller's tensors (the layout of PrefixFFTCache):
+ *   prefix (F, d) c64   V_buf, Q_buf (n_fft, d) f32   sum_q (d) f32   — all updated in place;  q_t, v_t, out: (d) f32
+ *   ln_w, ln_b (d); w1 (h1, d), b1 (h1); w2 (2*G*K, h1), b2 (2*G*K): q_norm and gate_mlp parameters, row-major f32
+ *   modrelu_bias (G * F);  t = absolute position of the new token (cache.t + 1)
+ *   workspace: spectre_decode_head_workspace_bytes(n_fft, d, G, K) bytes
+ */
+typedef struct SpectreDecodeHeadArgs {
+  void* prefix;
+  void* V_buf;
+  void* Q_buf;
+  void* sum_q;
+  const void* q_t;
+  const void* v_t;
+  void* out;
+  void* workspace;
+  const void *ln_w, *ln_b, *w1, *b1, *w2, *b2, *modrelu_bias;
+  float ln_eps, modrelu_eps;
+  int64_t n_fft, d, G, K, h1;
+  int64_t t;
+  int32_t device;
+  void* stream;
+} SpectreDecodeHeadArgs;
+
+int64_t spectre_decode_head_workspace_bytes(int64_t n_fft, int64_t d, int64_t G, int64_t K);
+int spectre_decode_head_step(const SpectreDecodeHeadArgs* args);
 
 #ifdef __cplusplus
 }

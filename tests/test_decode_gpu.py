@@ -83,3 +83,23 @@ def test_state_only_decode_step_and_prefill_shapes():
     assert_close(torch.view_as_real(pf).cpu().numpy(), torch.view_as_real(opf).numpy(), what="state-only spectrum")
     assert_close(sq.cpu().numpy(), osq.numpy(), what="sum_q")
     assert torch.equal(c.V_buf.cpu(), oc.V_buf) and torch.equal(c.Q_buf.cpu(), oc.Q_buf)
+
+
+def test_fused_and_ops_decode_paths_agree():
+    """SpectreHead.decode_step = one C-ABI call; the ops path (kept for non-standard gate MLPs) must give the same step."""
+    from fft_amd import PrefixFFTCache, SpectreHead
+    from fft_amd.decode import _head_decode_step_ops
+    torch.manual_seed(5)
+    n_fft, dim = 60, 48
+    head = SpectreHead(dim, n_fft, num_groups=2, pooling_type="mean").to(DEV).eval()
+    Qp, Vp = torch.randn(55, dim, device=DEV), torch.randn(55, dim, device=DEV)
+    q, v = torch.randn(20, dim, device=DEV), torch.randn(20, dim, device=DEV)
+    c1 = PrefixFFTCache(n_fft, dim, device=torch.device(DEV)); c1.prefill(Qp, Vp)
+    c2 = PrefixFFTCache(n_fft, dim, device=torch.device(DEV)); c2.prefill(Qp, Vp)
+    for i in range(20):
+        a = head.decode_step(q[i], v[i], c1)
+        b = _head_decode_step_ops(head, q[i], v[i], c2)
+        assert_close(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol_rms=1e-4, what=f"step {i}")
+    assert c1.t == c2.t
+    assert_close(c1.sum_q.cpu().numpy(), c2.sum_q.cpu().numpy(), what="sum_q")
+    assert torch.equal(c1.V_buf, c2.V_buf) and torch.equal(c1.Q_buf, c2.Q_buf)
