@@ -55,8 +55,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJDIR, exist_ok=True)
     cc = hipcc()
 
+    hdr_time = _newest([os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS] + [os.path.abspath(__file__)])
+
     def compile_one(src: str) -> str:
         obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(hdr_time, os.path.getmtime(os.path.join(CSRC, src))):
+            return obj                                # up to date (every translation unit includes most of the headers)
         cmd = [cc, *CXXFLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
