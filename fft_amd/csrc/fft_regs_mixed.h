@@ -32,6 +32,7 @@ template <> struct Split<32> { static constexpr int RA = 4, RB = 8; };
 template <> struct Split<40> { static constexpr int RA = 8, RB = 5; };
 template <> struct Split<48> { static constexpr int RA = 8, RB = 6; };
 template <> struct Split<50> { static constexpr int RA = 2, RB = 25; };
+template <> struct Split<56> { static constexpr int RA = 8, RB = 7; };
 template <> struct Split<60> { static constexpr int RA = 4, RB = 15; };
 template <> struct Split<64> { static constexpr int RA = 8, RB = 8; };
 

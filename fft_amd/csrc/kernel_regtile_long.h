@@ -1,9 +1,10 @@
-// kernel_regtile_long.h — register-resident spectral mix for n_fft = 8192 = 64 x 128 on gfx950.
+// kernel_regtile_long.h — register-resident spectral mix for n_fft = RF x 128, RF in {40, 48, 56, 64}
+// (5120, 6144, 7168, 8192) on gfx950.
 //
 // Same plan as kernel_regtile.h (which see: /root/reference/spectre.py:506, :542-553 in one kernel, two real channels
 // per complex sequence, LDS only as the transposition buffer), with two changes forced by the length:
-//   * a tile is 8 channels (4 packed sequences, 32-byte fp32 row segments) x 8192 rows = 256 KiB — the same half register
-//     file as the 4096-row tile; four neighbouring tiles share every 128-byte line and are adjacent in the
+//   * a tile is 8 channels (4 packed sequences, 32-byte fp32 row segments) x n_fft rows = 256 KiB at 8192 — the same half
+//     register file as the 4096-row tile; four neighbouring tiles share every 128-byte line and are adjacent in the
 //     XCD-contiguous order, so the line is fetched once (the gate-gradient kernels use the same trick);
 //   * the second transform has 128 points but a thread holds 64 values: a lane PAIR (h = lane & 1) owns one (column,
 //     k1), each lane transforming the 64 samples n2 = 2m + h, and the radix-2 step across the pair goes through a DPP
@@ -11,9 +12,9 @@
 //                  X[k2' + 64] = E_0[k2'] - W_128^k2' E_1[k2']      (kept by h = 1)
 //     and the inverse runs the same butterfly as decimation in frequency before the two 64-point inverse transforms.
 //
-//   thread roles   rows : tid = p + 4 n2          (n2 < 128: loads, F1 over n1, twiddles, I2, stores)
-//                  bins : tid = h + 2 p + 8 k1     (k1 < 64, h < 2: F2, pair butterfly, gate, inverse)
-//   n = n2 + 128 n1,  k = k1 + 64 k2,  k2 = k2' + 64 h.
+//   thread roles   rows : tid = p + 4 n2          (n2 < 128: loads, F1 over n1 < RF, twiddles, I2, stores)
+//                  bins : tid = h + 2 p + 8 k1     (k1 < RF, h < 2: F2, pair butterfly, gate, inverse)
+//   n = n2 + 128 n1,  k = k1 + RF k2,  k2 = k2' + 64 h.  The RF-point transforms use the mixed-radix engine (RF = 64: 8 x 8).
 #pragma once
 #include "kernel_regtile.h"
 #include "fft_regs_mixed.h"   // TwTab<128>
@@ -21,10 +22,10 @@
 namespace sfft {
 
 constexpr int kLongPC = 4;                     // packed sequences per tile (8 channels)
-constexpr int kLongN = 8192, kLongRF = 64, kLongRS = 128;
+constexpr int kLongRS = 128;
 constexpr int kLongRow1 = kLongRS * kLongPC + 8;     // E1 image [k1][n2][p]: row stride 520 floats (8-float pad: banks)
-constexpr int kLongRow2 = kLongRF * kLongPC + 4;     // E2 image [n2][sigma(k1)][p]: row stride 260 floats
-constexpr int long_image_bytes() { return (kLongRF * kLongRow1 > kLongRS * kLongRow2 ? kLongRF * kLongRow1 : kLongRS * kLongRow2) * 4; }
+constexpr int long_row2(int RF) { return RF * kLongPC + 4; }   // E2 image [n2][sigma(k1)][p]: row stride = 4 (mod 32) floats
+constexpr int long_image_bytes(int RF) { return (RF * kLongRow1 > kLongRS * long_row2(RF) ? RF * kLongRow1 : kLongRS * long_row2(RF)) * 4; }
 
 // slot of bin class k1 inside an E2 row: the two low bits move up by one so that the 32 lanes of a write group
 // (h', p, k1 & 3) fall into 32 different banks; the reader's k1 is a compile-time constant, so this costs nothing
@@ -35,10 +36,12 @@ __device__ __forceinline__ float dpp_swap1(float v) {      // value of the neigh
 }
 
 // MODE 0: N_in >= n_fft and D % 8 == 0 (no predicates); 1: row / channel predicates; 2: predicates + memory_fft
-template <bool IN_BF16, bool OUT_BF16, int MODE>
+template <int RF, bool IN_BF16, bool OUT_BF16, int MODE>
 __global__ void __launch_bounds__(512) spectre_mix_regtile_long(const RegtileArgs a) {
+  static_assert(RF % 8 == 0 && RF <= 64, "RF: multiple of 8 up to 64");
   constexpr bool GENERAL = MODE != 0, WITH_MEM = MODE == 2;
-  constexpr int N = kLongN, RF = kLongRF, RS = kLongRS, PC = kLongPC;
+  constexpr int N = RF * kLongRS, RS = kLongRS, PC = kLongPC, kLongRow2 = long_row2(RF);
+  constexpr int RAF = Split<RF>::RA, RBF = Split<RF>::RB;
   constexpr int ES_IN = IN_BF16 ? 2 : 4, ES_OUT = OUT_BF16 ? 2 : 4;
   constexpr float inv_n = 1.0f / (float)N;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -57,11 +60,13 @@ __global__ void __launch_bounds__(512) spectre_mix_regtile_long(const RegtileArg
   if constexpr (GENERAL) ca_ok = ca < a.D;
   // bin role
   const int h = tid & 1, pb = (tid >> 1) & (PC - 1), k1 = tid >> 3;
+  const bool bins = k1 < RF;                         // (RF < 64: the last threads have no bin class)
   const int cb_raw = ct * (2 * PC) + 2 * pb;
   const int cb = cb_raw < a.D ? cb_raw : 0;
 
-  auto load_twiddle_bases = [&](float2 (&wa)[8], float2 (&wb)[8]) {     // W_N^(n2 ka), W_N^(n2 8 kb)
-    static_for<1, 8>([&](auto jc) { constexpr int j = decltype(jc)::value; wa[j] = a.tw[n2 * j]; wb[j] = a.tw[n2 * 8 * j]; });
+  auto load_twiddle_bases = [&](float2 (&wa)[RAF], float2 (&wb)[RBF]) {     // W_N^(n2 ka), W_N^(n2 RAF kb)
+    static_for<1, RAF>([&](auto jc) { constexpr int j = decltype(jc)::value; wa[j] = a.tw[n2 * j]; });
+    static_for<1, RBF>([&](auto jc) { constexpr int j = decltype(jc)::value; wb[j] = a.tw[n2 * RAF * j]; });
   };
 
   float2 z[64];
@@ -70,8 +75,8 @@ __global__ void __launch_bounds__(512) spectre_mix_regtile_long(const RegtileArg
   {
     const char* vb = reinterpret_cast<const char*>(a.v) + ((size_t)b * a.v_sb + (size_t)ct * (2 * PC)) * ES_IN;
     const uint32_t voff = (uint32_t)(((long long)n2 * a.v_sn + 2 * pa) * ES_IN);
-    static_for<0, 64>([&](auto ic) {
-      constexpr int q = (decltype(ic)::value / 8) + 8 * (decltype(ic)::value % 8);
+    static_for<0, RF>([&](auto ic) {
+      constexpr int q = (decltype(ic)::value / RAF) + RBF * (decltype(ic)::value % RAF);
       const char* ptr = vb + (size_t)q * RS * a.v_sn * ES_IN + voff;
       bool ok = true;
       if constexpr (GENERAL) {
@@ -87,25 +92,25 @@ __global__ void __launch_bounds__(512) spectre_mix_regtile_long(const RegtileArg
       }
       z[q] = ok ? val : make_float2(0.f, 0.f);
     });
-    fftA<8, 8, false>(z);                              // k1 = ka + 8 kb at position 8 ka + kb
-    float2 wa[8], wb[8];
+    fft_ct<RF, false, IdentityMap, 64>(z);             // k1 at position out_pos<RF>(k1)
+    float2 wa[RAF], wb[RBF];
     load_twiddle_bases(wa, wb);
-    static_for<1, 64>([&](auto jc) {
-      constexpr int j = decltype(jc)::value, ka = j / 8, kb = j % 8;
-      if constexpr (ka > 0) z[j] = cmul(z[j], wa[ka]);
-      if constexpr (kb > 0) z[j] = cmul(z[j], wb[kb]);
+    static_for<1, RF>([&](auto kc) {
+      constexpr int kk = decltype(kc)::value, ka = kk % RAF, kb = kk / RAF, pos = out_pos<RF>(kk);
+      if constexpr (ka > 0) z[pos] = cmul(z[pos], wa[ka]);
+      if constexpr (kb > 0) z[pos] = cmul(z[pos], wb[kb]);
     });
   }
 
   // ---- E1: (n2, k1) -> bin thread (k1, h = n2 & 1), slot m = n2 >> 1; one float plane at a time --------------------
   {
     float* wbase = img + n2 * PC + pa;
-    const float* rbase = img + k1 * kLongRow1 + h * PC + pb;
-    static_for<0, 64>([&](auto jc) { constexpr int j = decltype(jc)::value; constexpr int kk = (j / 8) + 8 * (j % 8); wbase[kk * kLongRow1] = z[j].x; });
+    const float* rbase = img + (bins ? k1 : 0) * kLongRow1 + h * PC + pb;
+    static_for<0, RF>([&](auto kc) { constexpr int kk = decltype(kc)::value; wbase[kk * kLongRow1] = z[out_pos<RF>(kk)].x; });
     __syncthreads();
     static_for<0, 64>([&](auto mc) { constexpr int m = decltype(mc)::value; z[m].x = rbase[m * 2 * PC]; });   // real parts replaced first,
     __syncthreads();                                                                                            // imaginary parts still in place
-    static_for<0, 64>([&](auto jc) { constexpr int j = decltype(jc)::value; constexpr int kk = (j / 8) + 8 * (j % 8); wbase[kk * kLongRow1] = z[j].y; });
+    static_for<0, RF>([&](auto kc) { constexpr int kk = decltype(kc)::value; wbase[kk * kLongRow1] = z[out_pos<RF>(kk)].y; });
     __syncthreads();
     static_for<0, 64>([&](auto mc) { constexpr int m = decltype(mc)::value; z[m].y = rbase[m * 2 * PC]; });
     __syncthreads();
@@ -117,6 +122,7 @@ __global__ void __launch_bounds__(512) spectre_mix_regtile_long(const RegtileArg
     const float sgn = h ? -1.f : 1.f;
     const int grp = cb / a.d_g;
     const float2* gp = a.gate + ((size_t)b * a.G + grp) * a.F;
+    const int kc1 = bins ? k1 : 0;                    // threads without a bin class compute on garbage and never store it
     static_for<0, 64>([&](auto jc) {
       constexpr int j = decltype(jc)::value, k2p = (j / 8) + 8 * (j % 8);
       if constexpr (j % 8 == 0 && j > 0) __builtin_amdgcn_sched_barrier(0);   // keep the gate loads 8 deep (register budget)
@@ -128,11 +134,11 @@ __global__ void __launch_bounds__(512) spectre_mix_regtile_long(const RegtileArg
         own = make_float2(own.x * c + own.y * s, own.y * c - own.x * s);
       }
       float2 x = make_float2(fmaf(sgn, own.x, dpp_swap1(own.x)), fmaf(sgn, own.y, dpp_swap1(own.y)));
-      // bin k = k1 + 64 (k2' + 64 h): h = 1 is the upper half -> conj(g[N - k]), N - k = 64 (64 - k2') - k1
-      const int idx = h ? 64 * (64 - k2p) - k1 : k1 + 64 * k2p;
+      // bin k = k1 + RF (k2' + 64 h): h = 1 is the upper half -> conj(g[N - k]), N - k = RF (64 - k2') - k1
+      const int idx = h ? RF * (64 - k2p) - kc1 : kc1 + RF * k2p;
       float2 g = gp[idx];
       if (a.conj_gate) g.y = -g.y;
-      const bool edge = (k2p == 0) && (k1 == 0);       // DC (h = 0) and Nyquist (h = 1): irfft ignores Im
+      const bool edge = (k2p == 0) && (kc1 == 0);      // DC (h = 0) and Nyquist (h = 1): irfft ignores Im
       if (edge) g.y = 0.f;
       if (h) g.y = -g.y;
       g.x *= inv_n; g.y *= inv_n;
@@ -161,29 +167,29 @@ __global__ void __launch_bounds__(512) spectre_mix_regtile_long(const RegtileArg
   {
     float* wbase = img + h * kLongRow2 + long_sigma(k1) * PC + pb;
     const float* rbase = img + n2 * kLongRow2 + pa;
-    static_for<0, 64>([&](auto mc) { constexpr int m = decltype(mc)::value; wbase[m * 2 * kLongRow2] = z[m].x; });
+    if (bins) static_for<0, 64>([&](auto mc) { constexpr int m = decltype(mc)::value; wbase[m * 2 * kLongRow2] = z[m].x; });
     __syncthreads();
-    static_for<0, 64>([&](auto kc) { constexpr int kk = decltype(kc)::value; z[kk].x = rbase[long_sigma(kk) * PC]; });
+    static_for<0, RF>([&](auto kc) { constexpr int kk = decltype(kc)::value; z[kk].x = rbase[long_sigma(kk) * PC]; });
     __syncthreads();
-    static_for<0, 64>([&](auto mc) { constexpr int m = decltype(mc)::value; wbase[m * 2 * kLongRow2] = z[m].y; });
+    if (bins) static_for<0, 64>([&](auto mc) { constexpr int m = decltype(mc)::value; wbase[m * 2 * kLongRow2] = z[m].y; });
     __syncthreads();
-    static_for<0, 64>([&](auto kc) { constexpr int kk = decltype(kc)::value; z[kk].y = rbase[long_sigma(kk) * PC]; });
+    static_for<0, RF>([&](auto kc) { constexpr int kk = decltype(kc)::value; z[kk].y = rbase[long_sigma(kk) * PC]; });
   }
 
   // ---- conj twiddle, I2 over k1, store rows n2 + 128 n1 ----------------------------------------------------------------
   {
-    float2 wa[8], wb[8];
+    float2 wa[RAF], wb[RBF];
     load_twiddle_bases(wa, wb);
-    static_for<1, 64>([&](auto jc) {
-      constexpr int j = decltype(jc)::value, ja = j % 8, jb = j / 8;   // position j carries k1 = j = ja + 8 jb
+    static_for<1, RF>([&](auto jc) {
+      constexpr int j = decltype(jc)::value, ja = j % RAF, jb = j / RAF;   // position j carries k1 = j = ja + RAF jb
       if constexpr (ja > 0) z[j] = cmulc(z[j], wa[ja]);
       if constexpr (jb > 0) z[j] = cmulc(z[j], wb[jb]);
     });
-    fftA<8, 8, true>(z);                               // n1 = na + 8 nb at position 8 na + nb
+    fft_ct<RF, true, IdentityMap, 64>(z);              // n1 at position out_pos<RF>(n1)
     char* ob = reinterpret_cast<char*>(a.out) + ((size_t)b * a.out_sb + (size_t)ct * (2 * PC)) * ES_OUT;
     const uint32_t ooff = (uint32_t)(((long long)n2 * a.out_sn + 2 * pa) * ES_OUT);
-    static_for<0, 64>([&](auto jc) {
-      constexpr int j = decltype(jc)::value, n1 = (j / 8) + 8 * (j % 8);
+    static_for<0, RF>([&](auto nc) {
+      constexpr int n1 = decltype(nc)::value, j = out_pos<RF>(n1);
       char* ptr = ob + (size_t)n1 * RS * a.out_sn * ES_OUT + ooff;
       bool ok = true;
       if constexpr (GENERAL) ok = ca_ok && (n2 + RS * n1) < a.N_in;
@@ -195,9 +201,10 @@ __global__ void __launch_bounds__(512) spectre_mix_regtile_long(const RegtileArg
   }
 }
 
+template <int RF>
 inline hipError_t launch_regtile_long(const RegtileArgs& a, bool in_bf16, bool out_bf16, int mode, hipStream_t stream) {
   const dim3 grid(a.n_wg), block(512);
-  const size_t lds = long_image_bytes();
+  const size_t lds = long_image_bytes(RF);
   const int key = (in_bf16 ? 8 : 0) | (out_bf16 ? 4 : 0) | mode;
   static bool lds_opt_in[16][16] = {};
   auto go = [&](auto kern) -> hipError_t {
@@ -212,18 +219,18 @@ inline hipError_t launch_regtile_long(const RegtileArgs& a, bool in_bf16, bool o
     return hipGetLastError();
   };
   switch (key) {
-    case 0: return go(spectre_mix_regtile_long<false, false, 0>);
-    case 1: return go(spectre_mix_regtile_long<false, false, 1>);
-    case 2: return go(spectre_mix_regtile_long<false, false, 2>);
-    case 4: return go(spectre_mix_regtile_long<false, true, 0>);
-    case 5: return go(spectre_mix_regtile_long<false, true, 1>);
-    case 6: return go(spectre_mix_regtile_long<false, true, 2>);
-    case 8: return go(spectre_mix_regtile_long<true, false, 0>);
-    case 9: return go(spectre_mix_regtile_long<true, false, 1>);
-    case 10: return go(spectre_mix_regtile_long<true, false, 2>);
-    case 12: return go(spectre_mix_regtile_long<true, true, 0>);
-    case 13: return go(spectre_mix_regtile_long<true, true, 1>);
-    case 14: return go(spectre_mix_regtile_long<true, true, 2>);
+    case 0: return go(spectre_mix_regtile_long<RF, false, false, 0>);
+    case 1: return go(spectre_mix_regtile_long<RF, false, false, 1>);
+    case 2: return go(spectre_mix_regtile_long<RF, false, false, 2>);
+    case 4: return go(spectre_mix_regtile_long<RF, false, true, 0>);
+    case 5: return go(spectre_mix_regtile_long<RF, false, true, 1>);
+    case 6: return go(spectre_mix_regtile_long<RF, false, true, 2>);
+    case 8: return go(spectre_mix_regtile_long<RF, true, false, 0>);
+    case 9: return go(spectre_mix_regtile_long<RF, true, false, 1>);
+    case 10: return go(spectre_mix_regtile_long<RF, true, false, 2>);
+    case 12: return go(spectre_mix_regtile_long<RF, true, true, 0>);
+    case 13: return go(spectre_mix_regtile_long<RF, true, true, 1>);
+    case 14: return go(spectre_mix_regtile_long<RF, true, true, 2>);
     default: return hipErrorInvalidValue;
   }
 }

@@ -30,7 +30,10 @@ template <> hipError_t launch_regtile<32, 16>(const RegtileArgs&, bool, bool, in
 template <> hipError_t launch_regtile<32, 32>(const RegtileArgs&, bool, bool, int, hipStream_t);
 template <> hipError_t launch_regtile<64, 32>(const RegtileArgs&, bool, bool, int, hipStream_t);
 template <> hipError_t launch_regtile<64, 64>(const RegtileArgs&, bool, bool, int, hipStream_t);
-hipError_t launch_regtile_long_8192(const RegtileArgs&, bool, bool, int, hipStream_t);   // regtile_n8192.hip
+hipError_t launch_regtile_long_8192(const RegtileArgs&, bool, bool, int, hipStream_t);   // regtile_n8192.hip ... regtile_n5120.hip
+hipError_t launch_regtile_long_7168(const RegtileArgs&, bool, bool, int, hipStream_t);
+hipError_t launch_regtile_long_6144(const RegtileArgs&, bool, bool, int, hipStream_t);
+hipError_t launch_regtile_long_5120(const RegtileArgs&, bool, bool, int, hipStream_t);
 template <> hipError_t launch_regtile_mixed<60, 50>(const RegtileArgs&, bool, bool, int, hipStream_t);
 template <> hipError_t launch_regtile_mixed<32, 24>(const RegtileArgs&, bool, bool, int, hipStream_t);
 template <> hipError_t launch_regtile_mixed<48, 32>(const RegtileArgs&, bool, bool, int, hipStream_t);
@@ -94,7 +97,10 @@ const TileSize kTileSizes[] = {
     {1024, 32, 32, false, false, &sfft::launch_regtile<32, 32>, &sfft::launch_gate_grad_regtile<32, 32>},
     {2048, 64, 32, false, false, &sfft::launch_regtile<64, 32>, &sfft::launch_gate_grad_regtile<64, 32>},
     {4096, 64, 64, false, false, &sfft::launch_regtile<64, 64>, &sfft::launch_gate_grad_regtile<64, 64>},
-    {8192, 64, 128, true, false, &sfft::launch_regtile_long_8192, nullptr, 8},   // 8-channel tiles, lane-pair 128-point transform
+    {8192, 64, 128, true, false, &sfft::launch_regtile_long_8192, nullptr, 8},
+    {7168, 56, 128, true, false, &sfft::launch_regtile_long_7168, nullptr, 8},
+    {6144, 48, 128, true, false, &sfft::launch_regtile_long_6144, nullptr, 8},
+    {5120, 40, 128, true, false, &sfft::launch_regtile_long_5120, nullptr, 8},   // 8-channel tiles, lane-pair 128-point transform
     {3000, 60, 50, true, false, &sfft::launch_regtile_mixed<60, 50>, &sfft::launch_gate_grad_mixed<60, 50>},
     {768, 32, 24, true, true, &sfft::launch_regtile_mixed<32, 24>, &sfft::launch_gate_grad_mixed<32, 24>},
     {1536, 48, 32, true, true, &sfft::launch_regtile_mixed<48, 32>, &sfft::launch_gate_grad_mixed<48, 32>},

@@ -32,7 +32,7 @@ static void round_trip(float* d) {
 extern "C" int fft_engine_run(int R, int mode, float* d) {
   switch (R) {
     CASE(2) CASE(3) CASE(4) CASE(5) CASE(7) CASE(8) CASE(6) CASE(14) CASE(10) CASE(12) CASE(15) CASE(16) CASE(20) CASE(24) CASE(25)
-    CASE(30) CASE(32) CASE(40) CASE(48) CASE(50) CASE(60) CASE(64)
+    CASE(30) CASE(32) CASE(40) CASE(48) CASE(50) CASE(56) CASE(60) CASE(64)
     default: return -1;
   }
 }

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LENGTHS = [2, 3, 4, 5, 7, 8, 6, 14, 10, 12, 15, 16, 20, 24, 25, 30, 32, 40, 48, 50, 60, 64]
+LENGTHS = [2, 3, 4, 5, 7, 8, 6, 14, 10, 12, 15, 16, 20, 24, 25, 30, 32, 40, 48, 50, 56, 60, 64]
 
 
 @pytest.fixture(scope="module")

@@ -70,6 +70,9 @@ def test_native_library_is_the_thing_that_runs():
     assert "mode=3" in _describe(Vn.to(DEV), gn.to(DEV), None, 4096)
     Vn, gn, _ = _problem(0, 1, 8192, 8, 1, 8192)
     assert _describe(Vn.to(DEV), gn.to(DEV)).startswith("regtile-long 64x128 in=f32 out=f32 mode=0 tiles=1")
+    for n, tag in ((5120, "40x128"), (6144, "48x128"), (7168, "56x128")):
+        Vn, gn, _ = _problem(0, 1, n, 8, 1, n)
+        assert _describe(Vn.to(DEV), gn.to(DEV)).startswith("regtile-long " + tag)
     Vn, gn, _ = _problem(0, 1, 768, 16, 1, 768)      # secondary lengths are built for equal storage dtypes only
     assert _describe(Vn.to(DEV).bfloat16(), gn.to(DEV), out_dtype=torch.float32).startswith("stockham")
 
@@ -98,6 +101,7 @@ SHAPES = [  # (B, N, D, G, n_fft)
     (2, 1200, 32, 2, 1200), (2, 1920, 32, 2, 1920), (2, 2400, 32, 2, 2400), (1, 3600, 32, 2, 3600),   # ... incl. radix 7 (196 = 14 x 14)
     (3, 50, 48, 2, 64), (3, 150, 24, 2, 196), (2, 500, 32, 2, 384), (2, 2000, 48, 2, 2400), (1, 4000, 32, 2, 3600),
     (2, 8192, 32, 2, 8192), (2, 5000, 24, 2, 8192), (1, 9000, 12, 2, 8192), (1, 8192, 768, 4, 8192),   # 8192: lane-pair kernel
+    (2, 5120, 32, 2, 5120), (2, 6144, 24, 2, 6144), (1, 7168, 32, 2, 7168), (2, 6000, 16, 2, 6144), (1, 7000, 12, 2, 7168),   # ... RF = 40, 48, 56
     (2, 1500, 32, 4, 1500), (2, 2304, 32, 2, 2304),                                 # Stockham, smooth
     (2, 1000, 32, 2, 1024), (2, 5000, 32, 2, 4096), (1, 100, 16, 2, 128),          # pad / truncate
     (2, 97, 12, 2, 97), (2, 331, 8, 2, 331), (1, 2039, 8, 1, 2039),                # primes: Bluestein
