@@ -62,16 +62,18 @@ def test_random_vs_fp64_closed_form(shape):
     assert_close(torch.view_as_real(dg2).cpu().numpy(), torch.view_as_real(dg).cpu().numpy(), rtol=1e-5, atol_rms=1e-5)   # Stockham path: atomics, order varies
 
 
-def test_bf16_backward():
+@pytest.mark.parametrize("n", [1024, 3000, 196, 4096, 300])
+def test_bf16_backward(n):
     g = torch.Generator().manual_seed(5)
-    V = torch.randn(2, 1024, 32, generator=g).bfloat16()
-    gate = (torch.complex(torch.randn(2, 2, 513, generator=g), torch.randn(2, 2, 513, generator=g)) * 0.3).to(torch.complex64)
-    dout = torch.randn(2, 1024, 32, generator=g).bfloat16()
-    dV_ref, dg_ref = spectral_mix_backward_numpy(V.float().numpy(), gate.numpy(), dout.float().numpy(), 1024)
-    dv, dg = _bwd(V, gate, dout, 1024)
+    F = n // 2 + 1
+    V = torch.randn(2, n, 32, generator=g).bfloat16()
+    gate = (torch.complex(torch.randn(2, 2, F, generator=g), torch.randn(2, 2, F, generator=g)) * 0.3).to(torch.complex64)
+    dout = torch.randn(2, n, 32, generator=g).bfloat16()
+    dV_ref, dg_ref = spectral_mix_backward_numpy(V.float().numpy(), gate.numpy(), dout.float().numpy(), n)
+    dv, dg = _bwd(V, gate, dout, n)
     assert dv.dtype == torch.bfloat16
     assert_close(dv.float().cpu().numpy(), dV_ref, rtol=1e-2, atol_rms=1e-2, what="bf16 dV")      # bf16 storage of dV
-    assert_close(torch.view_as_real(dg).cpu().numpy(), dg_ref.astype(np.complex64).view(np.float32).reshape(2, 2, 513, 2), what="dgate")
+    assert_close(torch.view_as_real(dg).cpu().numpy(), dg_ref.astype(np.complex64).view(np.float32).reshape(2, 2, F, 2), what="dgate")
 
 
 def test_module_autograd_matches_torch_fft_autograd():
