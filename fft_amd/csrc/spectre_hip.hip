@@ -34,6 +34,10 @@ hipError_t launch_regtile_long_8192(const RegtileArgs&, bool, bool, int, hipStre
 hipError_t launch_regtile_long_7168(const RegtileArgs&, bool, bool, int, hipStream_t);
 hipError_t launch_regtile_long_6144(const RegtileArgs&, bool, bool, int, hipStream_t);
 hipError_t launch_regtile_long_5120(const RegtileArgs&, bool, bool, int, hipStream_t);
+hipError_t launch_gate_grad_long_8192(const GateGradArgs&, bool, bool, hipStream_t);
+hipError_t launch_gate_grad_long_7168(const GateGradArgs&, bool, bool, hipStream_t);
+hipError_t launch_gate_grad_long_6144(const GateGradArgs&, bool, bool, hipStream_t);
+hipError_t launch_gate_grad_long_5120(const GateGradArgs&, bool, bool, hipStream_t);
 template <> hipError_t launch_regtile_mixed<60, 50>(const RegtileArgs&, bool, bool, int, hipStream_t);
 template <> hipError_t launch_regtile_mixed<32, 24>(const RegtileArgs&, bool, bool, int, hipStream_t);
 template <> hipError_t launch_regtile_mixed<48, 32>(const RegtileArgs&, bool, bool, int, hipStream_t);
@@ -97,10 +101,10 @@ const TileSize kTileSizes[] = {
     {1024, 32, 32, false, false, &sfft::launch_regtile<32, 32>, &sfft::launch_gate_grad_regtile<32, 32>},
     {2048, 64, 32, false, false, &sfft::launch_regtile<64, 32>, &sfft::launch_gate_grad_regtile<64, 32>},
     {4096, 64, 64, false, false, &sfft::launch_regtile<64, 64>, &sfft::launch_gate_grad_regtile<64, 64>},
-    {8192, 64, 128, true, false, &sfft::launch_regtile_long_8192, nullptr, 8},
-    {7168, 56, 128, true, false, &sfft::launch_regtile_long_7168, nullptr, 8},
-    {6144, 48, 128, true, false, &sfft::launch_regtile_long_6144, nullptr, 8},
-    {5120, 40, 128, true, false, &sfft::launch_regtile_long_5120, nullptr, 8},   // 8-channel tiles, lane-pair 128-point transform
+    {8192, 64, 128, true, false, &sfft::launch_regtile_long_8192, &sfft::launch_gate_grad_long_8192, 8},
+    {7168, 56, 128, true, false, &sfft::launch_regtile_long_7168, &sfft::launch_gate_grad_long_7168, 8},
+    {6144, 48, 128, true, false, &sfft::launch_regtile_long_6144, &sfft::launch_gate_grad_long_6144, 8},
+    {5120, 40, 128, true, false, &sfft::launch_regtile_long_5120, &sfft::launch_gate_grad_long_5120, 8},   // 8-channel tiles, lane-pair 128-point transform
     {3000, 60, 50, true, false, &sfft::launch_regtile_mixed<60, 50>, &sfft::launch_gate_grad_mixed<60, 50>},
     {768, 32, 24, true, true, &sfft::launch_regtile_mixed<32, 24>, &sfft::launch_gate_grad_mixed<32, 24>},
     {1536, 48, 32, true, true, &sfft::launch_regtile_mixed<48, 32>, &sfft::launch_gate_grad_mixed<48, 32>},
@@ -560,7 +564,7 @@ int spectre_mix_bwd(const SpectreMixBwdArgs* a) {
     const int64_t n = a->n_fft, D = a->D, d_g = D / a->G_tot;
     const TileSize* ts = find_tile_size(n);
     static const bool force_stockham = [] { const char* e = getenv("SPECTRE_GATE_GRAD"); return e && !strcmp(e, "stockham"); }();
-    if (ts && ts->grad && !force_stockham && a->v_sn * 64 * 4 < ((int64_t)1 << 31) && a->dout_sn * 64 * 4 < ((int64_t)1 << 31) &&
+    if (ts && ts->grad && !force_stockham && a->v_sn * 128 * 4 < ((int64_t)1 << 31) && a->dout_sn * 128 * 4 < ((int64_t)1 << 31) &&
         a->B * a->G_tot * 8 < ((int64_t)1 << 31)) {
       // register-tile gate gradient (kernel_regtile_grad.h / kernel_regtile_mixed_grad.h): 8-channel tiles, S workgroups
       // per (batch, group)
@@ -568,12 +572,13 @@ int spectre_mix_bwd(const SpectreMixBwdArgs* a) {
       k.v = a->v; k.dout = a->dout; k.part = reinterpret_cast<float2*>(a->workspace); k.tw = plan->tw_n;
       k.B = (int)a->B; k.N_in = (int)std::min<int64_t>(a->N_in, (int64_t)1 << 30); k.D = (int)D; k.G = (int)a->G_tot;
       k.d_g = (int)d_g; k.F = (int)(n / 2 + 1);
-      k.T = (int)((d_g + 7) / 8);
-      int S = std::min(k.T, 4);
+      const int gch = ts->tile_ch == 8 ? 4 : 8;       // channels per gradient tile (one per lane p)
+      k.T = (int)((d_g + gch - 1) / gch);
+      int S = std::min(k.T, gch == 4 ? 8 : 4);        // the tiles of one 128-byte line go to neighbouring workgroups
       while (a->B * a->G_tot * S < 1024 && 2 * S <= std::min(k.T, 8)) S *= 2;
       k.S = S; k.n_wg = (int)(a->B * a->G_tot * S);
       k.v_sb = a->v_sb; k.v_sn = a->v_sn; k.dout_sb = a->dout_sb; k.dout_sn = a->dout_sn;
-      const bool bf = a->io_dtype == SPECTRE_BF16, general = (a->N_in < n) || (d_g % 8 != 0);
+      const bool bf = a->io_dtype == SPECTRE_BF16, general = (a->N_in < n) || (d_g % gch != 0);
       hipError_t e = ts->grad(k, bf, general, stream);
       if (e != hipSuccess) return fail(SPECTRE_E_HIP, "gate-gradient launch failed: %s", hipGetErrorString(e));
       const int64_t total = a->B * a->G_tot * (n / 2 + 1);
