@@ -34,6 +34,10 @@ hipError_t launch_regtile_long_8192(const RegtileArgs&, bool, bool, int, hipStre
 hipError_t launch_regtile_long_7168(const RegtileArgs&, bool, bool, int, hipStream_t);
 hipError_t launch_regtile_long_6144(const RegtileArgs&, bool, bool, int, hipStream_t);
 hipError_t launch_regtile_long_5120(const RegtileArgs&, bool, bool, int, hipStream_t);
+hipError_t launch_regtile_quad_16384(const RegtileArgs&, bool, bool, int, hipStream_t);   // regtile_n16384.hip ... regtile_n10240.hip
+hipError_t launch_regtile_quad_14336(const RegtileArgs&, bool, bool, int, hipStream_t);
+hipError_t launch_regtile_quad_12288(const RegtileArgs&, bool, bool, int, hipStream_t);
+hipError_t launch_regtile_quad_10240(const RegtileArgs&, bool, bool, int, hipStream_t);
 hipError_t launch_gate_grad_long_8192(const GateGradArgs&, bool, bool, hipStream_t);
 hipError_t launch_gate_grad_long_7168(const GateGradArgs&, bool, bool, hipStream_t);
 hipError_t launch_gate_grad_long_6144(const GateGradArgs&, bool, bool, hipStream_t);
@@ -93,7 +97,7 @@ struct TileSize {
   bool same_dtype;   // built for f32->f32 and bf16->bf16 only
   TileLauncher launch;
   GradLauncher grad;
-  int tile_ch = 16;  // channels per tile (8 for the long kernel)   // register-resident gate gradient, or nullptr (LDS Stockham path)
+  int tile_ch = 16;  // channels per tile (8 for the lane-pair kernels, 4 for the lane-quad kernels)   // register-resident gate gradient, or nullptr (LDS Stockham path)
 };
 const TileSize kTileSizes[] = {
     {256, 16, 16, false, false, &sfft::launch_regtile<16, 16>, &sfft::launch_gate_grad_regtile<16, 16>},
@@ -101,6 +105,10 @@ const TileSize kTileSizes[] = {
     {1024, 32, 32, false, false, &sfft::launch_regtile<32, 32>, &sfft::launch_gate_grad_regtile<32, 32>},
     {2048, 64, 32, false, false, &sfft::launch_regtile<64, 32>, &sfft::launch_gate_grad_regtile<64, 32>},
     {4096, 64, 64, false, false, &sfft::launch_regtile<64, 64>, &sfft::launch_gate_grad_regtile<64, 64>},
+    {16384, 64, 256, true, true, &sfft::launch_regtile_quad_16384, nullptr, 4},   // 4-channel tiles, lane-quad 256-point transform
+    {14336, 56, 256, true, true, &sfft::launch_regtile_quad_14336, nullptr, 4},
+    {12288, 48, 256, true, true, &sfft::launch_regtile_quad_12288, nullptr, 4},
+    {10240, 40, 256, true, true, &sfft::launch_regtile_quad_10240, nullptr, 4},
     {8192, 64, 128, true, false, &sfft::launch_regtile_long_8192, &sfft::launch_gate_grad_long_8192, 8},
     {7168, 56, 128, true, false, &sfft::launch_regtile_long_7168, &sfft::launch_gate_grad_long_7168, 8},
     {6144, 48, 128, true, false, &sfft::launch_regtile_long_6144, &sfft::launch_gate_grad_long_6144, 8},
@@ -311,8 +319,8 @@ int choose(const SpectreMixArgs* a, const Plan* plan, Choice* c) {
   else if ((reinterpret_cast<uintptr_t>(a->out) % (2 * es_out)) || (a->out_sn % 2) || (a->out_sb % 2)) why = "out not pair-aligned";
   else if (a->mem && (reinterpret_cast<uintptr_t>(a->mem) % 16)) why = "mem not 16-byte aligned";
   else if (reinterpret_cast<uintptr_t>(a->gate) % 8) why = "gate not 8-byte aligned";
-  else if (a->v_sn * 127 * 4 + 64 >= ((int64_t)1 << 31) || a->out_sn * 127 * 4 + 64 >= ((int64_t)1 << 31)) why = "row stride too large";
-  else if (a->B * ((D + 7) / 8) >= ((int64_t)1 << 31)) why = "too many tiles";
+  else if (a->v_sn * 255 * 4 + 64 >= ((int64_t)1 << 31) || a->out_sn * 255 * 4 + 64 >= ((int64_t)1 << 31)) why = "row stride too large";
+  else if (a->B * ((D + 3) / 4) >= ((int64_t)1 << 31)) why = "too many tiles";
   c->why_not_regtile = why;
   const bool can_regtile = why[0] == 0;
   if (a->algo == SPECTRE_ALGO_REGTILE && !can_regtile)
@@ -321,7 +329,7 @@ int choose(const SpectreMixArgs* a, const Plan* plan, Choice* c) {
   if (can_regtile && a->algo != SPECTRE_ALGO_STOCKHAM) {
     c->regtile = true;
     c->tile = ts; c->RF = ts->RF; c->RS = ts->RS;
-    if (ts->tile_ch == 8) c->mode = a->mem ? 2 : ((a->N_in < a->n_fft) || (D % 8 != 0)) ? 1 : 0;   // gate always from global
+    if (ts->tile_ch < 16) c->mode = a->mem ? 2 : ((a->N_in < a->n_fft) || (D % ts->tile_ch != 0)) ? 1 : 0;   // gate always from global
     else if (!ts->mixed) c->mode = (d_g % 16 != 0) ? (a->mem ? 2 : 1) : a->mem ? 4 : (a->N_in < a->n_fft) ? 3 : 0;   // 3, 4: gate still in LDS
     else c->mode = a->mem ? 2 : (d_g % 16 != 0) ? 1 : (a->N_in < a->n_fft) ? 3 : 0;
     return SPECTRE_OK;
@@ -479,7 +487,7 @@ int spectre_mix_describe(const SpectreMixArgs* a, char* buf, size_t cap) {
   const char* in = a->in_dtype == SPECTRE_BF16 ? "bf16" : "f32";
   const char* out = a->out_dtype == SPECTRE_BF16 ? "bf16" : "f32";
   if (c.regtile) {
-    snprintf(buf, cap, "regtile%s %dx%d in=%s out=%s mode=%d tiles=%lld", c.tile->tile_ch == 8 ? "-long" : c.tile->mixed ? "-mixed" : "", c.RF, c.RS,
+    snprintf(buf, cap, "regtile%s %dx%d in=%s out=%s mode=%d tiles=%lld", c.tile->tile_ch == 4 ? "-quad" : c.tile->tile_ch == 8 ? "-long" : c.tile->mixed ? "-mixed" : "", c.RF, c.RS,
              in, out, c.mode, (long long)(a->B * ((a->D + c.tile->tile_ch - 1) / c.tile->tile_ch)));
   } else {
     std::string r;

@@ -70,6 +70,9 @@ def test_native_library_is_the_thing_that_runs():
     assert "mode=3" in _describe(Vn.to(DEV), gn.to(DEV), None, 4096)
     Vn, gn, _ = _problem(0, 1, 8192, 8, 1, 8192)
     assert _describe(Vn.to(DEV), gn.to(DEV)).startswith("regtile-long 64x128 in=f32 out=f32 mode=0 tiles=1")
+    for n, tag in ((16384, "64x256"), (12288, "48x256")):
+        Vn, gn, _ = _problem(0, 1, n, 4, 1, n)
+        assert _describe(Vn.to(DEV), gn.to(DEV)).startswith("regtile-quad " + tag)
     for n, tag in ((5120, "40x128"), (6144, "48x128"), (7168, "56x128")):
         Vn, gn, _ = _problem(0, 1, n, 8, 1, n)
         assert _describe(Vn.to(DEV), gn.to(DEV)).startswith("regtile-long " + tag)
@@ -102,12 +105,13 @@ SHAPES = [  # (B, N, D, G, n_fft)
     (3, 50, 48, 2, 64), (3, 150, 24, 2, 196), (2, 500, 32, 2, 384), (2, 2000, 48, 2, 2400), (1, 4000, 32, 2, 3600),
     (2, 8192, 32, 2, 8192), (2, 5000, 24, 2, 8192), (1, 9000, 12, 2, 8192), (1, 8192, 768, 4, 8192),   # 8192: lane-pair kernel
     (2, 5120, 32, 2, 5120), (2, 6144, 24, 2, 6144), (1, 7168, 32, 2, 7168), (2, 6000, 16, 2, 6144), (1, 7000, 12, 2, 7168),   # ... RF = 40, 48, 56
+    (1, 16384, 16, 2, 16384), (2, 12288, 8, 2, 12288), (1, 14336, 12, 2, 14336), (1, 10240, 8, 1, 10240), (1, 12000, 6, 1, 16384),   # lane-quad kernels
     (2, 1500, 32, 4, 1500), (2, 2304, 32, 2, 2304),                                 # Stockham, smooth
     (2, 1000, 32, 2, 1024), (2, 5000, 32, 2, 4096), (1, 100, 16, 2, 128),          # pad / truncate
     (2, 97, 12, 2, 97), (2, 331, 8, 2, 331), (1, 2039, 8, 1, 2039),                # primes: Bluestein
     (2, 60, 6, 2, 60), (2, 64, 10, 2, 64), (2, 256, 24, 8, 256),                   # odd d_g (solo): Stockham
     (2, 4096, 24, 2, 4096), (2, 3000, 40, 2, 3000), (3, 1024, 8, 2, 1024), (2, 256, 100, 2, 256), (2, 200, 36, 6, 196),   # ragged last tile (D % 16 != 0)
-    (1, 8192, 8, 2, 8192), (1, 6000, 8, 2, 6000), (1, 16384, 4, 1, 16384), (1, 10000, 4, 2, 10000), (1, 5003, 4, 1, 5003), (2, 1, 4, 2, 1), (2, 2, 4, 2, 2), (2, 3, 4, 1, 3),
+    (1, 8192, 8, 2, 8192), (1, 6000, 8, 2, 6000), (1, 16384, 4, 1, 16384), (1, 10000, 4, 2, 10000), (1, 9216, 4, 2, 9216), (1, 5003, 4, 1, 5003), (2, 1, 4, 2, 1), (2, 2, 4, 2, 2), (2, 3, 4, 1, 3),
 ]
 
 
@@ -253,7 +257,7 @@ def test_full_size_properties(B, N, D, G, dt):
         assert_close(y1[idx_b][:, :, c:c + 1].cpu().numpy(), ref, what=f"column {c}")
 
 
-@pytest.mark.parametrize("n_fft", [4096, 3000, 1024, 300, 97, 8192])
+@pytest.mark.parametrize("n_fft", [4096, 3000, 1024, 300, 97, 8192, 16384])
 def test_in_place_is_allowed(n_fft):
     """A workgroup reads every row of its channel tile before it writes any, and tiles are disjoint: out may alias V."""
     from fft_amd import spectral_mix
