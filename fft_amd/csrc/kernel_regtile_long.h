@@ -79,9 +79,9 @@ __global__ void __launch_bounds__(512) spectre_mix_regtile_long(const RegtileArg
       constexpr int q = (decltype(ic)::value / RAF) + RBF * (decltype(ic)::value % RAF);
       const char* ptr = vb + (size_t)q * RS * a.v_sn * ES_IN + voff;
       bool ok = true;
-      if constexpr (GENERAL) {
+      if constexpr (GENERAL) {                       // uniform base + 32-bit lane offset (one address register per load, not two)
         ok = ca_ok && (n2 + RS * q) < a.N_in;
-        ptr = ok ? ptr : vb;
+        ptr = vb + (ok ? (uint32_t)((uint32_t)(q * RS) * (uint32_t)a.v_sn * ES_IN + voff) : 0u);
       }
       float2 val;
       if constexpr (IN_BF16) {
@@ -90,7 +90,14 @@ __global__ void __launch_bounds__(512) spectre_mix_regtile_long(const RegtileArg
       } else {
         val = *reinterpret_cast<const float2*>(ptr);
       }
-      z[q] = ok ? val : make_float2(0.f, 0.f);
+      if constexpr (GENERAL) {
+        // rows beyond N_in read as zero: AND with an all-ones / zero mask, not `ok ? val : 0` — a select whose only other
+        // operand is a load gets turned into a branch around the load (64 branches, values parked in scratch)
+        const uint32_t keep = ok ? 0xffffffffu : 0u;
+        z[q] = make_float2(__uint_as_float(__float_as_uint(val.x) & keep), __uint_as_float(__float_as_uint(val.y) & keep));
+      } else {
+        z[q] = val;
+      }
     });
     fft_ct<RF, false, IdentityMap, 64>(z);             // k1 at position out_pos<RF>(k1)
     float2 wa[RAF], wb[RBF];
@@ -121,11 +128,20 @@ __global__ void __launch_bounds__(512) spectre_mix_regtile_long(const RegtileArg
     fftA<8, 8, false>(z);                              // E_h[k2'], k2' = ka + 8 kb at position 8 ka + kb
     const float sgn = h ? -1.f : 1.f;
     const int grp = cb / a.d_g;
-    const float2* gp = a.gate + ((size_t)b * a.G + grp) * a.F;
+    const float2* gp = a.gate + (size_t)b * a.G * a.F;   // workgroup-uniform base + 32-bit lane offset
     const int kc1 = bins ? k1 : 0;                    // threads without a bin class compute on garbage and never store it
+    // bin k = k1 + RF (k2' + 64 h): h = 1 is the upper half -> conj(g[N - k]), N - k = RF (64 - k2') - k1: base + step * k2'.
+    // The opaque copies below make every group of 8 bins compute its indices when it needs them: left alone, instruction
+    // selection evaluates all 64 up front and keeps them in 64 registers.
+    int mbase = h ? RF * 64 - kc1 : kc1;
+    int gstep = h ? -RF : RF;
+    int gbase = grp * a.F + mbase;
     static_for<0, 64>([&](auto jc) {
       constexpr int j = decltype(jc)::value, k2p = (j / 8) + 8 * (j % 8);
-      if constexpr (j % 8 == 0 && j > 0) __builtin_amdgcn_sched_barrier(0);   // keep the gate loads 8 deep (register budget)
+      if constexpr (j % 8 == 0 && j > 0) {
+        asm volatile("" : "+v"(gbase), "+v"(gstep), "+v"(mbase));
+        __builtin_amdgcn_sched_barrier(0);             // keep the gate loads 8 deep (register budget)
+      }
       // h = 1 first applies W_128^k2' to its half; then X = partner + sgn * own  (E_0 + W E_1 | E_0 - W E_1)
       constexpr float wc = (float)TwTab<128>::c[k2p], ws = (float)TwTab<128>::s[k2p];
       float2 own = z[j];
@@ -134,9 +150,7 @@ __global__ void __launch_bounds__(512) spectre_mix_regtile_long(const RegtileArg
         own = make_float2(own.x * c + own.y * s, own.y * c - own.x * s);
       }
       float2 x = make_float2(fmaf(sgn, own.x, dpp_swap1(own.x)), fmaf(sgn, own.y, dpp_swap1(own.y)));
-      // bin k = k1 + RF (k2' + 64 h): h = 1 is the upper half -> conj(g[N - k]), N - k = RF (64 - k2') - k1
-      const int idx = h ? RF * (64 - k2p) - kc1 : kc1 + RF * k2p;
-      float2 g = gp[idx];
+      float2 g = gp[gbase + gstep * k2p];
       if (a.conj_gate) g.y = -g.y;
       const bool edge = (k2p == 0) && (kc1 == 0);      // DC (h = 0) and Nyquist (h = 1): irfft ignores Im
       if (edge) g.y = 0.f;
@@ -144,7 +158,7 @@ __global__ void __launch_bounds__(512) spectre_mix_regtile_long(const RegtileArg
       g.x *= inv_n; g.y *= inv_n;
       float2 y = cmul(x, g);
       if constexpr (WITH_MEM) {                         // spectre.py:548-549
-        const float4 m = *reinterpret_cast<const float4*>(a.mem + ((size_t)idx * a.D + cb) * 2);
+        const float4 m = *reinterpret_cast<const float4*>(a.mem + ((size_t)(mbase + gstep * k2p) * a.D + cb) * 2);
         float2 add;
         if (edge)   add = make_float2(m.x, m.z);
         else if (h) add = make_float2(m.x + m.w, m.z - m.y);
@@ -188,11 +202,13 @@ __global__ void __launch_bounds__(512) spectre_mix_regtile_long(const RegtileArg
     fft_ct<RF, true, IdentityMap, 64>(z);              // n1 at position out_pos<RF>(n1)
     char* ob = reinterpret_cast<char*>(a.out) + ((size_t)b * a.out_sb + (size_t)ct * (2 * PC)) * ES_OUT;
     const uint32_t ooff = (uint32_t)(((long long)n2 * a.out_sn + 2 * pa) * ES_OUT);
+    int n_rows = a.N_in, n2s = n2;                      // opaque copies: otherwise the 64 row indices / predicates of the load phase
+    asm volatile("" : "+s"(n_rows), "+v"(n2s));        // are kept alive (in scratch) across the whole kernel to be reused here
     static_for<0, RF>([&](auto nc) {
       constexpr int n1 = decltype(nc)::value, j = out_pos<RF>(n1);
       char* ptr = ob + (size_t)n1 * RS * a.out_sn * ES_OUT + ooff;
       bool ok = true;
-      if constexpr (GENERAL) ok = ca_ok && (n2 + RS * n1) < a.N_in;
+      if constexpr (GENERAL) ok = ca_ok && (n2s + RS * n1) < n_rows;
       if (ok) {
         if constexpr (OUT_BF16) *reinterpret_cast<uint32_t*>(ptr) = f32_to_bf16_rne(z[j].x) | (f32_to_bf16_rne(z[j].y) << 16);
         else *reinterpret_cast<float2*>(ptr) = z[j];

@@ -137,17 +137,21 @@ __global__ void __launch_bounds__(512) spectre_gate_grad_regtile_long(const Gate
     {
       // partner of (k1, k2') with k2' < 64: row RF - k1 (0 for k1 = 0), slot 63 - k2' (64 - k2' for k1 = 0; k2' = 0 is DC, its own partner)
       const float* rre = img + (k1z ? 0 : RF - k1c) * RW + pb * PS + (k1z ? 64 : 63);
+      int roff = 0;                                   // opaque per group of 8: keeps the 64 partner addresses from being formed up front
       static_for<0, 64>([&](auto jc) {
         constexpr int j = decltype(jc)::value, k2p = (j / 8) + 8 * (j % 8);
-        if constexpr (j % 8 == 0 && j > 0) __builtin_amdgcn_sched_barrier(0);   // partner reads 8 deep (register budget)
+        if constexpr (j % 8 == 0 && j > 0) {
+          asm volatile("" : "+v"(roff));
+          __builtin_amdgcn_sched_barrier(0);           // partner reads 8 deep (register budget)
+        }
         float pr, pi;
         if constexpr (k2p == 0) {
           const float* r0 = img + (k1z ? 0 : RF - k1c) * RW + pb * PS + (k1z ? 0 : 63);
           pr = k1z ? z[j].x : r0[0];
           pi = k1z ? z[j].y : r0[PLANE];
         } else {
-          pr = rre[-k2p];
-          pi = rre[PLANE - k2p];
+          pr = rre[roff - k2p];
+          pi = rre[roff + PLANE - k2p];
         }
         float sr = 0.5f * (z[j].x * pi + z[j].y * pr);                                         // Im(A A') / 2
         float si = -0.25f * ((z[j].x * z[j].x + z[j].y * z[j].y) - (pr * pr + pi * pi));       // -(|A|^2 - |A'|^2) / 4

@@ -80,9 +80,9 @@ __global__ void __launch_bounds__(512) spectre_mix_regtile_quad(const RegtileArg
       constexpr int q = (decltype(ic)::value / RAF) + RBF * (decltype(ic)::value % RAF);
       const char* ptr = vb + (size_t)q * RS * a.v_sn * ES_IN + voff;
       bool ok = true;
-      if constexpr (GENERAL) {
+      if constexpr (GENERAL) {                       // uniform base + 32-bit lane offset (one address register per load, not two)
         ok = ca_ok && (n2 + RS * q) < a.N_in;
-        ptr = ok ? ptr : vb;
+        ptr = vb + (ok ? (uint32_t)((uint32_t)(q * RS) * (uint32_t)a.v_sn * ES_IN + voff) : 0u);
       }
       float2 val;
       if constexpr (IN_BF16) {
@@ -91,7 +91,14 @@ __global__ void __launch_bounds__(512) spectre_mix_regtile_quad(const RegtileArg
       } else {
         val = *reinterpret_cast<const float2*>(ptr);
       }
-      z[q] = ok ? val : make_float2(0.f, 0.f);
+      if constexpr (GENERAL) {
+        // rows beyond N_in read as zero: AND with an all-ones / zero mask, not `ok ? val : 0` — a select whose only other
+        // operand is a load gets turned into a branch around the load (64 branches, values parked in scratch)
+        const uint32_t keep = ok ? 0xffffffffu : 0u;
+        z[q] = make_float2(__uint_as_float(__float_as_uint(val.x) & keep), __uint_as_float(__float_as_uint(val.y) & keep));
+      } else {
+        z[q] = val;
+      }
     });
     fft_ct<RF, false, IdentityMap, 64>(z);
     float2 wa[RAF], wb[RBF];
@@ -203,11 +210,13 @@ __global__ void __launch_bounds__(512) spectre_mix_regtile_quad(const RegtileArg
     fft_ct<RF, true, IdentityMap, 64>(z);
     char* ob = reinterpret_cast<char*>(a.out) + ((size_t)b * a.out_sb + (size_t)ct * (2 * PC)) * ES_OUT;
     const uint32_t ooff = (uint32_t)(((long long)n2 * a.out_sn + 2 * pa) * ES_OUT);
+    int n_rows = a.N_in, n2s = n2;                      // opaque copies: otherwise the 64 row indices / predicates of the load phase
+    asm volatile("" : "+s"(n_rows), "+v"(n2s));        // are kept alive (in scratch) across the whole kernel to be reused here
     static_for<0, RF>([&](auto nc) {
       constexpr int n1 = decltype(nc)::value, j = out_pos<RF>(n1);
       char* ptr = ob + (size_t)n1 * RS * a.out_sn * ES_OUT + ooff;
       bool ok = true;
-      if constexpr (GENERAL) ok = ca_ok && (n2 + RS * n1) < a.N_in;
+      if constexpr (GENERAL) ok = ca_ok && (n2s + RS * n1) < n_rows;
       if (ok) {
         if constexpr (OUT_BF16) *reinterpret_cast<uint32_t*>(ptr) = f32_to_bf16_rne(z[j].x) | (f32_to_bf16_rne(z[j].y) << 16);
         else *reinterpret_cast<float2*>(ptr) = z[j];
