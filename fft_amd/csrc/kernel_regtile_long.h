@@ -1,5 +1,5 @@
 // kernel_regtile_long.h — register-resident spectral mix for n_fft = RF x 128, RF in {40, 48, 56, 64}
-// (5120, 6144, 7168, 8192) on gfx950.
+// (5120, 6144, 7168, 8192; the library builds 6144 and 8192) on gfx950.
 //
 // Same plan as kernel_regtile.h (which see: /root/reference/spectre.py:506, :542-553 in one kernel, two real channels
 // per complex sequence, LDS only as the transposition buffer), with two changes forced by the length:
@@ -239,11 +239,7 @@ inline hipError_t launch_regtile_long(const RegtileArgs& a, bool in_bf16, bool o
     case 1: return go(spectre_mix_regtile_long<RF, false, false, 1>);
     case 2: return go(spectre_mix_regtile_long<RF, false, false, 2>);
     case 4: return go(spectre_mix_regtile_long<RF, false, true, 0>);
-    case 5: return go(spectre_mix_regtile_long<RF, false, true, 1>);
-    case 6: return go(spectre_mix_regtile_long<RF, false, true, 2>);
     case 8: return go(spectre_mix_regtile_long<RF, true, false, 0>);
-    case 9: return go(spectre_mix_regtile_long<RF, true, false, 1>);
-    case 10: return go(spectre_mix_regtile_long<RF, true, false, 2>);
     case 12: return go(spectre_mix_regtile_long<RF, true, true, 0>);
     case 13: return go(spectre_mix_regtile_long<RF, true, true, 1>);
     case 14: return go(spectre_mix_regtile_long<RF, true, true, 2>);

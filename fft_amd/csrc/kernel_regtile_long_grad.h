@@ -1,4 +1,4 @@
-// kernel_regtile_long_grad.h — register-resident gate gradient for n_fft = RF x 128 (5120 ... 8192).
+// kernel_regtile_long_grad.h — register-resident gate gradient for n_fft = RF x 128 (6144, 8192).
 //
 // Mathematics and work split of kernel_regtile_grad.h (one packed transform per channel, z = x_c + i dOut_c;
 // conj(X[k]) R[k] = Im(A[k] A[N-k]) / 2 - i (|A[k]|^2 - |A[N-k]|^2) / 4; S workgroups per (batch, group); deterministic

@@ -214,13 +214,7 @@ hipError_t launch_regtile_mixed(const RegtileArgs& a, bool in_bf16, bool out_bf1
       case 2: return go(spectre_mix_regtile_mixed<RF_, RS_, false, false, 2>);                               \
       case 3: return go(spectre_mix_regtile_mixed<RF_, RS_, false, false, 3>);                               \
       case 4: return go(spectre_mix_regtile_mixed<RF_, RS_, false, true, 0>);                                \
-      case 5: return go(spectre_mix_regtile_mixed<RF_, RS_, false, true, 1>);                                \
-      case 6: return go(spectre_mix_regtile_mixed<RF_, RS_, false, true, 2>);                                \
-      case 7: return go(spectre_mix_regtile_mixed<RF_, RS_, false, true, 3>);                                \
       case 8: return go(spectre_mix_regtile_mixed<RF_, RS_, true, false, 0>);                                \
-      case 9: return go(spectre_mix_regtile_mixed<RF_, RS_, true, false, 1>);                                \
-      case 10: return go(spectre_mix_regtile_mixed<RF_, RS_, true, false, 2>);                               \
-      case 11: return go(spectre_mix_regtile_mixed<RF_, RS_, true, false, 3>);                               \
       case 12: return go(spectre_mix_regtile_mixed<RF_, RS_, true, true, 0>);                                \
       case 13: return go(spectre_mix_regtile_mixed<RF_, RS_, true, true, 1>);                                \
       case 14: return go(spectre_mix_regtile_mixed<RF_, RS_, true, true, 2>);                                \

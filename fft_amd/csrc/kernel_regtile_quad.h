@@ -1,5 +1,5 @@
 // kernel_regtile_quad.h — register-resident spectral mix for n_fft = RF x 256, RF in {40, 48, 56, 64}
-// (10240, 12288, 14336, 16384) on gfx950.
+// (10240, 12288, 14336, 16384; the library builds 12288 and 16384) on gfx950.
 //
 // kernel_regtile_long.h taken one step further: a tile is 4 channels (2 packed sequences, 16-byte fp32 row segments; the
 // eight tiles of a 128-byte line are neighbours in the XCD-contiguous order) x n_fft rows — again 256 KiB of registers at

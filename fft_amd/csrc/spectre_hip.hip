@@ -30,18 +30,12 @@ template <> hipError_t launch_regtile<32, 16>(const RegtileArgs&, bool, bool, in
 template <> hipError_t launch_regtile<32, 32>(const RegtileArgs&, bool, bool, int, hipStream_t);
 template <> hipError_t launch_regtile<64, 32>(const RegtileArgs&, bool, bool, int, hipStream_t);
 template <> hipError_t launch_regtile<64, 64>(const RegtileArgs&, bool, bool, int, hipStream_t);
-hipError_t launch_regtile_long_8192(const RegtileArgs&, bool, bool, int, hipStream_t);   // regtile_n8192.hip ... regtile_n5120.hip
-hipError_t launch_regtile_long_7168(const RegtileArgs&, bool, bool, int, hipStream_t);
+hipError_t launch_regtile_long_8192(const RegtileArgs&, bool, bool, int, hipStream_t);   // regtile_n8192.hip, regtile_n6144.hip
 hipError_t launch_regtile_long_6144(const RegtileArgs&, bool, bool, int, hipStream_t);
-hipError_t launch_regtile_long_5120(const RegtileArgs&, bool, bool, int, hipStream_t);
-hipError_t launch_regtile_quad_16384(const RegtileArgs&, bool, bool, int, hipStream_t);   // regtile_n16384.hip ... regtile_n10240.hip
-hipError_t launch_regtile_quad_14336(const RegtileArgs&, bool, bool, int, hipStream_t);
+hipError_t launch_regtile_quad_16384(const RegtileArgs&, bool, bool, int, hipStream_t);   // regtile_n16384.hip, regtile_n12288.hip
 hipError_t launch_regtile_quad_12288(const RegtileArgs&, bool, bool, int, hipStream_t);
-hipError_t launch_regtile_quad_10240(const RegtileArgs&, bool, bool, int, hipStream_t);
 hipError_t launch_gate_grad_long_8192(const GateGradArgs&, bool, bool, hipStream_t);
-hipError_t launch_gate_grad_long_7168(const GateGradArgs&, bool, bool, hipStream_t);
 hipError_t launch_gate_grad_long_6144(const GateGradArgs&, bool, bool, hipStream_t);
-hipError_t launch_gate_grad_long_5120(const GateGradArgs&, bool, bool, hipStream_t);
 template <> hipError_t launch_regtile_mixed<60, 50>(const RegtileArgs&, bool, bool, int, hipStream_t);
 template <> hipError_t launch_regtile_mixed<32, 24>(const RegtileArgs&, bool, bool, int, hipStream_t);
 template <> hipError_t launch_regtile_mixed<48, 32>(const RegtileArgs&, bool, bool, int, hipStream_t);
@@ -106,13 +100,9 @@ const TileSize kTileSizes[] = {
     {2048, 64, 32, false, false, &sfft::launch_regtile<64, 32>, &sfft::launch_gate_grad_regtile<64, 32>},
     {4096, 64, 64, false, false, &sfft::launch_regtile<64, 64>, &sfft::launch_gate_grad_regtile<64, 64>},
     {16384, 64, 256, true, true, &sfft::launch_regtile_quad_16384, nullptr, 4},   // 4-channel tiles, lane-quad 256-point transform
-    {14336, 56, 256, true, true, &sfft::launch_regtile_quad_14336, nullptr, 4},
     {12288, 48, 256, true, true, &sfft::launch_regtile_quad_12288, nullptr, 4},
-    {10240, 40, 256, true, true, &sfft::launch_regtile_quad_10240, nullptr, 4},
     {8192, 64, 128, true, false, &sfft::launch_regtile_long_8192, &sfft::launch_gate_grad_long_8192, 8},
-    {7168, 56, 128, true, false, &sfft::launch_regtile_long_7168, &sfft::launch_gate_grad_long_7168, 8},
     {6144, 48, 128, true, false, &sfft::launch_regtile_long_6144, &sfft::launch_gate_grad_long_6144, 8},
-    {5120, 40, 128, true, false, &sfft::launch_regtile_long_5120, &sfft::launch_gate_grad_long_5120, 8},   // 8-channel tiles, lane-pair 128-point transform
     {3000, 60, 50, true, false, &sfft::launch_regtile_mixed<60, 50>, &sfft::launch_gate_grad_mixed<60, 50>},
     {768, 32, 24, true, true, &sfft::launch_regtile_mixed<32, 24>, &sfft::launch_gate_grad_mixed<32, 24>},
     {1536, 48, 32, true, true, &sfft::launch_regtile_mixed<48, 32>, &sfft::launch_gate_grad_mixed<48, 32>},
@@ -326,12 +316,22 @@ int choose(const SpectreMixArgs* a, const Plan* plan, Choice* c) {
   if (a->algo == SPECTRE_ALGO_REGTILE && !can_regtile)
     return fail(why[0] == 'v' || why[0] == 'o' || why[0] == 'm' || why[0] == 'g' ? SPECTRE_E_ALIGN : SPECTRE_E_UNSUPPORTED,
                 "register-tile kernel not applicable: %s", why);
-  if (can_regtile && a->algo != SPECTRE_ALGO_STOCKHAM) {
+  int mode = 0;
+  if (can_regtile) {
+    if (ts->tile_ch < 16) mode = a->mem ? 2 : ((a->N_in < a->n_fft) || (D % ts->tile_ch != 0)) ? 1 : 0;   // gate always from global
+    else if (!ts->mixed) mode = (d_g % 16 != 0) ? (a->mem ? 2 : 1) : a->mem ? 4 : (a->N_in < a->n_fft) ? 3 : 0;   // 3, 4: gate still in LDS
+    else mode = a->mem ? 2 : (d_g % 16 != 0) ? 1 : (a->N_in < a->n_fft) ? 3 : 0;
+  }
+  bool can = can_regtile;
+  if (can && mode != 0 && a->in_dtype != a->out_dtype) {   // differing storage dtypes are built for the fast mode only
+    c->why_not_regtile = "storage dtypes differ (built for the fast mode only)";
+    can = false;
+    if (a->algo == SPECTRE_ALGO_REGTILE) return fail(SPECTRE_E_UNSUPPORTED, "register-tile kernel not applicable: %s", c->why_not_regtile);
+  }
+  if (can && a->algo != SPECTRE_ALGO_STOCKHAM) {
     c->regtile = true;
     c->tile = ts; c->RF = ts->RF; c->RS = ts->RS;
-    if (ts->tile_ch < 16) c->mode = a->mem ? 2 : ((a->N_in < a->n_fft) || (D % ts->tile_ch != 0)) ? 1 : 0;   // gate always from global
-    else if (!ts->mixed) c->mode = (d_g % 16 != 0) ? (a->mem ? 2 : 1) : a->mem ? 4 : (a->N_in < a->n_fft) ? 3 : 0;   // 3, 4: gate still in LDS
-    else c->mode = a->mem ? 2 : (d_g % 16 != 0) ? 1 : (a->N_in < a->n_fft) ? 3 : 0;
+    c->mode = mode;
     return SPECTRE_OK;
   }
   // Stockham / Bluestein in LDS: one buffer of L points per slot; P slots per workgroup, limited by the LDS and by
