@@ -10,7 +10,8 @@ shapes = [(256, 4096, 768, "f32"), (256, 4096, 768, "bf16"), (256, 1024, 768, "f
           (256, 2560, 768, "f32"), (256, 3072, 768, "f32"), (256, 3840, 768, "f32"),
           (4096, 64, 768, "f32"), (4096, 128, 768, "f32"), (2048, 196, 768, "f32"), (1024, 384, 768, "f32"), (1024, 640, 768, "f32"),
           (512, 960, 768, "f32"), (256, 1200, 768, "f32"), (256, 1920, 768, "f32"), (256, 2400, 768, "f32"), (128, 3600, 768, "f32"),
-          (64, 8192, 768, "f32"), (64, 6000, 768, "f32"), (64, 2039, 768, "f32")]
+          (64, 8192, 768, "f32"), (64, 6144, 768, "f32"), (32, 16384, 768, "f32"), (32, 12288, 768, "f32"),
+          (64, 6000, 768, "f32"), (64, 2039, 768, "f32")]
 if len(sys.argv) > 1:
     shapes = [tuple(int(x) if x.isdigit() else x for x in s.split(",")) for s in sys.argv[1:]]
 for (B, N, D, io) in shapes:
