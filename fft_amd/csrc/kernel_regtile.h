@@ -88,7 +88,7 @@ __device__ __forceinline__ uint32_t f32_to_bf16_rne(float f) {
 // every ds_read_b32 of a 32-lane group hits 32 distinct banks thanks to the 32-byte pad per row.
 // The image is free on entry: every exchange ENDS with a barrier, so the first writes can be scheduled into the
 // code that produces z[j].  Reads follow the order in which the next butterfly stage consumes them.
-template <int E, int RA, int RB, class WR, class RD>
+template <int E, int RA, int RB, bool LAST_BARRIER = true, class WR, class RD>
 __device__ __forceinline__ void exchange_planes(float2 (&z)[E], float* img, WR wr, RD rd) {
   constexpr int SUB = RA * RB;             // consumer works on sub-arrays of SUB values (E / SUB sets)
   static_for<0, E>([&](auto jc) { constexpr int j = decltype(jc)::value; img[wr(jc)] = z[j].x; });
@@ -106,7 +106,7 @@ __device__ __forceinline__ void exchange_planes(float2 (&z)[E], float* img, WR w
     constexpr int m = (i / SUB) * SUB + ((i % SUB) / RA) + RB * ((i % SUB) % RA);
     z[m].y = img[rd(std::integral_constant<int, m>{})];
   });
-  __syncthreads();                         // image free again for the next exchange
+  if constexpr (LAST_BARRIER) __syncthreads();   // image free again for the next exchange
 }
 
 // Variant with 16-byte reads: image laid out [row][column p][slot], slot fastest, every column padded by 4 floats.
@@ -114,7 +114,7 @@ __device__ __forceinline__ void exchange_planes(float2 (&z)[E], float* img, WR w
 // E/2 ds_read2_b32 (128 B/clk); the ds_write_b32 side stays conflict-free (bank = 4p + row class), as are the b128
 // reads (checked for every (RF, RS) with the lane-group table of MI355X_MICROARCH.md).  wr(j) -> float index of
 // position j; rd4(m4) -> float index of the 4 slots m4..m4+3 (16-byte aligned).
-template <int E, int RA, int RB, class WR, class RD4>
+template <int E, int RA, int RB, bool LAST_BARRIER = true, class WR, class RD4>
 __device__ __forceinline__ void exchange_planes_b128(float2 (&z)[E], float* img, WR wr, RD4 rd4) {
   constexpr int SUB = RA * RB;             // consumer works on sub-arrays of SUB values
   auto read_plane = [&](auto is_im) {
@@ -137,7 +137,7 @@ __device__ __forceinline__ void exchange_planes_b128(float2 (&z)[E], float* img,
   static_for<0, E>([&](auto jc) { constexpr int j = decltype(jc)::value; img[wr(jc)] = z[j].y; });
   __syncthreads();
   read_plane(std::true_type{});
-  __syncthreads();                         // image free again for the next exchange
+  if constexpr (LAST_BARRIER) __syncthreads();   // image free again for the next exchange
 }
 
 // MODE 0 (fast): N_in >= n_fft (no row predicates), no memory_fft, every tile inside one gate group (gate staged in LDS).
@@ -174,6 +174,7 @@ __global__ void __launch_bounds__(kPC * RS) spectre_mix_regtile(const RegtileArg
   for (int it = 0; it < a.tpw; ++it) {
   const int tile = pair_base + 2 * it;
   if (tile >= a.n_tiles) break;                  // workgroup-uniform
+  if (it > 0) __syncthreads();                   // the previous tile's last exchange left its image reads unfenced
   // Opaque per-iteration copies of the lane coordinates and row strides: otherwise LICM hoists every per-lane
   // address (twiddle table, gate offsets, 2*RF row offsets) out of the tile loop and the allocator spills them.
   int p = p0, u = u0;
@@ -357,12 +358,12 @@ __global__ void __launch_bounds__(kPC * RS) spectre_mix_regtile(const RegtileArg
   if constexpr (!NO_LDS) {
     if constexpr (XV) {
       constexpr int PS = RF + 4, RW = kPC * PS;
-      exchange_planes_b128<RF, RAF, RBF>(z, img,
+      exchange_planes_b128<RF, RAF, RBF, false>(z, img,
           [&](auto jc) { constexpr int j = decltype(jc)::value; constexpr int t = j / RS, n2 = j % RS;
                          return n2 * RW + p * PS + (u + RS * t); },
           [&](auto mc) { constexpr int m = decltype(mc)::value; return u * RW + p * PS + m; });
     } else {
-      exchange_planes<RF, RAF, RBF>(z, img,
+      exchange_planes<RF, RAF, RBF, false>(z, img,
           [&](auto jc) { constexpr int j = decltype(jc)::value; constexpr int t = j / RS, n2 = j % RS;
                          return n2 * ROW2 + (u + RS * t) * kPC + p; },
           [&](auto mc) { constexpr int m = decltype(mc)::value; return u * ROW2 + m * kPC + p; });
