@@ -267,3 +267,16 @@ def test_in_place_is_allowed(n_fft):
     spectral_mix(Vd, gate.to(DEV), None, n_fft, out=Vd)
     torch.cuda.synchronize()
     assert torch.equal(Vd, want)
+
+
+def test_differing_storage_dtypes_outside_the_fast_mode_take_the_general_path():
+    """bf16 -> f32 (or f32 -> bf16) is built into the register-tile kernels for the fast mode only; a padded sequence
+    with differing dtypes must still work (LDS Stockham path) and say so."""
+    V, gate, _ = _problem(31, 2, 1000, 32, 2, 1024, dtype=torch.bfloat16)
+    d = _describe(V.to(DEV), gate.to(DEV), None, 1024, out_dtype=torch.float32)
+    assert d.startswith("stockham") and "storage dtypes differ" in d
+    y = _mix(V.to(DEV), gate.to(DEV), None, 1024, out_dtype=torch.float32)
+    assert y.dtype == torch.float32
+    assert_close(y.cpu().numpy(), _oracle(V, gate, None, 1024), what="bf16 -> f32, padded")
+    with pytest.raises(NotImplementedError, match="storage dtypes differ"):
+        _mix(V.to(DEV), gate.to(DEV), None, 1024, out_dtype=torch.float32, algo="regtile")
