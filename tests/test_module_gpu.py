@@ -48,3 +48,24 @@ def test_mean_pooling_fold_is_the_same_layer():
         y0, q0 = head(x, return_q_pool=True)
     assert float((q1 - q0).abs().max()) <= 2e-5 * float(q0.abs().max())
     assert_close(y1.cpu().numpy(), y0.cpu().numpy(), rtol=1e-4, atol_rms=1e-4, what="folded vs unfolded")
+
+
+def test_forward_can_be_captured_in_a_graph():
+    """The library only enqueues kernels on the caller's stream: after one warm-up call (plan upload, LDS opt-in) a layer
+    forward replays from a hipGraph with identical results ("Graph capture and streams")."""
+    from fft_amd import SpectreHead
+    torch.manual_seed(2)
+    head = SpectreHead(64, 1024, num_groups=4, pooling_type="mean").to("cuda:0").eval()
+    x = torch.randn(2, 1024, 64, device="cuda:0")
+    with torch.no_grad():
+        want = head(x)                                   # warm-up: builds the plan
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            y = head(x)
+        x.copy_(torch.randn(2, 1024, 64, device="cuda:0"))
+        g.replay()
+        torch.cuda.synchronize()
+        want2 = head(x)
+    assert not torch.equal(want, want2)
+    assert torch.equal(y, want2)
