@@ -280,3 +280,24 @@ def test_differing_storage_dtypes_outside_the_fast_mode_take_the_general_path():
     assert_close(y.cpu().numpy(), _oracle(V, gate, None, 1024), what="bf16 -> f32, padded")
     with pytest.raises(NotImplementedError, match="storage dtypes differ"):
         _mix(V.to(DEV), gate.to(DEV), None, 1024, out_dtype=torch.float32, algo="regtile")
+
+
+def test_concurrent_streams():
+    """Launches are asynchronous on the caller's stream and share nothing but the read-only plan."""
+    from fft_amd import spectral_mix
+    V1, g1, _ = _problem(41, 4, 4096, 64, 4, 4096)
+    V2, g2, _ = _problem(42, 4, 3000, 64, 4, 3000)
+    V1d, g1d, V2d, g2d = V1.to(DEV), g1.to(DEV), V2.to(DEV), g2.to(DEV)
+    want1, want2 = _mix(V1d, g1d, None, 4096), _mix(V2d, g2d, None, 3000)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = []
+    for _ in range(5):
+        with torch.cuda.stream(s1):
+            a = spectral_mix(V1d, g1d, None, 4096)
+        with torch.cuda.stream(s2):
+            b = spectral_mix(V2d, g2d, None, 3000)
+        outs.append((a, b))
+    torch.cuda.synchronize()
+    for a, b in outs:
+        assert torch.equal(a, want1) and torch.equal(b, want2)
