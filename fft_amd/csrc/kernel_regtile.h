@@ -147,7 +147,8 @@ __device__ __forceinline__ void exchange_planes_b128(float2 (&z)[E], float* img,
 // ABL (ablation switches, tools/ablate_bench.hip only; 0 in the library): bit0 = no global loads/stores,
 // bit1 = no butterflies/twiddles/gate, bit2 = no LDS exchanges, bit3 = constant gate.
 template <int RF, int RS, bool IN_BF16, bool OUT_BF16, int MODE, int ABL = 0, int XV = SFFT_EXCHANGE_B128(RF, RS)>
-__global__ void __launch_bounds__(kPC * RS) spectre_mix_regtile(const RegtileArgs a) {
+__global__ void __launch_bounds__(kPC * RS, 2)   // at least two waves per SIMD (VGPR + AGPR budget 256): two 64x32 workgroups per CU
+spectre_mix_regtile(const RegtileArgs a) {
   constexpr bool GENERAL = MODE != 0, WITH_MEM = MODE == 2 || MODE == 4, GATE_LDS = MODE == 0 || MODE == 3 || MODE == 4;
   constexpr bool NO_IO = (ABL & 1) != 0, NO_MATH = (ABL & 2) != 0, NO_LDS = (ABL & 4) != 0, NO_GATE = (ABL & 8) != 0;
   static_assert(RF == RS || RF == 2 * RS, "n_fft = RS*RS or 2*RS*RS");

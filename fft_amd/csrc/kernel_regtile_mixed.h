@@ -27,8 +27,12 @@ template <int RF, int RS> constexpr int mixed_lds_total() { return mixed_image_b
 
 // MODE as in kernel_regtile.h: 0 fast (no predicates, gate staged in LDS), 1 general, 2 general + memory_fft,
 // 3 row predicates with the gate still in LDS (padded sequences)
+// Teams of up to 50 threads are held to 128 VGPRs (4 waves per SIMD): their workgroups have 4-7 waves, and two of them
+// only fit a CU together when no SIMD needs more than 4 slots; at 130-140 VGPRs (3 slots) the second workgroup usually
+// does not fit and the kernel runs one workgroup per CU.  Fast mode only: the general modes would spill ~200 registers.
 template <int RF, int RS, bool IN_BF16, bool OUT_BF16, int MODE>
-__global__ void __launch_bounds__(kPC * (RF > RS ? RF : RS)) spectre_mix_regtile_mixed(const RegtileArgs a) {
+__global__ void __launch_bounds__(kPC * (RF > RS ? RF : RS), (MODE == 0 && (RF > RS ? RF : RS) <= 50 ? 4 : 1))
+spectre_mix_regtile_mixed(const RegtileArgs a) {
   constexpr bool GENERAL = MODE != 0, WITH_MEM = MODE == 2, GATE_LDS = MODE == 0 || MODE == 3;
   constexpr int N = RF * RS, NZ = mixed_team<RF, RS>(), NT = mixed_threads<RF, RS>();
   static_assert(N % 2 == 0, "even n_fft");

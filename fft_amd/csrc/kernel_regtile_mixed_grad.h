@@ -17,7 +17,8 @@ template <int RF, int RS> constexpr int mixed_grad_image_bytes() {
 template <int RF, int RS> constexpr int mixed_grad_lds_total() { return mixed_grad_image_bytes<RF, RS>() + (RF * RS / 2 + 1) * 8; }
 
 template <int RF, int RS, bool IO_BF16, bool GENERAL>
-__global__ void __launch_bounds__(kPC * (RF > RS ? RF : RS)) spectre_gate_grad_regtile_mixed(const GateGradArgs a) {
+__global__ void __launch_bounds__(kPC * (RF > RS ? RF : RS), (!GENERAL && (RF > RS ? RF : RS) <= 50 ? 4 : 1))   // see kernel_regtile_mixed.h
+spectre_gate_grad_regtile_mixed(const GateGradArgs a) {
   static_assert(RS % 2 == 0, "the half exchange needs an even RS");
   constexpr int N = RF * RS, NZ = mixed_team<RF, RS>(), NT = mixed_threads<RF, RS>();
   constexpr int RAF = Split<RF>::RA, RBF = Split<RF>::RB;
