@@ -51,6 +51,10 @@ struct RegtileArgs {
   int tpw;              // tiles per workgroup (>= 1)
   int n_wg;             // workgroups launched = 2 * ceil(n_tiles / (2 * tpw))
   int conj_gate;        // 1: filter with conj(gate) — the adjoint w.r.t. v (dV = mix(dOut, conj(gate)))
+  unsigned long long* trace;   // tools/trace_bench.hip only (ABL bit4): 8 words per workgroup, nullptr in the library
+  int stagger_ticks, stagger_classes, stagger_first;   // first-generation phase stagger (100 MHz ticks per class), see kernel
+  unsigned* sem; int sem_k;    // load-admission semaphore per XCD (ABL bit7): [x*64] tickets issued, [x*64+32] loads completed
+  int pf_dist;                 // ABL bit8: touch the 64-B row segments of tile + pf_dist (the tile a CU of this XCD loads one generation later)
 };
 
 constexpr int kPC = 8;                       // pair-columns per tile: 16 channels, 64-byte fp32 row segments
@@ -145,12 +149,41 @@ __device__ __forceinline__ void exchange_planes_b128(float2 (&z)[E], float* img,
 // MODE 3: row predicates only (N_in < n_fft, the padded-sequence case) with the gate still staged in LDS.
 // MODE 4: MODE 3 + memory_fft.
 // ABL (ablation switches, tools/ablate_bench.hip only; 0 in the library): bit0 = no global loads/stores,
-// bit1 = no butterflies/twiddles/gate, bit2 = no LDS exchanges, bit3 = constant gate.
+// bit1 = no butterflies/twiddles/gate, bit2 = no LDS exchanges, bit3 = constant gate, bit4 = per-workgroup phase
+// timestamps (s_memrealtime, 100 MHz) into a.trace, bit5 = additionally wait for the stores' acknowledgement.
 template <int RF, int RS, bool IN_BF16, bool OUT_BF16, int MODE, int ABL = 0, int XV = SFFT_EXCHANGE_B128(RF, RS)>
 __global__ void __launch_bounds__(kPC * RS, 2)   // at least two waves per SIMD (VGPR + AGPR budget 256): two 64x32 workgroups per CU
 spectre_mix_regtile(const RegtileArgs a) {
   constexpr bool GENERAL = MODE != 0, WITH_MEM = MODE == 2 || MODE == 4, GATE_LDS = MODE == 0 || MODE == 3 || MODE == 4;
   constexpr bool NO_IO = (ABL & 1) != 0, NO_MATH = (ABL & 2) != 0, NO_LDS = (ABL & 4) != 0, NO_GATE = (ABL & 8) != 0;
+  constexpr bool TRACE = (ABL & 16) != 0, TRACE_ACK = (ABL & 32) != 0;
+  [[maybe_unused]] auto stamp = [&](int slot) {
+    if constexpr (TRACE) { if (threadIdx.x == 0) a.trace[(size_t)blockIdx.x * 8 + slot] = wall_clock64(); }
+  };
+  if constexpr (TRACE) {
+    if (threadIdx.x == 0) {
+      uint32_t hw, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      a.trace[(size_t)blockIdx.x * 8 + 7] = ((unsigned long long)xcc << 32) | hw;
+    }
+  }
+  if constexpr ((ABL & 64) != 0) {   // de-synchronise the first generation of workgroups (pairs of neighbouring tiles keep one phase)
+    if ((int)blockIdx.x < a.stagger_first) {
+      const int cls = ((blockIdx.x / 8) / 2) % a.stagger_classes;
+      const unsigned long long t0 = wall_clock64(), wait = (unsigned long long)cls * a.stagger_ticks;
+      while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+    }
+  }
+  if constexpr ((ABL & 128) != 0) {   // at most sem_k workgroups per XCD in their load phase, admitted in ticket order
+    if (threadIdx.x == 0) {              // [0] tickets issued (workgroups), [32] waves whose loads have landed
+      unsigned* sem = a.sem + (blockIdx.x % 8) * 64;
+      const unsigned ticket = __hip_atomic_fetch_add(&sem[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      while ((int)(ticket * 8u - __hip_atomic_load(&sem[32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= a.sem_k * 8) __builtin_amdgcn_s_sleep(8);
+    }
+    __syncthreads();
+  }
+  stamp(0);
   static_assert(RF == RS || RF == 2 * RS, "n_fft = RS*RS or 2*RS*RS");
   constexpr int N = RF * RS, NS = RF / RS;                  // NS sets of RS values per thread in the middle phase
   constexpr int RAF = FftCfg<RF>::RA, RBF = FftCfg<RF>::RB; // RF-point transforms (F1, I2)
@@ -241,6 +274,22 @@ spectre_mix_regtile(const RegtileArgs a) {
     });
   }
 
+  if constexpr ((ABL & 256) != 0) {   // L2 / Infinity-Cache prefetch: one dword per row segment, result discarded (AGPR a0)
+    const int pt = tile + a.pf_dist;
+    if (pt < a.n_tiles) {
+      const int pb = pt / a.tiles_per_row, pct = pt - pb * a.tiles_per_row;
+      const char* pv = reinterpret_cast<const char*>(a.v) + ((size_t)pb * a.v_sb + (size_t)pct * (2 * kPC)) * ES_IN;
+      static_for<0, N / (kPC * RS)>([&](auto ic) {
+        const char* ptr = pv + (size_t)(tid + decltype(ic)::value * kPC * RS) * v_sn * ES_IN;
+        asm volatile("global_load_dword a0, %0, off" :: "v"(ptr) : "a0");
+      });
+    }
+  }
+  if constexpr ((ABL & 128) != 0) {   // this wave's loads have landed: one eighth of a slot is free again
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&a.sem[(blockIdx.x % 8) * 64 + 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if constexpr (TRACE) { stamp(1); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(2); }
   // ---- F1: RF-point forward transform over n1, then W_N^(u*k1) ---------------------------------------
   if constexpr (!NO_MATH) {
     fftA_stage1<RAF, RBF, false>(z);
@@ -274,6 +323,7 @@ spectre_mix_regtile(const RegtileArgs a) {
     }
   }
 
+  stamp(3);
   // ---- middle: per set t (k1 = u + RS*t):  F2 stage 1, then per register group  F2 stage 2 -> gate -> I1 stage 1,
   //      then I1 stage 2.  Bin of register (ka, kb) of set t: k = k1 + RF*k2, k2 = ka + RAS*kb.  k2 >= RS/2 means
   //      k > N/2 (or k == N/2 when k1 == 0): the Hermitian extension reads conj(g[N - k]).
@@ -371,6 +421,7 @@ spectre_mix_regtile(const RegtileArgs a) {
     }
   }
 
+  stamp(4);
   // ---- conj twiddle, I2 and store (spectre.py:553 keeps rows < min(N, n_fft)) -----------------------------
   if constexpr (!NO_MATH) {
     float2 wa[RAF], wb[RBF];
@@ -404,6 +455,8 @@ spectre_mix_regtile(const RegtileArgs a) {
       }
     });
   }
+  stamp(5);
+  if constexpr (TRACE_ACK) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(6); }
   }  // tile loop
 }
 
