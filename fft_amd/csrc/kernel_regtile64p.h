@@ -1,0 +1,268 @@
+// kernel_regtile64p.h — persistent, software-pipelined spectral mix for n_fft = 4096 = 64 x 64 on gfx950 (fast mode:
+// N_in >= n_fft, no memory_fft, every 16-channel tile inside one gate group, 16-byte aligned fp32 rows).
+//
+// Same mathematics and the same register-tile plan as kernel_regtile.h (one workgroup owns 16 channels x 4096 rows; F1 ->
+// twiddle -> E1 -> F2 -> gate -> I1 -> E2 -> conj twiddle -> I2; replaces /root/reference/spectre.py:506 + :542-553), rebuilt
+// around what the round-2 measurements showed (tools/trace_bench.hip, tools/iolab.hip, profiles/r02_*):
+//
+//  * all 256 CUs run in lock-step — everybody loads, then everybody computes — and that state is an attractor (a CU that
+//    loads while the others compute finishes early and drifts back into the pack), so HBM idles while the chip computes.
+//    Loads of tile t+1 therefore have to be in flight while tile t is still being computed on the SAME CU;
+//  * a wave's stores and loads retire through one in-order counter (vmcnt): loads issued behind the stores of the previous
+//    tile cannot be consumed before those stores are acknowledged.  The next tile's first half is therefore requested BEFORE
+//    the stores, as LDS-DMA (global_load_lds_dwordx4, no VGPR needed) into the exchange image, which is idle between the last
+//    exchange of tile t and the first exchange of tile t+1.  Every lane reads back exactly the 16 bytes it requested, so the
+//    staging needs no barrier of its own;
+//  * the second half is loaded straight into the registers that the stores of I2 have just released (store register group g of
+//    tile t, then load row group g of tile t+1 into it: same 8 x 8 register <-> row pattern on both sides);
+//  * 16-byte global accesses: a lane moves the 4 channels (2 packed sequences) of one row; v_permlane16_swap hands the
+//    second sequence to the partner lane (lane ^ 16) and receives the partner's row of this lane's sequence, so a lane still
+//    owns ONE sequence.  The lane <-> (sequence, row class) map is chosen so that the existing conflict-free LDS image layout
+//    stays conflict-free (checked with the bank model of MI355X_MICROARCH.md: write banks 4p + rc, b128 read groups distinct).
+//
+// Thread <-> data:  lane = (pp = lane & 3, rcl = (lane >> 2) & 3, h = (lane >> 4) & 1, rch = lane >> 5);
+//   sequence p = 2 pp + h, team index u = rcl + 4 rch + 8 wave  (n2 in F1 / I2, k1 in the middle phase);
+//   register position j = 8 g + e  <->  row n1 = g + 8 e  (both when loading and when storing).
+#pragma once
+#include "kernel_regtile.h"
+
+namespace sfft {
+
+constexpr int kP64ImageBytes = regtile_image_bytes<64, 64, 1>();
+constexpr int kP64LdsTotal = regtile_lds_total<64, 64, 1>();
+
+__device__ __forceinline__ void lane16_swap(float& x, float& y) {   // x of the odd 16-lane rows <-> y of the even rows
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  x = __uint_as_float(r[0]);
+  y = __uint_as_float(r[1]);
+}
+
+// SPLIT = row groups (of 8) of the next tile that travel through LDS (0: everything is loaded behind the stores).
+template <int SPLIT, int ABL = 0>
+__global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileArgs a) {
+  constexpr int RW = 8 * 68, PS = 68;              // image row / column strides in floats (kernel_regtile.h, 16-byte layout)
+  constexpr float inv_n = 1.0f / 4096.0f;
+  static_assert(SPLIT >= 0 && SPLIT <= 4 && SPLIT * 4 * 1024 * 8 <= kP64ImageBytes, "staging lives in the exchange image");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* img = reinterpret_cast<float*>(smem);
+  float2* glds = reinterpret_cast<float2*>(smem + kP64ImageBytes);
+
+  // Only threadIdx.x stays live across the tile loop; the lane coordinates are re-derived from an opaque copy per tile
+  // (otherwise LICM hoists every per-lane address out of the loop and the allocator spills them).
+  const int tid0 = threadIdx.x;
+  int lane, pp, h, p, u;
+  char* slot;
+  auto coords = [&]() {
+    int t = tid0;
+    asm volatile("" : "+v"(t));
+    lane = t & 63;
+    pp = lane & 3; h = (lane >> 4) & 1;
+    p = 2 * pp + h;
+    u = ((lane >> 2) & 3) + 4 * (lane >> 5) + 8 * (t >> 6);
+    slot = smem + __builtin_amdgcn_readfirstlane(t >> 6) * (SPLIT * 4 * 1024);   // this wave's landing slots
+  };
+  coords();
+
+  const int wg_lin = xcd_contiguous(blockIdx.x, a.n_wg);
+  const int pair_base = (wg_lin >> 1) * a.tpw * 2 + (wg_lin & 1);   // workgroups 2m, 2m+1 walk through adjacent tiles in step
+  if (pair_base >= a.n_tiles) return;
+
+  // ABL (tools/trace64p_bench.hip only; 0 in the library): bit4 = phase timestamps (100 MHz) into a.trace, 8 per (workgroup, tile)
+  [[maybe_unused]] auto stamp = [&](int it, int slot) {
+    if constexpr ((ABL & 16) != 0) { if (threadIdx.x == 0) a.trace[((size_t)blockIdx.x * a.tpw + it) * 8 + slot] = wall_clock64(); }
+  };
+  float2 z[64];
+  float2 gstage[5];      // the next tile's gate bins on their way to LDS (4097 bins / 512 threads, rounded up; + 1 for the last)
+
+  auto tile_ptrs = [&](int tile, const char*& vb, char*& ob, const float2*& gp) {
+    const int b = tile / a.tiles_per_row, ct = tile - b * a.tiles_per_row;
+    vb = reinterpret_cast<const char*>(a.v) + ((size_t)b * a.v_sb + (size_t)ct * 16) * 4;
+    ob = reinterpret_cast<char*>(a.out) + ((size_t)b * a.out_sb + (size_t)ct * 16) * 4;
+    gp = a.gate + ((size_t)b * a.G + (ct * 16) / a.d_g) * a.F;
+  };
+  // row of this lane in load / store instruction (g, m):  u + 512 h + 64 g + 1024 m; addresses = workgroup-uniform base of the
+  // instruction (SGPRs) + one 32-bit lane offset (spectre_hip.hip bounds 4095 * row stride * 4 + 64 below 2^31)
+  auto load_group = [&](const char* vb, uint32_t voff, long long sn, auto gc) {       // straight into the registers of group g
+    constexpr int g = decltype(gc)::value;
+    static_for<0, 4>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      const float4 t = *reinterpret_cast<const float4*>(vb + (size_t)(64 * g + 1024 * m) * sn * 4 + voff);
+      z[8 * g + 2 * m] = make_float2(t.x, t.y);
+      z[8 * g + 2 * m + 1] = make_float2(t.z, t.w);
+    });
+  };
+  auto dma_group = [&](const char* vb, uint32_t voff, long long sn, auto gc) {        // into this wave's LDS slots (1 KiB per instruction)
+    constexpr int g = decltype(gc)::value;
+    static_for<0, 4>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(vb + (size_t)(64 * g + 1024 * m) * sn * 4 + voff),
+          (__attribute__((address_space(3))) void*)(slot + (4 * g + m) * 1024), 16, 0, 0);
+    });
+  };
+  auto read_group = [&](auto gc) {                                       // this lane's 16 bytes back out of the slot
+    constexpr int g = decltype(gc)::value;
+    static_for<0, 4>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      const float4 t = *reinterpret_cast<const float4*>(slot + (4 * g + m) * 1024 + lane * 16);
+      z[8 * g + 2 * m] = make_float2(t.x, t.y);
+      z[8 * g + 2 * m + 1] = make_float2(t.z, t.w);
+    });
+  };
+  auto swap_group = [&](auto gc) {      // rows (g + 16 m, g + 16 m + 8) of sequences (2pp, 2pp+1)  <->  both rows of sequence p
+    constexpr int g = decltype(gc)::value;
+    static_for<0, 4>([&](auto mc) {
+      constexpr int j = 8 * g + 2 * decltype(mc)::value;
+      lane16_swap(z[j].x, z[j + 1].x);
+      lane16_swap(z[j].y, z[j + 1].y);
+    });
+  };
+  auto gate_fetch = [&](const float2* gp) {
+    static_for<0, 5>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const int k = lane + 64 * (u >> 3) + 512 * i;
+      float2 g = make_float2(0.f, 0.f);
+      if (i < 4 || k <= 2048) g = gp[k];
+      if (k == 0 || k == 2048) g.y = 0.f;          // irfft ignores Im(DC), Im(Nyquist) (spectre.py:551)
+      if (a.conj_gate) g.y = -g.y;
+      gstage[i] = make_float2(g.x * inv_n, g.y * inv_n);
+    });
+  };
+  auto gate_commit = [&]() {
+    static_for<0, 5>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const int k = lane + 64 * (u >> 3) + 512 * i;
+      if (i < 4 || k <= 2048) glds[k] = gstage[i];
+    });
+  };
+
+  // ---- prologue: request tile 0 the same way every later tile is requested --------------------------------------------
+  {
+    const char* vb; char* ob; const float2* gp;
+    tile_ptrs(pair_base, vb, ob, gp);
+    const uint32_t voff = (uint32_t)(((long long)(u + 512 * h) * a.v_sn + 4 * pp) * 4);
+    static_for<0, SPLIT>([&](auto gc) { dma_group(vb, voff, a.v_sn, gc); });
+    asm volatile("" ::: "memory");
+    static_for<SPLIT, 8>([&](auto gc) { load_group(vb, voff, a.v_sn, gc); });
+    gate_fetch(gp);
+  }
+
+  for (int it = 0; it < a.tpw; ++it) {
+    const int tile = pair_base + 2 * it;
+    if (tile >= a.n_tiles) break;                  // workgroup-uniform
+    const bool more = (it + 1 < a.tpw) && (tile + 2 < a.n_tiles);
+    coords();
+    long long v_sn = a.v_sn, out_sn = a.out_sn;
+    asm volatile("" : "+s"(v_sn), "+s"(out_sn));
+    const char* vb; char* ob; const float2* gp;
+    tile_ptrs(tile, vb, ob, gp);
+    const char* vbn = vb; char* obn = ob; const float2* gpn = gp;
+    if (more) tile_ptrs(tile + 2, vbn, obn, gpn);
+
+    stamp(it, 0);
+    // ---- the tile arrives: LDS-staged groups first (requested before the previous tile's stores; completion is in order, so
+    //      everything but the 16 youngest stores and the 5 gate loads has retired), then the groups loaded straight into registers
+    if constexpr (SPLIT > 0) {
+      asm volatile("s_waitcnt vmcnt(21)" ::: "memory");
+      static_for<0, SPLIT>([&](auto gc) { read_group(gc); });
+    }
+
+    stamp(it, 1);
+    // ---- F1: 64-point forward transform over n1 (register position 8g + e holds row g + 8e), then W_N^(u*k1) ------------
+    static_for<0, 8>([&](auto gc) {
+      constexpr int g = decltype(gc)::value;
+      swap_group(gc);
+      bfly<8, false, 8 * g, 1, 64>(z);             // over e -> ka at position 8g + ka
+      static_for<1, 8>([&](auto kac) { constexpr int ka = decltype(kac)::value; z[8 * g + ka] = twid64<g * ka, false>(z[8 * g + ka]); });
+    });
+    gate_commit();                                 // this tile's gate bins (fetched behind the previous tile's stores) -> LDS
+    {
+      float2 wa[8], wb[8];
+      __builtin_amdgcn_sched_barrier(0);           // keep the base loads (and their registers) out of stage 1
+      static_for<1, 8>([&](auto jc) { constexpr int j = decltype(jc)::value; wa[j] = a.tw[u * j]; wb[j] = a.tw[u * 8 * j]; });
+      static_for<0, 8>([&](auto kac) { bfly<8, false, decltype(kac)::value, 8, 64>(z); });   // over g -> kb at position 8kb + ka: k1 = position
+      static_for<1, 64>([&](auto jc) {
+        constexpr int j = decltype(jc)::value, ka = j % 8, kb = j / 8;
+        if constexpr (ka > 0) z[j] = cmul(z[j], wa[ka]);
+        if constexpr (kb > 0) z[j] = cmul(z[j], wb[kb]);
+      });
+    }
+
+    // ---- E1: position k1 -> image row k1, column (p, u); thread (p, s = u) reads row u, slot n2 ---------------------------
+    stamp(it, 2);
+    __syncthreads();                               // every wave has emptied its landing slots / finished E2's reads of the previous tile
+    exchange_planes_b128<64, 8, 8>(z, img,
+        [&](auto jc) { return decltype(jc)::value * RW + p * PS + u; },
+        [&](auto mc) { return u * RW + p * PS + decltype(mc)::value; });
+
+    stamp(it, 3);
+    // ---- middle: F2 -> gate -> I1 (kernel_regtile.h; bin of register (ka, kb): k = k1 + 64 k2, k2 = ka + 8 kb) -------------
+    {
+      const int k1 = u;
+      fftA_stage1<8, 8, false>(z);
+      auto fetch_gate = [&](int k2, bool upper) -> float2 {
+        float2 g = glds[upper ? 64 * (64 - k2) - k1 : k1 + 64 * k2];      // scaled by 1/N, edges fixed, conj applied
+        if (upper) g.y = -g.y;                                          // Hermitian extension above N/2
+        return g;
+      };
+      float2 gcur[8], gnxt[8];
+      static_for<0, 8>([&](auto kbc) { constexpr int k2 = 8 * decltype(kbc)::value; gcur[decltype(kbc)::value] = fetch_gate(k2, k2 >= 32); });
+      static_for<0, 8>([&](auto kac) {
+        constexpr int ka = decltype(kac)::value;
+        if constexpr (ka + 1 < 8)
+          static_for<0, 8>([&](auto kbc) { constexpr int k2n = ka + 1 + 8 * decltype(kbc)::value; gnxt[decltype(kbc)::value] = fetch_gate(k2n, k2n >= 32); });
+        fftA_stage2_group<8, 8, false, ka>(z);
+        static_for<0, 8>([&](auto kbc) { constexpr int kb = decltype(kbc)::value; z[8 * ka + kb] = cmul(z[8 * ka + kb], gcur[kb]); });   // spectre.py:545
+        fftB_stage1_group<8, 8, true, ka>(z);
+        if constexpr (ka + 1 < 8) static_for<0, 8>([&](auto kbc) { gcur[decltype(kbc)::value] = gnxt[decltype(kbc)::value]; });
+        __builtin_amdgcn_sched_barrier(0);         // keep the gate prefetch one group deep (register budget)
+      });
+      fftB_stage2<8, 8, true>(z);                  // natural order: position n2
+    }
+
+    // ---- E2: position n2 -> image row n2, column (p, k1 = u); thread (p, u) reads row u, slot k1 --------------------------
+    exchange_planes_b128<64, 8, 8, (SPLIT > 0)>(z, img,
+        [&](auto jc) { return decltype(jc)::value * RW + p * PS + u; },
+        [&](auto mc) { return u * RW + p * PS + decltype(mc)::value; });
+
+    stamp(it, 4);
+    // ---- the image is idle until the next E1: let the first row groups of the next tile land in it, and fetch its gate -----
+    const uint32_t voff = (uint32_t)(((long long)(u + 512 * h) * v_sn + 4 * pp) * 4);
+    if (more) {
+      static_for<0, SPLIT>([&](auto gc) { dma_group(vbn, voff, v_sn, gc); });
+      asm volatile("" ::: "memory");               // the vmcnt() above counts on these being older than every store below
+    }
+
+    // ---- conj twiddle, I2, stores (spectre.py:553) interleaved with the loads that refill the released registers -----------
+    {
+      float2 wa[8], wb[8];
+      static_for<1, 8>([&](auto jc) { constexpr int j = decltype(jc)::value; wa[j] = a.tw[u * j]; wb[j] = a.tw[u * 8 * j]; });
+      static_for<1, 64>([&](auto jc) {
+        constexpr int j = decltype(jc)::value, ja = j % 8, jb = j / 8;   // position j carries k1 = j
+        if constexpr (ja > 0) z[j] = cmulc(z[j], wa[ja]);
+        if constexpr (jb > 0) z[j] = cmulc(z[j], wb[jb]);
+      });
+      fftA_stage1<8, 8, true>(z);
+    }
+    {
+      const uint32_t ooff = (uint32_t)(((long long)(u + 512 * h) * out_sn + 4 * pp) * 4);
+      static_for<0, 8>([&](auto ic) {
+        constexpr int g = (decltype(ic)::value + SPLIT) % 8;             // register-loaded groups first: their reloads start earliest
+        fftA_stage2_group<8, 8, true, g>(z);                              // rows g + 8e at positions 8g + e
+        swap_group(std::integral_constant<int, g>{});
+        static_for<0, 4>([&](auto mc) {
+          constexpr int m = decltype(mc)::value;
+          *reinterpret_cast<float4*>(ob + (size_t)(64 * g + 1024 * m) * out_sn * 4 + ooff) =
+              make_float4(z[8 * g + 2 * m].x, z[8 * g + 2 * m].y, z[8 * g + 2 * m + 1].x, z[8 * g + 2 * m + 1].y);
+        });
+        if constexpr (g >= SPLIT) { if (more) load_group(vbn, voff, v_sn, std::integral_constant<int, g>{}); }
+      });
+    }
+    if (more) gate_fetch(gpn);                     // committed to LDS after F1's first stage of the next tile
+    stamp(it, 5);
+  }  // tile loop
+}
+
+hipError_t launch_regtile64p(const RegtileArgs& a, hipStream_t stream);
+
+}  // namespace sfft

@@ -30,6 +30,7 @@ template <> hipError_t launch_regtile<32, 16>(const RegtileArgs&, bool, bool, in
 template <> hipError_t launch_regtile<32, 32>(const RegtileArgs&, bool, bool, int, hipStream_t);
 template <> hipError_t launch_regtile<64, 32>(const RegtileArgs&, bool, bool, int, hipStream_t);
 template <> hipError_t launch_regtile<64, 64>(const RegtileArgs&, bool, bool, int, hipStream_t);
+hipError_t launch_regtile64p(const RegtileArgs&, hipStream_t);                           // regtile_n4096p.hip (persistent, pipelined)
 hipError_t launch_regtile_long_8192(const RegtileArgs&, bool, bool, int, hipStream_t);   // regtile_n8192.hip, regtile_n6144.hip
 hipError_t launch_regtile_long_6144(const RegtileArgs&, bool, bool, int, hipStream_t);
 hipError_t launch_regtile_quad_16384(const RegtileArgs&, bool, bool, int, hipStream_t);   // regtile_n16384.hip, regtile_n12288.hip
@@ -272,6 +273,7 @@ struct Choice {
   const TileSize* tile = nullptr;
   int RF = 0, RS = 0;      // n_fft = RF * RS
   int mode = 0;            // 0 fast, 1 general (row predicates / gate from global), 2 general + memory_fft, 3 row predicates only
+  bool pipelined = false;  // n_fft = 4096 fast mode, fp32, 16-byte aligned rows: persistent software-pipelined kernel (kernel_regtile64p.h)
   // stockham
   int P = 0, S = 0, solo = 0;
   const char* why_not_regtile = "";
@@ -332,6 +334,11 @@ int choose(const SpectreMixArgs* a, const Plan* plan, Choice* c) {
     c->regtile = true;
     c->tile = ts; c->RF = ts->RF; c->RS = ts->RS;
     c->mode = mode;
+    static const bool p64_off = [] { const char* e = getenv("SPECTRE_P64"); return e && atoi(e) == 0; }();   // A/B switch (tuning aid)
+    c->pipelined = !p64_off && n == 4096 && mode == 0 && a->in_dtype == SPECTRE_F32 && a->out_dtype == SPECTRE_F32 &&
+                   reinterpret_cast<uintptr_t>(a->v) % 16 == 0 && reinterpret_cast<uintptr_t>(a->out) % 16 == 0 &&
+                   a->v_sn % 4 == 0 && a->v_sb % 4 == 0 && a->out_sn % 4 == 0 && a->out_sb % 4 == 0 &&
+                   a->v_sn * 576 * 4 + 64 < ((int64_t)1 << 31) && a->out_sn * 576 * 4 + 64 < ((int64_t)1 << 31);
     return SPECTRE_OK;
   }
   // Stockham / Bluestein in LDS: one buffer of L points per slot; P slots per workgroup, limited by the LDS and by
@@ -368,6 +375,15 @@ int tiles_per_workgroup(int n_tiles) {
   return forced > 0 ? forced : 1;
 }
 
+int cu_count(int device) {
+  static int cached[64] = {};
+  if (device >= 0 && device < 64 && cached[device] > 0) return cached[device];
+  int n = 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || n < 1) n = 256;
+  if (device >= 0 && device < 64) cached[device] = n;
+  return n;
+}
+
 struct DeviceGuard {
   int prev = -1;
   bool ok = true;
@@ -396,7 +412,15 @@ int launch(const SpectreMixArgs* a, const Plan* plan, const Choice& c, bool conj
     k.n_wg = 2 * ((k.n_tiles + 2 * k.tpw - 1) / (2 * k.tpw));
     const bool ib = a->in_dtype == SPECTRE_BF16, ob = a->out_dtype == SPECTRE_BF16;
     if (c.tile->mixed) { k.tpw = 1; k.n_wg = 2 * ((k.n_tiles + 1) / 2); }
-    e = c.tile->launch(k, ib, ob, c.mode, stream);
+    if (c.pipelined) {   // one workgroup per CU walks through tpw tiles; pairs of workgroups stay on adjacent tiles
+      const int ncu = cu_count(a->device);
+      static const int forced = [] { const char* e = getenv("SPECTRE_P64_TPW"); return e ? atoi(e) : 0; }();
+      k.tpw = forced > 0 ? forced : std::max(1, (k.n_tiles + ncu - 1) / ncu);
+      k.n_wg = 2 * ((k.n_tiles + 2 * k.tpw - 1) / (2 * k.tpw));
+      e = sfft::launch_regtile64p(k, stream);
+    } else {
+      e = c.tile->launch(k, ib, ob, c.mode, stream);
+    }
   } else {
     sfft::StockhamArgs k{};
     k.v = a->v; k.gate = reinterpret_cast<const float2*>(a->gate); k.mem = reinterpret_cast<const float*>(a->mem); k.out = a->out;
@@ -487,7 +511,7 @@ int spectre_mix_describe(const SpectreMixArgs* a, char* buf, size_t cap) {
   const char* in = a->in_dtype == SPECTRE_BF16 ? "bf16" : "f32";
   const char* out = a->out_dtype == SPECTRE_BF16 ? "bf16" : "f32";
   if (c.regtile) {
-    snprintf(buf, cap, "regtile%s %dx%d in=%s out=%s mode=%d tiles=%lld", c.tile->tile_ch == 4 ? "-quad" : c.tile->tile_ch == 8 ? "-long" : c.tile->mixed ? "-mixed" : "", c.RF, c.RS,
+    snprintf(buf, cap, "regtile%s %dx%d in=%s out=%s mode=%d tiles=%lld", c.pipelined ? "-pipelined" : c.tile->tile_ch == 4 ? "-quad" : c.tile->tile_ch == 8 ? "-long" : c.tile->mixed ? "-mixed" : "", c.RF, c.RS,
              in, out, c.mode, (long long)(a->B * ((a->D + c.tile->tile_ch - 1) / c.tile->tile_ch)));
   } else {
     std::string r;
