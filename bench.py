@@ -68,6 +68,16 @@ def cpu_baseline(N, D, G, seconds_budget=20.0):
                       f"B={Bc} N={N} D={D} G={G}, {reps} reps in {el:.1f} s"}
 
 
+def launch_command(n_gpus: int, argv: list) -> list:
+    """`python -m torch.distributed.run` command that runs this file as n_gpus ranks on one node."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -78,7 +88,21 @@ def main():
     ap.add_argument("--shape", default="256,4096,768", help="per-GPU B,N,D")
     ap.add_argument("--groups", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--print-launch", action="store_true", help="print the multi-process launch command for --gpus N and exit")
     a = ap.parse_args()
+
+    # --gpus N without a launcher around us: become the launcher (one rank per GPU, RCCL rendezvous on 127.0.0.1)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        cmd = launch_command(a.gpus, [x for x in sys.argv[1:] if x != "--print-launch"])
+        if a.print_launch:
+            print(" ".join(cmd))
+            return
+        import torch
+        have = torch.cuda.device_count()
+        if have < a.gpus and not os.environ.get("SPECTRE_BENCH_OVERSUBSCRIBE"):
+            sys.exit(f"bench.py: --gpus {a.gpus} requested but only {have} HIP device(s) visible")
+        import subprocess
+        sys.exit(subprocess.call(cmd))
 
     import torch
     import torch.distributed as dist
@@ -86,9 +110,13 @@ def main():
     from fft_amd import _native
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU (python bench.py --gpus N does it)")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    local = local % max(1, torch.cuda.device_count())           # (several ranks on one GPU only in dry runs)
+    if local >= torch.cuda.device_count() and not os.environ.get("SPECTRE_BENCH_OVERSUBSCRIBE"):
+        sys.exit(f"bench.py: rank {rank} has no GPU (LOCAL_RANK={local}, {torch.cuda.device_count()} visible)")
+    local = local % max(1, torch.cuda.device_count())           # (several ranks on one GPU only in oversubscribed dry runs)
     backend = os.environ.get("SPECTRE_BENCH_BACKEND", "nccl")  # RCCL; "gloo" for dry runs — no tensor data crosses ranks
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -184,13 +212,15 @@ def main():
         es = V.element_size()
         alg = algorithmic_bytes(B, N, N, D, G, es, es)
         achieved = alg / (kern_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_source = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")  # written by tools/collect_pmc.py on the GPU box
         if os.path.exists(pmc):
             try:
                 rec = json.load(open(pmc))
                 if rec.get("io") == a.io and rec.get("shape") == [B, N, D]:
                     traffic = rec.get("hbm_bytes_per_launch")
+                    traffic_source = ("profiles/pmc_latest.json: separate rocprofv3 --pmc passes of this command "
+                                      "(tools/collect_pmc.py), kernel " + str(rec.get("kernel", "?")) + "; not collected in this run")
             except Exception:
                 traffic = None
         res = {
@@ -198,6 +228,7 @@ def main():
             "value": world * B * N * a.steps / wall,
             "unit": "tokens/s",
             "n_gpus": world,
+            "tokens_per_s_per_gpu": B * N * a.steps / wall,
             "steps": a.steps,
             "warmup": a.warmup,
             "ms_per_step": wall / a.steps * 1e3,
@@ -211,7 +242,7 @@ def main():
                        "io_dtype": a.io, "global_batch": world * B, "seq_len": N, "d_model": D,
                        "parallelism": f"batch-shard x{world} (no collective)", "kernel": kernel},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": alg, "kernel_ms": kern_ms},
         }
         if variants:

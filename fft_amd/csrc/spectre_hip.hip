@@ -261,10 +261,18 @@ int build_plan(int device, int64_t n, Plan** out) {
   return SPECTRE_OK;
 }
 
-int get_plan(int device, int64_t n, Plan** out) {
+// Plans live until spectre_plan_destroy, which must not run concurrently with a launch that uses the same (device, n_fft):
+// the launch paths keep the raw pointer after the mutex is released (documented in include/spectre_hip.h).
+// Building a plan allocates and copies synchronously, which would invalidate a stream capture: refuse instead of corrupting
+// the capture (the caller creates the plan first with spectre_plan_create or one eager call).
+int get_plan(int device, int64_t n, Plan** out, hipStream_t stream = nullptr) {
   std::lock_guard<std::mutex> lk(g_mu);
   auto it = g_plans.find({device, n});
   if (it != g_plans.end()) { *out = it->second.get(); return SPECTRE_OK; }
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (stream && hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+    return fail(SPECTRE_E_INVALID, "no plan for n_fft=%lld on device %d yet and the stream is capturing: call spectre_plan_create "
+                                   "(or run the op once eagerly) before the capture", (long long)n, device);
   return build_plan(device, n, out);
 }
 
@@ -312,6 +320,8 @@ int choose(const SpectreMixArgs* a, const Plan* plan, Choice* c) {
   else if (a->mem && (reinterpret_cast<uintptr_t>(a->mem) % 16)) why = "mem not 16-byte aligned";
   else if (reinterpret_cast<uintptr_t>(a->gate) % 8) why = "gate not 8-byte aligned";
   else if (a->v_sn * 255 * 4 + 64 >= ((int64_t)1 << 31) || a->out_sn * 255 * 4 + 64 >= ((int64_t)1 << 31)) why = "row stride too large";
+  else if (ts->tile_ch < 16 && (a->v_sn * (n - 1) * es_in + 64 >= ((int64_t)1 << 32) || a->out_sn * (n - 1) * es_out + 64 >= ((int64_t)1 << 32)))
+    why = "row stride too large for the 32-bit row offsets of the lane-pair / lane-quad kernels";
   else if (a->B * ((D + 3) / 4) >= ((int64_t)1 << 31)) why = "too many tiles";
   c->why_not_regtile = why;
   const bool can_regtile = why[0] == 0;
@@ -460,7 +470,7 @@ int launch(const SpectreMixArgs* a, const Plan* plan, const Choice& c, bool conj
 int prepare(const SpectreMixArgs* a, Plan** plan, Choice* c) {
   int rc = validate(a);
   if (rc) return rc;
-  rc = get_plan(a->device, a->n_fft, plan);
+  rc = get_plan(a->device, a->n_fft, plan, reinterpret_cast<hipStream_t>(a->stream));
   if (rc) return rc;
   return choose(a, *plan, c);
 }

@@ -77,7 +77,7 @@ class PrefixFFTCache:
         self.prefix_fft.copy_(rfft_prefill(V.float(), self.N))
         self.V_buf[:L].copy_(V)
         self.Q_buf[:L].copy_(Q)
-        self.sum_q = Q.sum(dim=0)
+        self.sum_q = Q.sum(dim=0).to(torch.float32).contiguous()      # fp32 always: the fused step reads and writes it as d floats
         self.t = L - 1
 
     # -- one step: spectrum update (+ optional fused filter and one-row inverse), ring buffers, query sum -------------
@@ -121,6 +121,14 @@ class PrefixFFTCache:
         return self.prefix_fft, self.sum_q
 
 
+def _same_device(a, b) -> bool:
+    a, b = torch.device(a), torch.device(b)
+    if a.type != b.type:
+        return False
+    cur = torch.cuda.current_device() if a.type == "cuda" else 0
+    return (a.index if a.index is not None else cur) == (b.index if b.index is not None else cur)
+
+
 def _fused_head_ok(head) -> bool:
     """The single-call path needs the reference's stock gate MLP (Linear -> GELU(erf) -> Linear) and LayerNorm in fp32."""
     import torch.nn as nn
@@ -142,10 +150,27 @@ def head_decode_step(head, q_t: torch.Tensor, v_t: torch.Tensor, cache: PrefixFF
     cache._require_hip()
     if not _fused_head_ok(head):
         return _head_decode_step_ops(head, q_t, v_t, cache)
+    # The C entry point takes raw pointers and reads every operand as d (or n_fft-derived) float32 values: refuse anything
+    # whose size, dtype or device does not match, where the reference would raise a shape error.
+    if cache.N != head.n_fft or cache.d != head.d:
+        raise ValueError(f"cache built for (n_fft={cache.N}, d={cache.d}) but the head has (n_fft={head.n_fft}, d={head.d})")
+    for name, x in (("q_t", q_t), ("v_t", v_t)):
+        if x.numel() != cache.d or not _same_device(x.device, cache.device):
+            raise ValueError(f"{name} must hold d={cache.d} values on {cache.device}, got {tuple(x.shape)} on {x.device}")
+    bias = head.modrelu.bias
+    if bias.dtype != torch.float32 or not bias.is_contiguous() or bias.numel() != head.G * head.F_half or not _same_device(bias.device, cache.device):
+        return _head_decode_step_ops(head, q_t, v_t, cache)
+    for buf, shape in ((cache.prefix_fft, (head.F_half, cache.d)), (cache.V_buf, (cache.N, cache.d)), (cache.Q_buf, (cache.N, cache.d))):
+        if tuple(buf.shape) != shape or not buf.is_contiguous() or not _same_device(buf.device, cache.device):
+            raise ValueError("PrefixFFTCache buffers were replaced by tensors of another shape, layout or device")
+    if cache.V_buf.dtype != torch.float32 or cache.Q_buf.dtype != torch.float32 or cache.prefix_fft.dtype != torch.complex64:
+        raise TypeError("PrefixFFTCache buffers must stay float32 / complex64")
     lib = _native.load()
     t = cache.t + 1
-    q_t = q_t.to(torch.float32).contiguous()
-    v_t = v_t.to(torch.float32).contiguous()
+    q_t = q_t.reshape(-1).to(torch.float32).contiguous()
+    v_t = v_t.reshape(-1).to(torch.float32).contiguous()
+    if cache.sum_q.dtype != torch.float32 or cache.sum_q.numel() != cache.d or not _same_device(cache.sum_q.device, cache.device):
+        cache.sum_q = cache.sum_q.reshape(-1).to(device=cache.device, dtype=torch.float32)
     out = torch.empty(cache.d, dtype=torch.float32, device=cache.device)
     need = lib.spectre_decode_head_workspace_bytes(cache.N, cache.d, head.G, head.B)
     if cache._ws is None or cache._ws.numel() < need:

@@ -181,12 +181,16 @@ class SpectreHead(nn.Module):
         self.dropout = nn.Dropout(dropout_p) if dropout_p > 0 else nn.Identity()
 
     # ---- host logic: everything up to the filter the kernel consumes (spectre.py:502-503, :511-536) --
-    def spectral_gate(self, x: torch.Tensor, pos_phase: Optional[torch.Tensor] = None
+    def spectral_gate(self, x: torch.Tensor, pos_phase: Optional[torch.Tensor] = None, *, v_out: Optional[torch.Tensor] = None
                       ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-        """Returns (V (B,N,d), gate (B,G,F_half) complex64, q_pool (B,d))."""
+        """Returns (V (B,N,d), gate (B,G,F_half) complex64, q_pool (B,d)).  `v_out` (inference only): a (B,N,d) view the value
+        projection is written into — e.g. this head's channel slice of a multi-head buffer — instead of a fresh tensor."""
         Bsz, N, d = x.shape
         assert d == self.d
-        V = self.W_v(x)
+        if v_out is not None:
+            V = torch.matmul(x, self.W_v.weight.t(), out=v_out)          # W_v has no bias (spectre.py:428)
+        else:
+            V = self.W_v(x)
         if self.fold_mean_pooling and x.is_cuda and isinstance(self.pooling, MeanPool):
             # mean_n(W_q x_n) = W_q(mean_n x_n): W_q has no bias and Q feeds nothing but the pooling (spectre.py:502,
             # :511-512), so the (B,N,d) x (d,d) GEMM and the pass over Q collapse into a row mean and a (B,d) GEMM —
@@ -195,8 +199,11 @@ class SpectreHead(nn.Module):
         else:
             q_pool = self.q_norm(self.pooling(self.W_q(x)))
         anchors = torch.view_as_complex(self.gate_mlp(q_pool).view(Bsz, self.G, self.B, 2))
-        if x.is_cuda and anchors.dtype == torch.complex64 and not (torch.is_grad_enabled() and anchors.requires_grad):
-            # inference: resample -> modReLU -> phase as one HIP launch (row N2); training keeps the ops autograd sees
+        wants_graph = torch.is_grad_enabled() and (anchors.requires_grad or self.modrelu.bias.requires_grad or
+                                                   (pos_phase is not None and pos_phase.requires_grad))
+        if x.is_cuda and anchors.dtype == torch.complex64 and not wants_graph:
+            # inference: resample -> modReLU -> phase as one HIP launch (row N2); training keeps the ops autograd sees (also when
+            # only modrelu.bias or a learnable pos_phase needs a gradient: the fused launch builds no graph)
             return V, spectral_gate_fused(anchors, self.modrelu.bias.detach(), self.modrelu.eps_value, self.F_half, pos_phase), q_pool
         gate = resample_complex(anchors, self.F_half, mode="cubic")
         gate = self.modrelu(gate.reshape(Bsz, -1)).view_as(gate)
@@ -251,12 +258,14 @@ class SpectreMultiHead(nn.Module):
 
     def __init__(self, embed_dim: int, num_heads: int, n_fft: int, d_gate: int = 256, use_toeplitz: bool = False,
                  dropout_p: float = 0.0, pooling_type: str = "dct", num_groups: int = 4,
-                 num_buckets: Optional[int] = None, wavelet_on_rate: float = 0.1):
+                 num_buckets: Optional[int] = None, wavelet_on_rate: float = 0.0):
         super().__init__()
         assert embed_dim % num_heads == 0
+        # Deviation from the reference's default (0.1): the refinement is out of scope, so the default
+        # constructor builds the layer WITHOUT it instead of failing; asking for it explicitly still raises.
         if wavelet_on_rate != 0.0:
             raise NotImplementedError("fft_amd.SpectreMultiHead: the stochastic WaveletRefinement (spectre.py:819-878) is not "
-                                      "implemented; construct with wavelet_on_rate=0.0")
+                                      "implemented; construct with wavelet_on_rate=0.0 (the default here; the reference's is 0.1)")
         self.num_heads = num_heads
         self.head_dim = embed_dim // num_heads
         self.heads = nn.ModuleList([
@@ -273,10 +282,15 @@ class SpectreMultiHead(nn.Module):
         if needs_graph or any(not isinstance(h.dropout, nn.Identity) for h in self.heads):
             mixed = torch.cat([h(c, pos_phase, memory_fft=m) for h, c, m in zip(self.heads, chunks, mems)], dim=-1)
             return self.out_proj(mixed)
-        n_out = min(x.shape[1], self.heads[0].n_fft)
-        mixed = torch.empty(x.shape[0], n_out, x.shape[2], dtype=x.dtype, device=x.device)
-        for i, (h, c, m) in enumerate(zip(self.heads, chunks, mems)):
-            V, gate, _ = h.spectral_gate(c, pos_phase)
-            spectral_mix(V, gate.to(torch.complex64), None if m is None else m.to(torch.complex64), h.n_fft,
-                         out=mixed[:, :, i * self.head_dim:(i + 1) * self.head_dim])
+        # One launch for all heads (row N3): every head's value projection lands in its channel slice of one (B, N, D) tensor,
+        # the heads' gates are stacked to (B, H*G, F) — channel c of the full tensor belongs to gate row c // d_g exactly as in
+        # the per-head calls — and memory_fft is used un-chunked.  Replaces the reference's per-head loop + torch.cat (:712-719).
+        hd = self.head_dim
+        V = torch.empty(x.shape[0], x.shape[1], x.shape[2], dtype=x.dtype, device=x.device)
+        gates = []
+        for i, (h, c) in enumerate(zip(self.heads, chunks)):
+            _, gate, _ = h.spectral_gate(c, pos_phase, v_out=V[:, :, i * hd:(i + 1) * hd])
+            gates.append(gate.to(torch.complex64))
+        gate_all = torch.cat(gates, dim=1)
+        mixed = spectral_mix(V, gate_all, None if memory_fft is None else memory_fft.to(torch.complex64), self.heads[0].n_fft)
         return self.out_proj(mixed)

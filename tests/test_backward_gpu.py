@@ -97,3 +97,32 @@ def test_module_autograd_matches_torch_fft_autograd():
         ref = p.grad
         scale = float(ref.abs().max()) + 1e-12
         assert float((got[k] - ref).abs().max()) <= 2e-3 * scale, k
+
+
+# ------------------------------------------------------------------------------------------------------
+# full benchmark sizes (BASELINE.json configs C2 and C4): columns of dV and whole (b, g) rows of dgate against the float64
+# closed form — the S-way partial-sum path of the gate gradient only grows to its full width at these sizes
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,N,D,G", [(256, 4096, 768, 4), (256, 3000, 768, 4)])
+def test_full_size_backward_columns_and_gate_rows(B, N, D, G):
+    from fft_amd import spectral_mix_backward
+    torch.manual_seed(1)
+    F = N // 2 + 1
+    V = torch.randn(B, N, D, device=DEV)
+    dY = torch.randn(B, N, D, device=DEV)
+    gate = torch.randn(B, G, F, dtype=torch.complex64, device=DEV) * 0.3
+    gate = gate * (torch.rand(B, G, F, device=DEV) >= 0.18)
+    dV, dG = spectral_mix_backward(V, gate, dY, N)
+    torch.cuda.synchronize()
+    d_g = D // G
+    for (b, c) in [(0, 0), (B - 1, D - 2), (B // 3, D // 2 + 2), (7, 16 * 11 + 6)]:
+        grp = c // d_g
+        rV, _ = spectral_mix_backward_numpy(V[b:b + 1, :, c:c + 2].cpu().numpy(), gate[b:b + 1, grp:grp + 1].cpu().numpy(),
+                                            dY[b:b + 1, :, c:c + 2].cpu().numpy(), N)
+        assert_close(dV[b:b + 1, :, c:c + 2].cpu().numpy(), rV, what=f"dV column ({b},{c})")
+    for (b, g) in [(0, 0), (B - 1, G - 1), (B // 2, 1)]:
+        sl = slice(g * d_g, (g + 1) * d_g)
+        _, rG = spectral_mix_backward_numpy(V[b:b + 1, :, sl].cpu().numpy(), gate[b:b + 1, g:g + 1].cpu().numpy(),
+                                            dY[b:b + 1, :, sl].cpu().numpy(), N)
+        got = torch.view_as_real(dG[b:b + 1, g:g + 1]).cpu().numpy()
+        assert_close(got, np.stack([rG.real, rG.imag], -1), what=f"dgate row ({b},{g})")

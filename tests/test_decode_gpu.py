@@ -103,3 +103,27 @@ def test_fused_and_ops_decode_paths_agree():
     assert c1.t == c2.t
     assert_close(c1.sum_q.cpu().numpy(), c2.sum_q.cpu().numpy(), what="sum_q")
     assert torch.equal(c1.V_buf, c2.V_buf) and torch.equal(c1.Q_buf, c2.Q_buf)
+
+
+def test_fused_step_validates_its_operands():
+    """the single-call decode step reads raw pointers as d floats — mismatched sizes must raise, a bf16 prompt must
+    not turn the running query sum into a half-sized buffer."""
+    import fft_amd
+    d, N = 32, 256
+    head = fft_amd.SpectreHead(d, N, num_groups=2, pooling_type="mean").to("cuda:0").eval()
+    cache = fft_amd.PrefixFFTCache(N, d, device="cuda:0")
+    Q = torch.randn(10, d, device="cuda:0")
+    V = torch.randn(10, d, device="cuda:0")
+    cache.prefill(Q.to(torch.bfloat16), V.to(torch.bfloat16))
+    assert cache.sum_q.dtype == torch.float32 and cache.sum_q.numel() == d
+    y = head.decode_step(torch.randn(d, device="cuda:0"), torch.randn(d, device="cuda:0"), cache)
+    torch.cuda.synchronize()
+    assert y.shape == (d,) and bool(torch.isfinite(y).all())
+    with pytest.raises(ValueError):
+        head.decode_step(torch.randn(d + 1, device="cuda:0"), torch.randn(d, device="cuda:0"), cache)
+    with pytest.raises(ValueError):
+        head.decode_step(torch.randn(d, device="cuda:0"), torch.randn(d), cache)                 # v_t on the CPU
+    with pytest.raises(ValueError):
+        head.decode_step(torch.randn(d, device="cuda:0"), torch.randn(d, device="cuda:0"), fft_amd.PrefixFFTCache(2 * N, d, device="cuda:0"))
+    with pytest.raises(ValueError):
+        head.decode_step(torch.randn(d, device="cuda:0"), torch.randn(d, device="cuda:0"), fft_amd.PrefixFFTCache(N, 2 * d, device="cuda:0"))

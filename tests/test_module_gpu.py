@@ -69,3 +69,21 @@ def test_forward_can_be_captured_in_a_graph():
         want2 = head(x)
     assert not torch.equal(want, want2)
     assert torch.equal(y, want2)
+
+
+def test_modrelu_bias_and_pos_phase_get_gradients_when_the_rest_is_frozen():
+    """with W_q / q_norm / gate_mlp frozen and x without grad, the anchors carry no graph — the fused gate launch must
+    not be taken then, or modrelu.bias and a learnable pos_phase silently get no gradient (the reference trains them)."""
+    from fft_amd import SpectreHead
+    torch.manual_seed(0)
+    head = SpectreHead(32, 256, num_groups=2, pooling_type="mean").to("cuda:0")
+    for m in (head.W_q, head.q_norm, head.gate_mlp):
+        for p in m.parameters():
+            p.requires_grad_(False)
+    x = torch.randn(2, 256, 32, device="cuda:0")
+    pos = torch.nn.Parameter(torch.exp(1j * torch.randn(129, device="cuda:0")).to(torch.complex64))
+    head(x, pos_phase=pos).square().sum().backward()
+    torch.cuda.synchronize()
+    assert head.modrelu.bias.grad is not None and float(head.modrelu.bias.grad.abs().sum()) > 0
+    assert pos.grad is not None and float(pos.grad.abs().sum()) > 0
+    assert head.W_v.weight.grad is not None

@@ -28,8 +28,9 @@ def test_surface_and_reference_state_dict():
     assert names == ["self", "embed_dim", "num_heads", "n_fft", "d_gate", "use_toeplitz", "dropout_p", "pooling_type",
                      "num_groups", "num_buckets", "wavelet_on_rate"]                    # spectre.py:664-676
     assert list(inspect.signature(SpectreMultiHead.forward).parameters) == ["self", "x", "pos_phase", "memory_fft"]
+    assert SpectreMultiHead(32, 2, 64).wavelet_refinement.on_rate == 0.0             # default constructor works (documented deviation: 0.0, reference 0.1)
     with pytest.raises(NotImplementedError, match="wavelet_on_rate"):
-        SpectreMultiHead(32, 2, 64)                                                     # reference default 0.1: refused loudly
+        SpectreMultiHead(32, 2, 64, wavelet_on_rate=0.1)                                # asking for the refinement is refused loudly
     assert len(MH) >= 2
     for p in MH:
         mh = _build(load_golden(p))
@@ -45,7 +46,7 @@ def test_forward_matches_reference(path):
     pp = torch.from_numpy(d["pos_phase"]).to("cuda:0") if "pos_phase" in d else None
     mem = torch.from_numpy(d["mem"]).to("cuda:0") if "mem" in d else None
     with torch.no_grad():
-        y = mh(x, pos_phase=pp, memory_fft=mem)                     # slice-writing path
+        y = mh(x, pos_phase=pp, memory_fft=mem)                     # single-launch path: one spectral mix over all heads
     y_graph = mh(x, pos_phase=pp, memory_fft=mem)                   # autograd path (per-head modules + cat)
     torch.cuda.synchronize()
     assert tuple(y.shape) == d["out"].shape
@@ -53,3 +54,25 @@ def test_forward_matches_reference(path):
     assert_close(y_graph.detach().cpu().numpy(), d["out"], rtol=1e-4, atol_rms=2e-4, what="multi-head forward (autograd path)")
     y_graph.sum().backward()
     assert all(p.grad is not None for n, p in mh.named_parameters() if not n.startswith("wavelet_refinement"))
+
+
+@pytest.mark.gpu
+def test_inference_is_one_mix_launch_over_all_heads(monkeypatch):
+    """Row N3 as SURVEY.md wrote it: without autograd the H heads run as ONE spectral-mix call on a (B, H*G, F) gate."""
+    import fft_amd.spectre as sp
+    d = load_golden(MH[0])
+    mh = _build(d).to("cuda:0")
+    calls = []
+    real = sp.spectral_mix
+
+    def counting(V, gate, *a, **k):
+        calls.append((tuple(V.shape), tuple(gate.shape)))
+        return real(V, gate, *a, **k)
+
+    monkeypatch.setattr(sp, "spectral_mix", counting)
+    x = torch.from_numpy(d["x"]).to("cuda:0")
+    with torch.no_grad():
+        mh(x)
+    assert len(calls) == 1
+    (vs, gs), = calls
+    assert vs[2] == mh.num_heads * mh.head_dim and gs[1] == mh.num_heads * mh.heads[0].G

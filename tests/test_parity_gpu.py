@@ -214,7 +214,7 @@ def test_runs_on_the_callers_stream():
 # ------------------------------------------------------------------------------------------------------
 # full benchmark sizes: properties instead of the (too slow) oracle
 # ------------------------------------------------------------------------------------------------------
-FULL = [(256, 4096, 768, 4, torch.float32), (256, 1024, 768, 4, torch.float32), (64, 3000, 768, 4, torch.float32),
+FULL = [(256, 4096, 768, 4, torch.float32), (256, 1024, 768, 4, torch.float32), (256, 3000, 768, 4, torch.float32),
         (256, 4096, 768, 4, torch.bfloat16)]
 
 

@@ -4,14 +4,15 @@ half the bytes of a wide coalesced streaming read (MI355X_MICROARCH.md, section 
 import csv, glob, json, os, sys
 
 root, io, shape = sys.argv[1], sys.argv[2], [int(x) for x in sys.argv[3].split(",")]
-vals = {}
+vals, kname = {}, None
 for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         if "spectre_mix" in r["Kernel_Name"] and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
             vals.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            kname = r["Kernel_Name"].split("(")[0][:80]
 fetch = sum(vals["FETCH_SIZE"]) / len(vals["FETCH_SIZE"])
 write = sum(vals["WRITE_SIZE"]) / len(vals["WRITE_SIZE"])
-rec = {"io": io, "shape": shape, "FETCH_SIZE_kb": fetch, "WRITE_SIZE_kb": write,
+rec = {"io": io, "shape": shape, "kernel": kname, "FETCH_SIZE_kb": fetch, "WRITE_SIZE_kb": write,
        "hbm_bytes_per_launch": fetch * 1024 * 2 + write * 1024,
        "note": "FETCH_SIZE doubled (gfx950 counts 128-B requests at 64 B), separate --pmc passes, per-dispatch average"}
 out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_latest.json")
