@@ -21,6 +21,7 @@
 #include "kernel_regtile_mixed_grad.h"
 #include "kernel_stockham.h"
 #include "kernel_gate.h"
+#include "kernel_gate_grad_twopass.h"
 #include "kernel_decode.h"
 
 namespace sfft {
@@ -643,7 +644,38 @@ int spectre_mix_bwd(const SpectreMixBwdArgs* a) {
       for (int r : rad) ok = ok && ((L / r) * 2 * cand <= (int64_t)sfft::kStockhamMaxThreads * sfft::stockham_kmax(r));
       if (ok) { P = cand; break; }
     }
-    if (P < 1) return fail(SPECTRE_E_UNSUPPORTED, "gate gradient: n_fft=%lld does not fit the LDS (transform length %lld)", (long long)n, (long long)L);
+    if (P < 1) {
+      // two LDS slots do not fit (n_fft = 12288, 16384, long Bluestein lengths): two-pass fallback — spectra of V and dOut with
+      // the half-spectrum kernel into a stream-ordered scratch buffer, then a reduction over each group's channels
+      // (kernel_gate_grad_twopass.h).  Never refuse a length the forward accepts.
+      const int64_t F = n / 2 + 1, per_b = F * D * (int64_t)sizeof(float2);
+      const int64_t Bc = std::max<int64_t>(1, std::min<int64_t>(a->B, ((int64_t)256 << 20) / per_b));
+      if (F >= ((int64_t)1 << 31) || a->G_tot >= 65536 || Bc >= 65536) return fail(SPECTRE_E_UNSUPPORTED, "gate gradient: grid too large");
+      float2 *X = nullptr, *R = nullptr;
+      hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&X), (size_t)(Bc * per_b), stream);
+      if (e == hipSuccess) e = hipMallocAsync(reinterpret_cast<void**>(&R), (size_t)(Bc * per_b), stream);
+      if (e != hipSuccess) { if (X) (void)hipFreeAsync(X, stream); return fail(SPECTRE_E_HIP, "gate gradient scratch (%lld bytes): %s", (long long)(2 * Bc * per_b), hipGetErrorString(e)); }
+      int rc2 = SPECTRE_OK;
+      for (int64_t b0 = 0; b0 < a->B && rc2 == SPECTRE_OK; b0 += Bc) {
+        const int64_t bc = std::min<int64_t>(Bc, a->B - b0);
+        SpectreRfftArgs r{};
+        r.B = bc; r.n_fft = n; r.D = D; r.in_dtype = a->io_dtype; r.device = a->device; r.stream = a->stream;
+        r.v = reinterpret_cast<const char*>(a->v) + b0 * a->v_sb * es; r.spec = X; r.N_in = a->N_in; r.v_sb = a->v_sb; r.v_sn = a->v_sn;
+        rc2 = spectre_rfft_fwd(&r);
+        if (rc2 == SPECTRE_OK) {
+          r.v = reinterpret_cast<const char*>(a->dout) + b0 * a->dout_sb * es; r.spec = R; r.N_in = n_out; r.v_sb = a->dout_sb; r.v_sn = a->dout_sn;
+          rc2 = spectre_rfft_fwd(&r);
+        }
+        if (rc2 == SPECTRE_OK) {
+          hipLaunchKernelGGL(sfft::spectre_gate_grad_reduce, dim3((unsigned)F, (unsigned)a->G_tot, (unsigned)bc), dim3(64), 0, stream, X, R,
+                             reinterpret_cast<float2*>(a->dgate) + b0 * a->G_tot * F, (int)F, (int)D, (int)a->G_tot, (int)d_g, (int)n);
+          if ((e = hipGetLastError()) != hipSuccess) rc2 = fail(SPECTRE_E_HIP, "gate-gradient reduce launch failed: %s", hipGetErrorString(e));
+        }
+      }
+      (void)hipFreeAsync(X, stream);
+      (void)hipFreeAsync(R, stream);
+      return rc2;
+    }
     sfft::StockhamArgs k{};
     k.v = a->v; k.gate = reinterpret_cast<const float2*>(a->gate); k.mem = nullptr; k.out = nullptr;
     k.B = (int)a->B; k.N_in = (int)std::min<int64_t>(a->N_in, (int64_t)1 << 30); k.N = (int)n; k.D = (int)D; k.G = (int)a->G_tot;

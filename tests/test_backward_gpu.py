@@ -42,7 +42,9 @@ SHAPES = [(2, 4096, 64, 4, 4096), (2, 2048, 32, 2, 2048), (3, 1024, 48, 3, 1024)
           (3, 64, 32, 2, 64), (2, 128, 24, 2, 128), (2, 196, 32, 2, 196), (2, 384, 32, 2, 384), (2, 640, 32, 2, 640), (2, 960, 20, 2, 960),
           (2, 1200, 32, 2, 1200), (1, 1920, 32, 2, 1920), (1, 2400, 32, 2, 2400), (1, 3600, 32, 2, 3600), (2, 150, 32, 2, 196),
           # lane-pair gate gradient (n_fft = RF x 128), ragged channel tiles, short input
-          (2, 8192, 32, 2, 8192), (1, 8192, 24, 4, 8192), (1, 6000, 20, 2, 8192), (1, 6144, 16, 1, 6144), (2, 6100, 12, 2, 6144)]
+          (2, 8192, 32, 2, 8192), (1, 8192, 24, 4, 8192), (1, 6000, 20, 2, 8192), (1, 6144, 16, 1, 6144), (2, 6100, 12, 2, 6144),
+          # two-pass gate gradient (spectra of V and dOut, then a reduction): every length the forward accepts has a backward
+          (2, 16384, 16, 2, 16384), (1, 12288, 24, 3, 12288), (2, 15000, 12, 2, 16384), (1, 20000, 8, 1, 16384), (1, 12288, 10, 2, 12288)]
 
 
 @pytest.mark.parametrize("shape", SHAPES, ids=[f"B{s[0]}_N{s[1]}_D{s[2]}_G{s[3]}_fft{s[4]}" for s in SHAPES])
