@@ -29,6 +29,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "fft_regs.h"
 
 // LDS image layout per (RF, RS): 1 = [row][column][slot] with 16-byte reads, 0 = [row][slot][column] with 4-byte reads.
@@ -472,7 +473,7 @@ hipError_t launch_regtile(const RegtileArgs& a, bool in_bf16, bool out_bf16, int
     const dim3 grid(a.n_wg), block(regtile_threads<RF_, RS_>());                                             \
     const size_t lds = regtile_lds_total<RF_, RS_>();                                                        \
     const int key = (in_bf16 ? 16 : 0) | (out_bf16 ? 8 : 0) | mode;                                          \
-    static bool lds_opt_in[16][32] = {};   /* [device][variant]: >64 KiB of dynamic LDS needs a one-time opt-in */ \
+    static std::atomic<bool> lds_opt_in[16][32];   /* [device][variant]: >64 KiB of dynamic LDS needs a one-time opt-in */ \
     auto go = [&](auto kern) -> hipError_t {                                                                 \
       int dev = 0;                                                                                           \
       (void)hipGetDevice(&dev);                                                                              \

@@ -258,7 +258,8 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
         if constexpr (g >= SPLIT) { if (more) load_group(vbn, voff, v_sn, std::integral_constant<int, g>{}); }
       });
     }
-    if (more) gate_fetch(gpn);                     // committed to LDS after F1's first stage of the next tile
+    gate_fetch(gpn);                               // committed to LDS after F1's first stage of the next tile (after the last tile:
+                                                   // a harmless re-read of this tile's bins — keeps the staging registers out of a loop-carried phi)
     stamp(it, 5);
   }  // tile loop
 }

@@ -186,7 +186,7 @@ inline hipError_t launch_gate_grad_long(const GateGradArgs& a, bool io_bf16, boo
   const dim3 grid(a.n_wg), block(512);
   const size_t lds = long_grad_image_bytes(RF);
   const int key = (io_bf16 ? 2 : 0) | (general ? 1 : 0);
-  static bool lds_opt_in[16][4] = {};
+  static std::atomic<bool> lds_opt_in[16][4];
   auto go = [&](auto kern) -> hipError_t {
     int dev = 0;
     (void)hipGetDevice(&dev);

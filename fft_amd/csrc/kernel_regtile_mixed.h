@@ -199,7 +199,7 @@ hipError_t launch_regtile_mixed(const RegtileArgs& a, bool in_bf16, bool out_bf1
     const dim3 grid(a.n_wg), block(mixed_threads<RF_, RS_>());                                               \
     const size_t lds = mixed_lds_total<RF_, RS_>();                                                          \
     const int key = (in_bf16 ? 8 : 0) | (out_bf16 ? 4 : 0) | mode;                                           \
-    static bool lds_opt_in[16][16] = {};                                                                     \
+    static std::atomic<bool> lds_opt_in[16][16];                                                                     \
     auto go = [&](auto kern) -> hipError_t {                                                                 \
       int dev = 0;                                                                                           \
       (void)hipGetDevice(&dev);                                                                              \
@@ -236,7 +236,7 @@ hipError_t launch_regtile_mixed(const RegtileArgs& a, bool in_bf16, bool out_bf1
     const size_t lds = mixed_lds_total<RF_, RS_>();                                                          \
     if (in_bf16 != out_bf16) return hipErrorInvalidValue;                                                    \
     const int key = (in_bf16 ? 4 : 0) | mode;                                                                \
-    static bool lds_opt_in[16][8] = {};                                                                      \
+    static std::atomic<bool> lds_opt_in[16][8];                                                                      \
     auto go = [&](auto kern) -> hipError_t {                                                                 \
       int dev = 0;                                                                                           \
       (void)hipGetDevice(&dev);                                                                              \

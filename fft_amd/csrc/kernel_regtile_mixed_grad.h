@@ -154,7 +154,7 @@ hipError_t launch_gate_grad_mixed(const GateGradArgs& a, bool io_bf16, bool gene
     const dim3 grid(a.n_wg), block(mixed_threads<RF_, RS_>());                                               \
     const size_t lds = mixed_grad_lds_total<RF_, RS_>();                                                     \
     const int key = (io_bf16 ? 2 : 0) | (general ? 1 : 0);                                                   \
-    static bool lds_opt_in[16][4] = {};                                                                      \
+    static std::atomic<bool> lds_opt_in[16][4];                                                                      \
     auto go = [&](auto kern) -> hipError_t {                                                                 \
       int dev = 0;                                                                                           \
       (void)hipGetDevice(&dev);                                                                              \

@@ -232,7 +232,7 @@ inline hipError_t launch_regtile_quad(const RegtileArgs& a, bool in_bf16, bool o
   const dim3 grid(a.n_wg), block(512);
   const size_t lds = quad_image_bytes(RF);
   const int key = (in_bf16 ? 4 : 0) | mode;
-  static bool lds_opt_in[16][8] = {};
+  static std::atomic<bool> lds_opt_in[16][8];
   auto go = [&](auto kern) -> hipError_t {
     int dev = 0;
     (void)hipGetDevice(&dev);

@@ -40,6 +40,30 @@ def test_binding_matches_header(built_library):
     assert ctypes.sizeof(_native.SpectreMixArgs) == 4 * 8 + 9 * 8 + 4 * 4 + 8
 
 
+def test_every_abi_struct_has_the_layout_the_c_compiler_gives_the_header(tmp_path):
+    """sizeof and every field offset of the six argument structs: ctypes mirror (fft_amd/_native.py) vs gcc on include/spectre_hip.h."""
+    import subprocess
+    from fft_amd import _native
+    structs = ["SpectreMixArgs", "SpectreMixBwdArgs", "SpectreGateArgs", "SpectreRfftArgs", "SpectreDecodeArgs", "SpectreDecodeHeadArgs"]
+    lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "spectre_hip.h"', "int main(void) {"]
+    for sname in structs:
+        ct = getattr(_native, sname)
+        lines.append(f'  printf("{sname} %zu\\n", sizeof({sname}));')
+        for fname, _ in ct._fields_:
+            lines.append(f'  printf("{sname}.{fname} %zu\\n", offsetof({sname}, {fname}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "abi.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "abi"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = dict(l.split() for l in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
+    for sname in structs:
+        ct = getattr(_native, sname)
+        assert ctypes.sizeof(ct) == int(out[sname]), sname
+        for fname, _ in ct._fields_:
+            assert getattr(ct, fname).offset == int(out[f"{sname}.{fname}"]), f"{sname}.{fname}"
+
+
 def test_invalid_arguments_fail_loudly_without_a_gpu(built_library):
     from fft_amd import _native
     lib = _native.load()
