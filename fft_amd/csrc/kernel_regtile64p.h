@@ -37,12 +37,49 @@ __device__ __forceinline__ void lane16_swap(float& x, float& y) {   // x of the 
   y = __uint_as_float(r[1]);
 }
 
+// The 8 x 8 in-register transforms of fft_regs.h with a scheduling fence after every radix-8 butterfly: hipcc otherwise interleaves
+// all eight butterflies of a stage (up to 120 temporaries on top of the 128 data registers: the middle phase and I2's first stage
+// peak at 236 and 250 live VGPRs), and with the deferred-result registers of PF > 0 on top it parks those in scratch instead.
+// pin<BASE, STRIDE>: the eight values z[BASE + STRIDE j] have to exist in registers HERE.  sched_barrier only fences the machine
+// scheduler; the IR-level sinking pass still splits a butterfly and leaves half-finished sums alive until their first use
+// hundreds of instructions later (that, not the schedule, is where the 250-register peaks come from).
+template <int BASE, int STRIDE>
+__device__ __forceinline__ void pin8(float2 (&z)[64]) {
+  asm volatile("" : "+v"(z[BASE].x), "+v"(z[BASE].y), "+v"(z[BASE + STRIDE].x), "+v"(z[BASE + STRIDE].y),
+                    "+v"(z[BASE + 2 * STRIDE].x), "+v"(z[BASE + 2 * STRIDE].y), "+v"(z[BASE + 3 * STRIDE].x), "+v"(z[BASE + 3 * STRIDE].y),
+                    "+v"(z[BASE + 4 * STRIDE].x), "+v"(z[BASE + 4 * STRIDE].y), "+v"(z[BASE + 5 * STRIDE].x), "+v"(z[BASE + 5 * STRIDE].y),
+                    "+v"(z[BASE + 6 * STRIDE].x), "+v"(z[BASE + 6 * STRIDE].y), "+v"(z[BASE + 7 * STRIDE].x), "+v"(z[BASE + 7 * STRIDE].y));
+}
+
+template <bool INV, bool FENCE>
+__device__ __forceinline__ void p64_stageA1(float2 (&z)[64]) {      // type A stage 1: radix-8 over q1 (positions 8 q1 + q0), * W_64^(q0 ka)
+  static_for<0, 8>([&](auto q0c) {
+    constexpr int q0 = decltype(q0c)::value;
+    bfly<8, INV, q0, 8, 64>(z);
+    static_for<1, 8>([&](auto kac) { constexpr int ka = decltype(kac)::value; z[8 * ka + q0] = twid64<q0 * ka, INV>(z[8 * ka + q0]); });
+    if constexpr (FENCE) { pin8<q0, 8>(z); __builtin_amdgcn_sched_barrier(0); }
+  });
+}
+template <bool INV, bool FENCE>
+__device__ __forceinline__ void p64_stageB2(float2 (&z)[64]) {      // type B stage 2: radix-8 over ka (positions 8 ka + n_lo)
+  static_for<0, 8>([&](auto nc) {
+    bfly<8, INV, decltype(nc)::value, 8, 64>(z);
+    if constexpr (FENCE) { pin8<decltype(nc)::value, 8>(z); __builtin_amdgcn_sched_barrier(0); }
+  });
+}
+
 // SPLIT = row groups (of 8) of the next tile that travel through LDS (0: everything is loaded behind the stores).
-template <int SPLIT, int ABL = 0>
+// PF    = row groups whose I/O is moved out of the store/load burst into the exchange / middle phase, when no other memory
+//         traffic of this CU (and, the chip running in lock-step, of hardly any CU) is in flight: the results of the last PF
+//         groups of tile t stay in 16 PF registers through F1 of tile t+1 and are stored right before E1; the same registers
+//         then receive those groups of tile t+2, which trade places with the next results at the end of I2.
+template <int SPLIT, int PF = 0, int ABL = 0, bool FEN = (PF > 0)>
 __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileArgs a) {
   constexpr int RW = 8 * 68, PS = 68;              // image row / column strides in floats (kernel_regtile.h, 16-byte layout)
   constexpr float inv_n = 1.0f / 4096.0f;
   static_assert(SPLIT >= 0 && SPLIT <= 4 && SPLIT * 4 * 1024 * 8 <= kP64ImageBytes, "staging lives in the exchange image");
+  static_assert(PF >= 0 && SPLIT + PF <= 8, "row groups: SPLIT through LDS, PF deferred / prefetched in registers, the rest behind their stores");
+  constexpr int GP = 8 - PF;                       // first deferred / prefetched group
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* img = reinterpret_cast<float*>(smem);
   float2* glds = reinterpret_cast<float2*>(smem + kP64ImageBytes);
@@ -72,6 +109,8 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
     if constexpr ((ABL & 16) != 0) { if (threadIdx.x == 0) a.trace[((size_t)blockIdx.x * a.tpw + it) * 8 + slot] = wall_clock64(); }
   };
   float2 z[64];
+  float4 dfr[PF > 0 ? 4 * PF : 1];                 // deferred results of the previous tile / prefetched rows of the next one
+  char* obp = nullptr;                             // output tile of the deferred results
   float2 gstage[5];      // the next tile's gate bins on their way to LDS (4097 bins / 512 threads, rounded up; + 1 for the last)
 
   auto tile_ptrs = [&](int tile, const char*& vb, char*& ob, const float2*& gp) {
@@ -174,18 +213,42 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
       swap_group(gc);
       bfly<8, false, 8 * g, 1, 64>(z);             // over e -> ka at position 8g + ka
       static_for<1, 8>([&](auto kac) { constexpr int ka = decltype(kac)::value; z[8 * g + ka] = twid64<g * ka, false>(z[8 * g + ka]); });
+      if constexpr (FEN) { pin8<8 * g, 1>(z); __builtin_amdgcn_sched_barrier(0); }
     });
     gate_commit();                                 // this tile's gate bins (fetched behind the previous tile's stores) -> LDS
     {
       float2 wa[8], wb[8];
       __builtin_amdgcn_sched_barrier(0);           // keep the base loads (and their registers) out of stage 1
       static_for<1, 8>([&](auto jc) { constexpr int j = decltype(jc)::value; wa[j] = a.tw[u * j]; wb[j] = a.tw[u * 8 * j]; });
-      static_for<0, 8>([&](auto kac) { bfly<8, false, decltype(kac)::value, 8, 64>(z); });   // over g -> kb at position 8kb + ka: k1 = position
+      static_for<0, 8>([&](auto kac) {                                                        // over g -> kb at position 8kb + ka: k1 = position
+        bfly<8, false, decltype(kac)::value, 8, 64>(z);
+        if constexpr (FEN) { pin8<decltype(kac)::value, 8>(z); __builtin_amdgcn_sched_barrier(0); }
+      });
       static_for<1, 64>([&](auto jc) {
         constexpr int j = decltype(jc)::value, ka = j % 8, kb = j / 8;
         if constexpr (ka > 0) z[j] = cmul(z[j], wa[ka]);
         if constexpr (kb > 0) z[j] = cmul(z[j], wb[kb]);
+        if constexpr (FEN && ka == 7) { pin8<8 * kb, 1>(z); __builtin_amdgcn_sched_barrier(0); }   // one wb at a time
       });
+    }
+
+    // ---- the quiet part of the tile starts: flush the deferred results of the previous tile, request the same row groups
+    //      of the next tile into the registers they leave
+    if constexpr (PF > 0) {
+      const uint32_t ooff = (uint32_t)(((long long)(u + 512 * h) * out_sn + 4 * pp) * 4);
+      const uint32_t voff = (uint32_t)(((long long)(u + 512 * h) * v_sn + 4 * pp) * 4);
+      if (it > 0) {
+        static_for<0, 4 * PF>([&](auto ic) {
+          constexpr int g = GP + decltype(ic)::value / 4, m = decltype(ic)::value % 4;
+          *reinterpret_cast<float4*>(obp + (size_t)(64 * g + 1024 * m) * out_sn * 4 + ooff) = dfr[decltype(ic)::value];
+        });
+      }
+      if (more) {
+        static_for<0, 4 * PF>([&](auto ic) {
+          constexpr int g = GP + decltype(ic)::value / 4, m = decltype(ic)::value % 4;
+          dfr[decltype(ic)::value] = *reinterpret_cast<const float4*>(vbn + (size_t)(64 * g + 1024 * m) * v_sn * 4 + voff);
+        });
+      }
     }
 
     // ---- E1: position k1 -> image row k1, column (p, u); thread (p, s = u) reads row u, slot n2 ---------------------------
@@ -199,25 +262,31 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
     // ---- middle: F2 -> gate -> I1 (kernel_regtile.h; bin of register (ka, kb): k = k1 + 64 k2, k2 = ka + 8 kb) -------------
     {
       const int k1 = u;
-      fftA_stage1<8, 8, false>(z);
+      p64_stageA1<false, FEN>(z);
       auto fetch_gate = [&](int k2, bool upper) -> float2 {
         float2 g = glds[upper ? 64 * (64 - k2) - k1 : k1 + 64 * k2];      // scaled by 1/N, edges fixed, conj applied
         if (upper) g.y = -g.y;                                          // Hermitian extension above N/2
         return g;
       };
-      float2 gcur[8], gnxt[8];
+      // With deferred / prefetched groups (PF > 0) the gate bins of one register group are fetched right where they are used
+      // (16 registers); otherwise the next group's bins are prefetched while this group's butterflies run (32 registers).
+      float2 gcur[8], gnxt[FEN ? 1 : 8];
       static_for<0, 8>([&](auto kbc) { constexpr int k2 = 8 * decltype(kbc)::value; gcur[decltype(kbc)::value] = fetch_gate(k2, k2 >= 32); });
       static_for<0, 8>([&](auto kac) {
         constexpr int ka = decltype(kac)::value;
-        if constexpr (ka + 1 < 8)
+        if constexpr (ka + 1 < 8 && !FEN)
           static_for<0, 8>([&](auto kbc) { constexpr int k2n = ka + 1 + 8 * decltype(kbc)::value; gnxt[decltype(kbc)::value] = fetch_gate(k2n, k2n >= 32); });
         fftA_stage2_group<8, 8, false, ka>(z);
         static_for<0, 8>([&](auto kbc) { constexpr int kb = decltype(kbc)::value; z[8 * ka + kb] = cmul(z[8 * ka + kb], gcur[kb]); });   // spectre.py:545
+        if constexpr (FEN) { pin8<8 * ka, 1>(z); __builtin_amdgcn_sched_barrier(0); }
+        if constexpr (ka + 1 < 8 && FEN)
+          static_for<0, 8>([&](auto kbc) { constexpr int k2n = ka + 1 + 8 * decltype(kbc)::value; gcur[decltype(kbc)::value] = fetch_gate(k2n, k2n >= 32); });
         fftB_stage1_group<8, 8, true, ka>(z);
-        if constexpr (ka + 1 < 8) static_for<0, 8>([&](auto kbc) { gcur[decltype(kbc)::value] = gnxt[decltype(kbc)::value]; });
+        if constexpr (FEN) pin8<8 * ka, 1>(z);
+        if constexpr (ka + 1 < 8 && !FEN) static_for<0, 8>([&](auto kbc) { gcur[decltype(kbc)::value] = gnxt[decltype(kbc)::value]; });
         __builtin_amdgcn_sched_barrier(0);         // keep the gate prefetch one group deep (register budget)
       });
-      fftB_stage2<8, 8, true>(z);                  // natural order: position n2
+      p64_stageB2<true, FEN>(z);              // natural order: position n2
     }
 
     // ---- E2: position n2 -> image row n2, column (p, k1 = u); thread (p, u) reads row u, slot k1 --------------------------
@@ -241,23 +310,39 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
         constexpr int j = decltype(jc)::value, ja = j % 8, jb = j / 8;   // position j carries k1 = j
         if constexpr (ja > 0) z[j] = cmulc(z[j], wa[ja]);
         if constexpr (jb > 0) z[j] = cmulc(z[j], wb[jb]);
+        if constexpr (FEN && ja == 7) { pin8<8 * jb, 1>(z); __builtin_amdgcn_sched_barrier(0); }
       });
-      fftA_stage1<8, 8, true>(z);
+      if constexpr (FEN) __builtin_amdgcn_sched_barrier(0);
+      p64_stageA1<true, FEN>(z);
     }
     {
       const uint32_t ooff = (uint32_t)(((long long)(u + 512 * h) * out_sn + 4 * pp) * 4);
       static_for<0, 8>([&](auto ic) {
         constexpr int g = (decltype(ic)::value + SPLIT) % 8;             // register-loaded groups first: their reloads start earliest
         fftA_stage2_group<8, 8, true, g>(z);                              // rows g + 8e at positions 8g + e
+        if constexpr (FEN) pin8<8 * g, 1>(z);
         swap_group(std::integral_constant<int, g>{});
         static_for<0, 4>([&](auto mc) {
           constexpr int m = decltype(mc)::value;
-          *reinterpret_cast<float4*>(ob + (size_t)(64 * g + 1024 * m) * out_sn * 4 + ooff) =
-              make_float4(z[8 * g + 2 * m].x, z[8 * g + 2 * m].y, z[8 * g + 2 * m + 1].x, z[8 * g + 2 * m + 1].y);
+          const float4 res = make_float4(z[8 * g + 2 * m].x, z[8 * g + 2 * m].y, z[8 * g + 2 * m + 1].x, z[8 * g + 2 * m + 1].y);
+          if constexpr (g >= GP) {
+            if (more) {                              // trade places: results wait for the next quiet part, the prefetched rows move in
+              const float4 nx = dfr[4 * (g - GP) + m];
+              dfr[4 * (g - GP) + m] = res;
+              z[8 * g + 2 * m] = make_float2(nx.x, nx.y);
+              z[8 * g + 2 * m + 1] = make_float2(nx.z, nx.w);
+            } else {
+              *reinterpret_cast<float4*>(ob + (size_t)(64 * g + 1024 * m) * out_sn * 4 + ooff) = res;
+            }
+          } else {
+            *reinterpret_cast<float4*>(ob + (size_t)(64 * g + 1024 * m) * out_sn * 4 + ooff) = res;
+          }
         });
-        if constexpr (g >= SPLIT) { if (more) load_group(vbn, voff, v_sn, std::integral_constant<int, g>{}); }
+        if constexpr (g >= SPLIT && g < GP) { if (more) load_group(vbn, voff, v_sn, std::integral_constant<int, g>{}); }
+        if constexpr (FEN) __builtin_amdgcn_sched_barrier(0);
       });
     }
+    obp = ob;
     gate_fetch(gpn);                               // committed to LDS after F1's first stage of the next tile (after the last tile:
                                                    // a harmless re-read of this tile's bins — keeps the staging registers out of a loop-carried phi)
     stamp(it, 5);

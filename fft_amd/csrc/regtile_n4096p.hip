@@ -5,7 +5,12 @@
 namespace sfft {
 hipError_t launch_regtile64p(const RegtileArgs& a, hipStream_t stream) {
   static std::atomic<bool> lds_opt_in[16];   // [device]: > 64 KiB of dynamic LDS needs a one-time opt-in (idempotent; the flag only saves the call)
-  auto kern = spectre_mix_regtile64p<4>;   // 4 of the 8 row groups of the next tile travel through the exchange image
+  // PF (row groups whose stores / loads are moved into the exchange / middle phase) is a tuning aid: measured at (256,4096,768)
+  // it changes nothing within the +-3 % run-to-run noise (PF = 1) or loses 3-5 % (PF = 2: three spilled registers) — the CUs of
+  // the persistent kernel are NOT in lock-step any more (profiles/r02_trace64p_pf.log), so there is no quiet phase to fill.
+  static const int pf = [] { const char* e = getenv("SPECTRE_P64_PF"); return e ? atoi(e) : 0; }();
+  auto kern = pf == 2 ? spectre_mix_regtile64p<4, 2> : pf == 1 ? spectre_mix_regtile64p<4, 1> : pf == -1 ? spectre_mix_regtile64p<4, 0, 0, true>
+                                                                                                          : spectre_mix_regtile64p<4, 0>;
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev < 0 || dev >= 16 || !lds_opt_in[dev]) {

@@ -19,11 +19,12 @@ for (B, D, G) in [(1, 16, 1), (3, 64, 4), (2, 48, 3), (5, 80, 5), (37, 112, 7), 
             ref = spectral_mix_numpy(V.cpu().numpy(), g.cpu().numpy(), None, N)
             err = assert_close(y.cpu().numpy(), ref, what="p64")
         else:   # column spot check
-            idx = [(0, 0), (B - 1, D - 1), (B // 2, 17), (7, D // 2 + 1), (B - 2, 16 * 13 + 5)]
+            idx = [(0, 0), (B - 1, D - 1), (B // 2, 17), (7, D // 2 + 1), (B - 2, (16 * 13 + 5) % D)]
             err = 0.0
             for (b, c) in idx:
                 c0 = c // 2 * 2
-                ref = spectral_mix_numpy(V[b:b+1, :, c0:c0+2].cpu().numpy(), g[b:b+1, (c0 * G) // D:(c0 * G) // D + 1].cpu().numpy(), None, N)
+                grp = c0 // (D // G)
+                ref = spectral_mix_numpy(V[b:b+1, :, c0:c0+2].cpu().numpy(), g[b:b+1, grp:grp + 1].cpu().numpy(), None, N)
                 err = max(err, assert_close(y[b:b+1, :, c0:c0+2].cpu().numpy(), ref, what="p64 col"))
         print(f"OK   ({B},{N},{D}) G={G} err/rms={err:.2e} [{desc}]")
     except Exception as e:

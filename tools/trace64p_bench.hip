@@ -12,9 +12,9 @@
 using namespace sfft;
 static double pct(std::vector<double> v, double p) { if (v.empty()) return 0; std::sort(v.begin(), v.end()); return v[(size_t)(p * (v.size() - 1))]; }
 
-template <int SPLIT, int ABLX = 0>
+template <int SPLIT, int PF = 0, bool FEN = (PF > 0)>
 void run(const char* name, RegtileArgs a, int tpw) {
-  auto kern = spectre_mix_regtile64p<SPLIT, 16 | ABLX>;
+  auto kern = spectre_mix_regtile64p<SPLIT, PF, 16, FEN>;
   a.tiles_per_row = a.D / 16; a.n_tiles = a.B * a.tiles_per_row;
   a.tpw = tpw; a.n_wg = 2 * ((a.n_tiles + 2 * tpw - 1) / (2 * tpw));
   unsigned long long* tr;
@@ -39,7 +39,7 @@ void run(const char* name, RegtileArgs a, int tpw) {
       for (int k = 0; k < 5; ++k) d[k].push_back((t[k + 1] - t[k]) * 0.01);
       d[5].push_back((h[((size_t)w * tpw + it + 1) * 8] - t[0]) * 0.01);
     }
-  printf("== %s SPLIT=%d tpw=%d: %.3f ms, %.1f us per tile per CU\n", name, SPLIT, tpw, ms, ms * 1e3 * 256 / a.n_tiles);
+  printf("== %s SPLIT=%d PF=%d tpw=%d: %.3f ms, %.1f us per tile per CU\n", name, SPLIT, PF, tpw, ms, ms * 1e3 * 256 / a.n_tiles);
   for (int k = 0; k < 6; ++k) { double s = 0; for (double x : d[k]) s += x; printf("   %-52s p10 %6.2f p50 %6.2f p90 %6.2f mean %6.2f us\n", nm[k], pct(d[k], .1), pct(d[k], .5), pct(d[k], .9), s / std::max<size_t>(1, d[k].size())); }
   // lock-step census: number of workgroups inside "top -> F1 start" at 200 instants
   unsigned long long tmin = ~0ull, tmax = 0;
@@ -48,11 +48,11 @@ void run(const char* name, RegtileArgs a, int tpw) {
   for (int i = 0; i < 200; ++i) {
     const unsigned long long t = tmin + (unsigned long long)((tmax - tmin) * (0.15 + 0.7 * i / 199.0));
     int c = 0;
-    for (size_t r = 0; r < nrec; ++r) if (h[r * 8] <= t && t < h[r * 8 + 1]) ++c;
+    for (size_t r = 0; r + 1 < nrec; ++r) if (h[r * 8 + 4] && h[r * 8 + 4] <= t && h[(r + 1) * 8 + 1] && t < h[(r + 1) * 8 + 1] && ((r + 1) % tpw) != 0) ++c;
     nw.push_back(c);
   }
   double m = 0, q = 0; for (double x : nw) m += x; m /= nw.size(); for (double x : nw) q += (x - m) * (x - m);
-  printf("   workgroups waiting for their tile at an instant: %.1f +- %.1f\n", m, std::sqrt(q / nw.size()));
+  printf("   workgroups inside their store/load burst (after E2 .. next F1) at an instant: %.1f +- %.1f of %d\n", m, std::sqrt(q / nw.size()), a.n_wg);
   fflush(stdout);
 }
 
@@ -77,8 +77,9 @@ int main() {
   a.v = v; a.gate = gate; a.mem = nullptr; a.out = out; a.tw = tw;
   a.B = B; a.N_in = N; a.D = D; a.G = G; a.d_g = D / G; a.F = F;
   a.v_sb = (long long)N * D; a.v_sn = D; a.out_sb = (long long)N * D; a.out_sn = D;
-  run<4>("pipelined", a, 48);
-  run<0>("pipelined", a, 48);
-  run<4>("pipelined", a, 2);
+  run<4, 0>("pipelined", a, 48);
+  run<4, 0, true>("pipelined fenced", a, 48);
+  run<4, 1>("pipelined", a, 48);
+  run<4, 2>("pipelined", a, 48);
   return 0;
 }
