@@ -5,10 +5,10 @@
 namespace sfft {
 hipError_t launch_regtile64p(const RegtileArgs& a, hipStream_t stream) {
   static std::atomic<bool> lds_opt_in[16];   // [device]: > 64 KiB of dynamic LDS needs a one-time opt-in (idempotent; the flag only saves the call)
-  // PF (row groups whose stores / loads are moved into the exchange / middle phase) is a tuning aid: measured at (256,4096,768)
-  // it changes nothing within the +-3 % run-to-run noise (PF = 1) or loses 3-5 % (PF = 2: three spilled registers) — the CUs of
-  // the persistent kernel are NOT in lock-step any more (profiles/r02_trace64p_pf.log), so there is no quiet phase to fill.
-  static const int pf = [] { const char* e = getenv("SPECTRE_P64_PF"); return e ? atoi(e) : 0; }();
+  // PF = row groups whose stores / loads are moved into the exchange / middle phase.  Interleaved A/B on one box
+  // (tools/p64_ab_bench.hip, profiles/r02_p64_ab.log): PF = 0 1.792 ms, PF = 1 1.761 ms, PF = 2 1.823 ms (register pressure in the
+  // middle phase); SPLIT = 4 / 3 / 2 groups through LDS: 1.792 / 1.822 / 2.007 ms; round-1 kernel 1.918 ms.  SPECTRE_P64_PF overrides.
+  static const int pf = [] { const char* e = getenv("SPECTRE_P64_PF"); return e ? atoi(e) : 1; }();
   auto kern = pf == 2 ? spectre_mix_regtile64p<4, 2> : pf == 1 ? spectre_mix_regtile64p<4, 1> : pf == -1 ? spectre_mix_regtile64p<4, 0, 0, true>
                                                                                                           : spectre_mix_regtile64p<4, 0>;
   int dev = 0;

@@ -1,0 +1,83 @@
+// p64_ab_bench — A/B timing of variants of the pipelined 4096 kernel in ONE process, interleaved round-robin (box-to-box and
+// DVFS drift is +-3 %: only interleaved runs on one box separate small effects).  (256, 4096, 768) fp32, random data.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize tools/p64_ab_bench.hip -o tools/p64_ab_bench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <string>
+#include <functional>
+#include <cmath>
+#include <algorithm>
+#include <cstdint>
+#include "../fft_amd/csrc/kernel_regtile64p.h"
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
+using namespace sfft;
+
+struct Variant { std::string name; std::function<void()> launch; std::vector<float> ms; };
+
+template <class K> std::function<void()> make(K kern, RegtileArgs a, int tpw, size_t lds) {
+  a.tiles_per_row = a.D / 16; a.n_tiles = a.B * a.tiles_per_row;
+  a.tpw = tpw; a.n_wg = 2 * ((a.n_tiles + 2 * tpw - 1) / (2 * tpw));
+  CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  return [=] { hipLaunchKernelGGL(kern, dim3(a.n_wg), dim3(512), lds, 0, a); };
+}
+
+int main() {
+  const int B = 256, N = 4096, D = 768, G = 4, F = N / 2 + 1;
+  float *v, *out; float2 *gate, *tw;
+  CK(hipMalloc(&v, (size_t)B * N * D * 4)); CK(hipMalloc(&out, (size_t)B * N * D * 4));
+  CK(hipMalloc(&gate, (size_t)B * G * F * 8)); CK(hipMalloc(&tw, N * 8));
+  {
+    std::vector<float> hr(1 << 24);
+    uint32_t st = 12345u;
+    for (auto& x : hr) { st = st * 1664525u + 1013904223u; x = ((st >> 8) & 0xffff) / 32768.0f - 1.0f; }
+    for (size_t off = 0; off < (size_t)B * N * D; off += hr.size())
+      CK(hipMemcpy(v + off, hr.data(), std::min(hr.size(), (size_t)B * N * D - off) * 4, hipMemcpyHostToDevice));
+    for (size_t off = 0; off < (size_t)B * G * F * 2; off += hr.size())
+      CK(hipMemcpy((float*)gate + off, hr.data(), std::min(hr.size(), (size_t)B * G * F * 2 - off) * 4, hipMemcpyHostToDevice));
+  }
+  std::vector<float2> h(N);
+  for (int m = 0; m < N; ++m) h[m] = make_float2((float)cos(2 * M_PI * m / N), (float)-sin(2 * M_PI * m / N));
+  CK(hipMemcpy(tw, h.data(), N * 8, hipMemcpyHostToDevice));
+  RegtileArgs a{};
+  a.v = v; a.gate = gate; a.mem = nullptr; a.out = out; a.tw = tw;
+  a.B = B; a.N_in = N; a.D = D; a.G = G; a.d_g = D / G; a.F = F;
+  a.v_sb = (long long)N * D; a.v_sn = D; a.out_sb = (long long)N * D; a.out_sn = D;
+
+  std::vector<Variant> vs;
+  {  // the round-1 kernel, one tile per workgroup
+    RegtileArgs o = a; o.tiles_per_row = D / 16; o.n_tiles = B * (D / 16); o.tpw = 1; o.n_wg = o.n_tiles;
+    auto kern = spectre_mix_regtile<64, 64, false, false, 0, 0, 1>;
+    const size_t lds = regtile_lds_total<64, 64, 1>();
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    vs.push_back({"round-1 regtile<64,64> (one tile per workgroup)", [=] { hipLaunchKernelGGL(kern, dim3(o.n_wg), dim3(512), lds, 0, o); }, {}});
+  }
+  vs.push_back({"pipelined SPLIT=4 PF=0           tpw=48", make(spectre_mix_regtile64p<4, 0, 0, false>, a, 48, kP64LdsTotal), {}});
+  vs.push_back({"pipelined SPLIT=4 PF=0 fenced    tpw=48", make(spectre_mix_regtile64p<4, 0, 0, true>, a, 48, kP64LdsTotal), {}});
+  vs.push_back({"pipelined SPLIT=4 PF=1           tpw=48", make(spectre_mix_regtile64p<4, 1, 0, true>, a, 48, kP64LdsTotal), {}});
+  vs.push_back({"pipelined SPLIT=4 PF=2           tpw=48", make(spectre_mix_regtile64p<4, 2, 0, true>, a, 48, kP64LdsTotal), {}});
+  vs.push_back({"pipelined SPLIT=3 PF=0           tpw=48", make(spectre_mix_regtile64p<3, 0, 0, false>, a, 48, kP64LdsTotal), {}});
+  vs.push_back({"pipelined SPLIT=2 PF=0           tpw=48", make(spectre_mix_regtile64p<2, 0, 0, false>, a, 48, kP64LdsTotal), {}});
+  vs.push_back({"pipelined SPLIT=4 PF=0           tpw=2 ", make(spectre_mix_regtile64p<4, 0, 0, false>, a, 2, kP64LdsTotal), {}});
+  vs.push_back({"pipelined SPLIT=4 PF=0           tpw=1 ", make(spectre_mix_regtile64p<4, 0, 0, false>, a, 1, kP64LdsTotal), {}});
+  vs.push_back({"pipelined SPLIT=4 PF=0 fenced    tpw=2 ", make(spectre_mix_regtile64p<4, 0, 0, true>, a, 2, kP64LdsTotal), {}});
+
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (auto& x : vs) { x.launch(); x.launch(); }
+  CK(hipDeviceSynchronize());
+  for (int round = 0; round < 6; ++round)
+    for (auto& x : vs) {
+      CK(hipEventRecord(e0));
+      for (int i = 0; i < 5; ++i) x.launch();
+      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1)); x.ms.push_back(ms / 5);
+    }
+  const double bytes = 2.0 * B * N * D * 4 + (double)B * G * F * 8;
+  for (auto& x : vs) {
+    std::sort(x.ms.begin(), x.ms.end());
+    const float med = x.ms[x.ms.size() / 2];
+    printf("%-52s min %.3f  median %.3f  max %.3f ms   %.0f GB/s  frac %.3f\n", x.name.c_str(), x.ms.front(), med, x.ms.back(), bytes / med / 1e6, bytes / med / 1e6 / 8000);
+  }
+  return 0;
+}

@@ -40,3 +40,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "time":
     for rep in range(3):
         ms = time_kernel(V, g, None, N, out=out, warmup=3, iters=10)
         print(f"TIME (256,4096,768) f32: {ms:.3f} ms  {byt/ms/1e6:.0f} GB/s  frac={byt/ms/1e6/8000:.3f} [{describe(V,g,None,N)}]")
+    for (tin, tout) in ((torch.bfloat16, torch.bfloat16), (torch.bfloat16, torch.float32)):
+        Vb = V.to(tin); ob = torch.empty(B, N, D, dtype=tout, device=dev)
+        bytb = B * N * D * (Vb.element_size() + ob.element_size()) + B * G * (N // 2 + 1) * 8
+        for rep in range(2):
+            ms = time_kernel(Vb, g, None, N, out=ob, warmup=3, iters=10)
+            print(f"TIME (256,4096,768) {str(tin)[6:]}->{str(tout)[6:]}: {ms:.3f} ms  {bytb/ms/1e6:.0f} GB/s  frac={bytb/ms/1e6/8000:.3f} [{describe(Vb,g,None,N,out_dtype=tout)}]")
