@@ -1,5 +1,7 @@
-// kernel_regtile64p.h — persistent, software-pipelined spectral mix for n_fft = 4096 = 64 x 64 on gfx950 (fast mode:
-// N_in >= n_fft, no memory_fft, every 16-channel tile inside one gate group, 16-byte aligned fp32 rows).
+// kernel_regtile64p.h — persistent, software-pipelined spectral mix for n_fft = 4096 = 64 x 64 on gfx950 (no memory_fft, every
+// 16-channel tile inside one gate group, 16-byte aligned fp32 rows; ANY sequence length: rows beyond N_in are the buffer
+// instructions' out-of-range case — loads return 0 = rfft's zero padding (spectre.py:506), stores are dropped (spectre.py:553) —
+// so a padded sequence costs exactly what a full one costs, without a single predicate).
 //
 // Same mathematics and the same register-tile plan as kernel_regtile.h (one workgroup owns 16 channels x 4096 rows; F1 ->
 // twiddle -> E1 -> F2 -> gate -> I1 -> E2 -> conj twiddle -> I2; replaces /root/reference/spectre.py:506 + :542-553), rebuilt
@@ -30,6 +32,9 @@ namespace sfft {
 
 constexpr int kP64ImageBytes = regtile_image_bytes<64, 64, 1>();
 constexpr int kP64LdsTotal = regtile_lds_total<64, 64, 1>();
+
+typedef unsigned int p64_u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kP64RsrcFlags = 0x00020000;        // raw buffer, 32-bit data format (gfx90a / gfx942 / gfx950 dword 3)
 
 __device__ __forceinline__ void lane16_swap(float& x, float& y) {   // x of the odd 16-lane rows <-> y of the even rows
   const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
@@ -73,13 +78,14 @@ __device__ __forceinline__ void p64_stageB2(float2 (&z)[64]) {      // type B st
 //         traffic of this CU (and, the chip running in lock-step, of hardly any CU) is in flight: the results of the last PF
 //         groups of tile t stay in 16 PF registers through F1 of tile t+1 and are stored right before E1; the same registers
 //         then receive those groups of tile t+2, which trade places with the next results at the end of I2.
-template <int SPLIT, int PF = 0, int ABL = 0, bool FEN = (PF > 0)>
+template <int SPLIT, int PF = 0, int ABL = 0, bool FEN = (PF > 0), bool WITH_MEM = false>
 __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileArgs a) {
   constexpr int RW = 8 * 68, PS = 68;              // image row / column strides in floats (kernel_regtile.h, 16-byte layout)
   constexpr float inv_n = 1.0f / 4096.0f;
   static_assert(SPLIT >= 0 && SPLIT <= 4 && SPLIT * 4 * 1024 * 8 <= kP64ImageBytes, "staging lives in the exchange image");
   static_assert(PF >= 0 && SPLIT + PF <= 8, "row groups: SPLIT through LDS, PF deferred / prefetched in registers, the rest behind their stores");
   constexpr int GP = 8 - PF;                       // first deferred / prefetched group
+  static_assert(!WITH_MEM || FEN, "memory_fft: one register group of gate bins and memory rows at a time");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* img = reinterpret_cast<float*>(smem);
   float2* glds = reinterpret_cast<float2*>(smem + kP64ImageBytes);
@@ -121,23 +127,37 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
   };
   // row of this lane in load / store instruction (g, m):  u + 512 h + 64 g + 1024 m; addresses = workgroup-uniform base of the
   // instruction (SGPRs) + one 32-bit lane offset (spectre_hip.hip bounds 4095 * row stride * 4 + 64 below 2^31)
-  auto load_group = [&](const char* vb, uint32_t voff, long long sn, auto gc) {       // straight into the registers of group g
+  // Buffer resources: base = the tile's first row, num_records = the bytes of its rows below N_in.  The range check covers the
+  // VGPR offset (lane offset + row-block offset; the SGPR offset operand is not checked on gfx9), so both go there.
+  auto rsrc_in = [&](const char* vb, long long sn) {
+    const int rows = a.N_in < 4096 ? a.N_in : 4096;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(vb), 0, (int)((long long)rows * sn * 4), kP64RsrcFlags);
+  };
+  auto rsrc_out = [&](char* ob, long long sn) {
+    const int rows = a.N_in < 4096 ? a.N_in : 4096;
+    return __builtin_amdgcn_make_buffer_rsrc(ob, 0, (int)((long long)rows * sn * 4), kP64RsrcFlags);
+  };
+  auto load_group = [&](__amdgpu_buffer_rsrc_t rs, uint32_t voff, long long sn, auto gc) {       // straight into the registers of group g
     constexpr int g = decltype(gc)::value;
     static_for<0, 4>([&](auto mc) {
       constexpr int m = decltype(mc)::value;
-      const float4 t = *reinterpret_cast<const float4*>(vb + (size_t)(64 * g + 1024 * m) * sn * 4 + voff);
-      z[8 * g + 2 * m] = make_float2(t.x, t.y);
-      z[8 * g + 2 * m + 1] = make_float2(t.z, t.w);
+      const p64_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + (uint32_t)((64 * g + 1024 * m) * sn * 4), 0, 0);
+      z[8 * g + 2 * m] = make_float2(__uint_as_float(t.x), __uint_as_float(t.y));
+      z[8 * g + 2 * m + 1] = make_float2(__uint_as_float(t.z), __uint_as_float(t.w));
     });
   };
-  auto dma_group = [&](const char* vb, uint32_t voff, long long sn, auto gc) {        // into this wave's LDS slots (1 KiB per instruction)
+  auto dma_group = [&](__amdgpu_buffer_rsrc_t rs, uint32_t voff, long long sn, auto gc) {        // into this wave's LDS slots (1 KiB per instruction)
     constexpr int g = decltype(gc)::value;
     static_for<0, 4>([&](auto mc) {
       constexpr int m = decltype(mc)::value;
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(vb + (size_t)(64 * g + 1024 * m) * sn * 4 + voff),
-          (__attribute__((address_space(3))) void*)(slot + (4 * g + m) * 1024), 16, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(slot + (4 * g + m) * 1024), 16,
+                                               voff + (uint32_t)((64 * g + 1024 * m) * sn * 4), 0, 0, 0);
     });
+  };
+  auto store16 = [&](__amdgpu_buffer_rsrc_t rs, uint32_t off, const float4 v) {
+    p64_u32x4 t;
+    t.x = __float_as_uint(v.x); t.y = __float_as_uint(v.y); t.z = __float_as_uint(v.z); t.w = __float_as_uint(v.w);
+    __builtin_amdgcn_raw_buffer_store_b128(t, rs, off, 0, 0);
   };
   auto read_group = [&](auto gc) {                                       // this lane's 16 bytes back out of the slot
     constexpr int g = decltype(gc)::value;
@@ -180,9 +200,10 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
     const char* vb; char* ob; const float2* gp;
     tile_ptrs(pair_base, vb, ob, gp);
     const uint32_t voff = (uint32_t)(((long long)(u + 512 * h) * a.v_sn + 4 * pp) * 4);
-    static_for<0, SPLIT>([&](auto gc) { dma_group(vb, voff, a.v_sn, gc); });
+    const __amdgpu_buffer_rsrc_t rs = rsrc_in(vb, a.v_sn);
+    static_for<0, SPLIT>([&](auto gc) { dma_group(rs, voff, a.v_sn, gc); });
     asm volatile("" ::: "memory");
-    static_for<SPLIT, 8>([&](auto gc) { load_group(vb, voff, a.v_sn, gc); });
+    static_for<SPLIT, 8>([&](auto gc) { load_group(rs, voff, a.v_sn, gc); });
     gate_fetch(gp);
   }
 
@@ -197,6 +218,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
     tile_ptrs(tile, vb, ob, gp);
     const char* vbn = vb; char* obn = ob; const float2* gpn = gp;
     if (more) tile_ptrs(tile + 2, vbn, obn, gpn);
+    const __amdgpu_buffer_rsrc_t rs_next = rsrc_in(vbn, v_sn), rs_out = rsrc_out(ob, out_sn);
 
     stamp(it, 0);
     // ---- the tile arrives: LDS-staged groups first (requested before the previous tile's stores; completion is in order, so
@@ -240,13 +262,14 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
       if (it > 0) {
         static_for<0, 4 * PF>([&](auto ic) {
           constexpr int g = GP + decltype(ic)::value / 4, m = decltype(ic)::value % 4;
-          *reinterpret_cast<float4*>(obp + (size_t)(64 * g + 1024 * m) * out_sn * 4 + ooff) = dfr[decltype(ic)::value];
+          store16(rsrc_out(obp, out_sn), ooff + (uint32_t)((64 * g + 1024 * m) * out_sn * 4), dfr[decltype(ic)::value]);
         });
       }
       if (more) {
         static_for<0, 4 * PF>([&](auto ic) {
           constexpr int g = GP + decltype(ic)::value / 4, m = decltype(ic)::value % 4;
-          dfr[decltype(ic)::value] = *reinterpret_cast<const float4*>(vbn + (size_t)(64 * g + 1024 * m) * v_sn * 4 + voff);
+          const p64_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_next, voff + (uint32_t)((64 * g + 1024 * m) * v_sn * 4), 0, 0);
+          dfr[decltype(ic)::value] = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
         });
       }
     }
@@ -271,16 +294,45 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
       // With deferred / prefetched groups (PF > 0) the gate bins of one register group are fetched right where they are used
       // (16 registers); otherwise the next group's bins are prefetched while this group's butterflies run (32 registers).
       float2 gcur[8], gnxt[FEN ? 1 : 8];
-      static_for<0, 8>([&](auto kbc) { constexpr int k2 = 8 * decltype(kbc)::value; gcur[decltype(kbc)::value] = fetch_gate(k2, k2 >= 32); });
+      // memory_fft (spectre.py:548-549): row k of the (F, D) complex buffer, this lane's two channels = 16 bytes; one register
+      // group (8 bins) at a time, requested right after the previous group has been consumed (L2 / Infinity-Cache resident:
+      // 12.6 MB at the headline shape, re-read by every batch element).  These loads sit in the exchange / middle phase, when the
+      // CU has no other memory traffic in flight.
+      [[maybe_unused]] float4 mcur[WITH_MEM ? 8 : 1];
+      [[maybe_unused]] const float* mbase = nullptr;
+      if constexpr (WITH_MEM) mbase = a.mem + (size_t)((tile - (tile / a.tiles_per_row) * a.tiles_per_row) * 16 + 2 * p) * 2;
+      auto fetch_mem = [&](int k2, bool upper) -> float4 {
+        return *reinterpret_cast<const float4*>(mbase + (size_t)(upper ? 64 * (64 - k2) - k1 : k1 + 64 * k2) * a.D * 2);
+      };
+      static_for<0, 8>([&](auto kbc) {
+        constexpr int k2 = 8 * decltype(kbc)::value;
+        gcur[decltype(kbc)::value] = fetch_gate(k2, k2 >= 32);
+        if constexpr (WITH_MEM) mcur[decltype(kbc)::value] = fetch_mem(k2, k2 >= 32);
+      });
       static_for<0, 8>([&](auto kac) {
         constexpr int ka = decltype(kac)::value;
         if constexpr (ka + 1 < 8 && !FEN)
           static_for<0, 8>([&](auto kbc) { constexpr int k2n = ka + 1 + 8 * decltype(kbc)::value; gnxt[decltype(kbc)::value] = fetch_gate(k2n, k2n >= 32); });
         fftA_stage2_group<8, 8, false, ka>(z);
-        static_for<0, 8>([&](auto kbc) { constexpr int kb = decltype(kbc)::value; z[8 * ka + kb] = cmul(z[8 * ka + kb], gcur[kb]); });   // spectre.py:545
+        static_for<0, 8>([&](auto kbc) {
+          constexpr int kb = decltype(kbc)::value, j = 8 * ka + kb, k2 = ka + 8 * kb;
+          z[j] = cmul(z[j], gcur[kb]);                                   // spectre.py:545
+          if constexpr (WITH_MEM) {                                      // Mf[k] = mem_c[k] + i mem_{c+1}[k] below N/2, conj(mem_c[N-k]) + i conj(mem_{c+1}[N-k]) above
+            const float4 m = mcur[kb];
+            float2 add;
+            if ((k2 == 0 || k2 == 32) && k1 == 0) add = make_float2(m.x, m.z);          // DC, Nyquist: real parts only
+            else if (k2 >= 32)                    add = make_float2(m.x + m.w, m.z - m.y);
+            else                                  add = make_float2(m.x - m.w, m.y + m.z);
+            z[j].x += add.x * inv_n; z[j].y += add.y * inv_n;
+          }
+        });
         if constexpr (FEN) { pin8<8 * ka, 1>(z); __builtin_amdgcn_sched_barrier(0); }
         if constexpr (ka + 1 < 8 && FEN)
-          static_for<0, 8>([&](auto kbc) { constexpr int k2n = ka + 1 + 8 * decltype(kbc)::value; gcur[decltype(kbc)::value] = fetch_gate(k2n, k2n >= 32); });
+          static_for<0, 8>([&](auto kbc) {
+            constexpr int k2n = ka + 1 + 8 * decltype(kbc)::value;
+            gcur[decltype(kbc)::value] = fetch_gate(k2n, k2n >= 32);
+            if constexpr (WITH_MEM) mcur[decltype(kbc)::value] = fetch_mem(k2n, k2n >= 32);
+          });
         fftB_stage1_group<8, 8, true, ka>(z);
         if constexpr (FEN) pin8<8 * ka, 1>(z);
         if constexpr (ka + 1 < 8 && !FEN) static_for<0, 8>([&](auto kbc) { gcur[decltype(kbc)::value] = gnxt[decltype(kbc)::value]; });
@@ -298,7 +350,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
     // ---- the image is idle until the next E1: let the first row groups of the next tile land in it, and fetch its gate -----
     const uint32_t voff = (uint32_t)(((long long)(u + 512 * h) * v_sn + 4 * pp) * 4);
     if (more) {
-      static_for<0, SPLIT>([&](auto gc) { dma_group(vbn, voff, v_sn, gc); });
+      static_for<0, SPLIT>([&](auto gc) { dma_group(rs_next, voff, v_sn, gc); });
       asm volatile("" ::: "memory");               // the vmcnt() above counts on these being older than every store below
     }
 
@@ -332,13 +384,13 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
               z[8 * g + 2 * m] = make_float2(nx.x, nx.y);
               z[8 * g + 2 * m + 1] = make_float2(nx.z, nx.w);
             } else {
-              *reinterpret_cast<float4*>(ob + (size_t)(64 * g + 1024 * m) * out_sn * 4 + ooff) = res;
+              store16(rs_out, ooff + (uint32_t)((64 * g + 1024 * m) * out_sn * 4), res);
             }
           } else {
-            *reinterpret_cast<float4*>(ob + (size_t)(64 * g + 1024 * m) * out_sn * 4 + ooff) = res;
+            store16(rs_out, ooff + (uint32_t)((64 * g + 1024 * m) * out_sn * 4), res);
           }
         });
-        if constexpr (g >= SPLIT && g < GP) { if (more) load_group(vbn, voff, v_sn, std::integral_constant<int, g>{}); }
+        if constexpr (g >= SPLIT && g < GP) { if (more) load_group(rs_next, voff, v_sn, std::integral_constant<int, g>{}); }
         if constexpr (FEN) __builtin_amdgcn_sched_barrier(0);
       });
     }

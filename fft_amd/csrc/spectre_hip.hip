@@ -346,10 +346,12 @@ int choose(const SpectreMixArgs* a, const Plan* plan, Choice* c) {
     c->tile = ts; c->RF = ts->RF; c->RS = ts->RS;
     c->mode = mode;
     static const bool p64_off = [] { const char* e = getenv("SPECTRE_P64"); return e && atoi(e) == 0; }();   // A/B switch (tuning aid)
-    c->pipelined = !p64_off && n == 4096 && mode == 0 && a->in_dtype == SPECTRE_F32 && a->out_dtype == SPECTRE_F32 &&
+    // fast mode, padded sequences (mode 3: rows >= N_in are the buffer instructions' out-of-range case) and memory_fft (mode 4);
+    // 32-bit byte offsets
+    c->pipelined = !p64_off && n == 4096 && (mode == 0 || mode == 3 || mode == 4) && a->in_dtype == SPECTRE_F32 && a->out_dtype == SPECTRE_F32 &&
                    reinterpret_cast<uintptr_t>(a->v) % 16 == 0 && reinterpret_cast<uintptr_t>(a->out) % 16 == 0 &&
                    a->v_sn % 4 == 0 && a->v_sb % 4 == 0 && a->out_sn % 4 == 0 && a->out_sb % 4 == 0 &&
-                   a->v_sn * 576 * 4 + 64 < ((int64_t)1 << 31) && a->out_sn * 576 * 4 + 64 < ((int64_t)1 << 31);
+                   a->v_sn * 4096 * 4 + 64 < ((int64_t)1 << 32) && a->out_sn * 4096 * 4 + 64 < ((int64_t)1 << 32);
     return SPECTRE_OK;
   }
   // Stockham / Bluestein in LDS: one buffer of L points per slot; P slots per workgroup, limited by the LDS and by

@@ -92,3 +92,39 @@ def test_backward_through_pipelined_kernel():
     rV, rG = spectral_mix_backward_numpy(V.numpy(), gate.numpy(), dY.numpy(), N)
     assert_close(dV.cpu().numpy(), rV, what="dV")
     assert_close(torch.view_as_real(dG).cpu().numpy(), np.stack([rG.real, rG.imag], -1), what="dgate")
+
+
+@pytest.mark.parametrize("B,N_in,D,G", [(2, 4000, 32, 2), (3, 1, 16, 1), (2, 63, 48, 3), (2, 2049, 64, 4), (5, 3999, 80, 5), (2, 5000, 32, 2), (24, 3000, 192, 4)])
+def test_padded_and_truncated_sequences_on_the_pipelined_kernel(B, N_in, D, G):
+    """n_fft = 4096 with N_in != n_fft: rows >= N_in are never read (the buffer loads return the zero padding of spectre.py:506) and
+    never written (spectre.py:553 keeps min(N, n_fft) rows); guard rows around the output must stay untouched."""
+    from fft_amd import describe, spectral_mix
+    g = torch.Generator().manual_seed(N_in + D)
+    V = torch.randn(B, N_in, D, generator=g)
+    F = N // 2 + 1
+    gate = (torch.complex(torch.randn(B, G, F, generator=g), torch.randn(B, G, F, generator=g)) * 0.3).to(torch.complex64)
+    Vd, gd = V.to(DEV), gate.to(DEV)
+    assert describe(Vd, gd, None, N).startswith("regtile-pipelined 64x64")
+    n_out = min(N_in, N)
+    guard = torch.full((B, n_out + 3, D), 7.25, device=DEV)            # three sentinel rows behind every batch element's output
+    out = guard[:, :n_out]
+    spectral_mix(Vd, gd, None, N, out=out)
+    torch.cuda.synchronize()
+    assert bool((guard[:, n_out:] == 7.25).all()), "rows beyond min(N, n_fft) were written"
+    assert_close(out.cpu().numpy(), spectral_mix_numpy(V.numpy(), gate.numpy(), None, N), what=f"padded ({B},{N_in},{D})")
+
+
+@pytest.mark.parametrize("B,N_in,D,G", [(1, 4096, 16, 1), (3, 4096, 64, 4), (2, 4000, 48, 3), (24, 4096, 192, 4), (5, 100, 80, 5), (2, 5000, 32, 2)])
+def test_memory_fft_on_the_pipelined_kernel(B, N_in, D, G):
+    """spectre.py:548-549 (mixed + memory_fft before the inverse transform), incl. padded / truncated sequences and 2 tiles per workgroup."""
+    from fft_amd import describe, spectral_mix
+    g = torch.Generator().manual_seed(17 * N_in + D)
+    V = torch.randn(B, N_in, D, generator=g)
+    F = N // 2 + 1
+    gate = (torch.complex(torch.randn(B, G, F, generator=g), torch.randn(B, G, F, generator=g)) * 0.3).to(torch.complex64)
+    mem = (torch.complex(torch.randn(F, D, generator=g), torch.randn(F, D, generator=g)) * 0.2).to(torch.complex64)
+    Vd, gd, md = V.to(DEV), gate.to(DEV), mem.to(DEV)
+    assert describe(Vd, gd, md, N).startswith("regtile-pipelined 64x64 in=f32 out=f32 mode=4")
+    y = spectral_mix(Vd, gd, md, N)
+    torch.cuda.synchronize()
+    assert_close(y.cpu().numpy(), spectral_mix_numpy(V.numpy(), gate.numpy(), mem.numpy(), N), what=f"memory_fft ({B},{N_in},{D})")
