@@ -14,14 +14,14 @@ import torch  # noqa: F401  — must be imported first: the library binds to the
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPECTRE_HIP_LIB") or os.path.join(_HERE, "lib", "libspectre_hip.so")   # env: A/B builds
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 F32, BF16 = 0, 1
 ALGO = {"auto": 0, "stockham": 1, "regtile": 2}
 
 # every symbol include/spectre_hip.h declares
 EXPORTS = ("spectre_version", "spectre_last_error", "spectre_mix_fwd", "spectre_mix_describe",
            "spectre_plan_create", "spectre_plan_destroy", "spectre_mix_time", "spectre_mix_bwd",
-           "spectre_mix_bwd_workspace_bytes", "spectre_gate_fwd", "spectre_rfft_fwd", "spectre_decode_workspace_bytes",
+           "spectre_mix_bwd_workspace_bytes", "spectre_gate_fwd", "spectre_gate_bwd", "spectre_rfft_fwd", "spectre_decode_workspace_bytes",
            "spectre_decode_step", "spectre_decode_head_workspace_bytes", "spectre_decode_head_step")
 
 
@@ -39,6 +39,15 @@ class SpectreMixArgs(ctypes.Structure):
 class SpectreGateArgs(ctypes.Structure):
     _fields_ = [
         ("anchors", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("phase", ctypes.c_void_p), ("gate", ctypes.c_void_p),
+        ("B", ctypes.c_int64), ("G", ctypes.c_int64), ("K", ctypes.c_int64), ("F", ctypes.c_int64),
+        ("phase_sb", ctypes.c_int64), ("eps", ctypes.c_float), ("device", ctypes.c_int32), ("stream", ctypes.c_void_p),
+    ]
+
+
+class SpectreGateBwdArgs(ctypes.Structure):
+    _fields_ = [
+        ("anchors", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("phase", ctypes.c_void_p), ("dgate", ctypes.c_void_p),
+        ("workspace", ctypes.c_void_p), ("danchors", ctypes.c_void_p), ("dbias", ctypes.c_void_p), ("dphase", ctypes.c_void_p),
         ("B", ctypes.c_int64), ("G", ctypes.c_int64), ("K", ctypes.c_int64), ("F", ctypes.c_int64),
         ("phase_sb", ctypes.c_int64), ("eps", ctypes.c_float), ("device", ctypes.c_int32), ("stream", ctypes.c_void_p),
     ]
@@ -129,6 +138,8 @@ def load():
         lib.spectre_mix_bwd_workspace_bytes.restype = ctypes.c_int64
         lib.spectre_gate_fwd.argtypes = [ctypes.POINTER(SpectreGateArgs)]
         lib.spectre_gate_fwd.restype = ctypes.c_int
+        lib.spectre_gate_bwd.argtypes = [ctypes.POINTER(SpectreGateBwdArgs)]
+        lib.spectre_gate_bwd.restype = ctypes.c_int
         lib.spectre_rfft_fwd.argtypes = [ctypes.POINTER(SpectreRfftArgs)]
         lib.spectre_rfft_fwd.restype = ctypes.c_int
         lib.spectre_decode_workspace_bytes.argtypes = [ctypes.c_int64] * 2

@@ -730,6 +730,32 @@ int spectre_gate_fwd(const SpectreGateArgs* a) {
   return SPECTRE_OK;
 }
 
+int spectre_gate_bwd(const SpectreGateBwdArgs* a) {
+  if (!a) return fail(SPECTRE_E_INVALID, "args is NULL");
+  if (a->B < 0 || a->G < 1 || a->K < 1 || a->F < 1) return fail(SPECTRE_E_INVALID, "bad sizes");
+  if (a->phase_sb != 0 && a->phase_sb != a->F) return fail(SPECTRE_E_INVALID, "phase_sb must be 0 or F");
+  if (a->B == 0) return SPECTRE_OK;
+  if (!a->anchors || !a->bias || !a->dgate || !a->workspace || !a->danchors || !a->dbias)
+    return fail(SPECTRE_E_INVALID, "anchors, bias, dgate, workspace, danchors and dbias must be non-NULL device pointers");
+  if (a->dphase && !a->phase) return fail(SPECTRE_E_INVALID, "dphase requested without a phase");
+  if (a->B * a->G * a->F >= ((int64_t)1 << 40) || a->K >= 65536 || a->F >= ((int64_t)1 << 24) || 2 * a->G >= 65536 || a->B >= 65536)
+    return fail(SPECTRE_E_UNSUPPORTED, "gate tensor too large");
+  DeviceGuard g(a->device);
+  if (!g.ok) return fail(SPECTRE_E_HIP, "cannot select device %d", a->device);
+  hipStream_t stream = reinterpret_cast<hipStream_t>(a->stream);
+  sfft::GateBwdArgs k{};
+  k.anchors = reinterpret_cast<const float2*>(a->anchors); k.bias = reinterpret_cast<const float*>(a->bias);
+  k.phase = reinterpret_cast<const float2*>(a->phase); k.dgate = reinterpret_cast<const float2*>(a->dgate);
+  k.dr = reinterpret_cast<float2*>(a->workspace); k.danchors = reinterpret_cast<float2*>(a->danchors);
+  k.dbias = reinterpret_cast<float*>(a->dbias); k.dphase = reinterpret_cast<float2*>(a->dphase);
+  k.B = (int)a->B; k.G = (int)a->G; k.K = (int)a->K; k.F = (int)a->F; k.phase_sb = a->phase_sb; k.eps = a->eps;
+  hipLaunchKernelGGL(sfft::spectre_gate_bwd_elem, dim3((unsigned)((a->G * a->F + 255) / 256)), dim3(256), 0, stream, k);
+  hipLaunchKernelGGL(sfft::spectre_gate_bwd_anchors, dim3((unsigned)a->K, (unsigned)(2 * a->G), (unsigned)a->B), dim3(64), 0, stream, k);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(SPECTRE_E_HIP, "gate backward launch failed: %s", hipGetErrorString(e));
+  return SPECTRE_OK;
+}
+
 int spectre_rfft_fwd(const SpectreRfftArgs* a) {
   if (!a) return fail(SPECTRE_E_INVALID, "args is NULL");
   if (a->B < 0 || a->N_in < 1 || a->n_fft < 1 || a->D < 1) return fail(SPECTRE_E_INVALID, "bad sizes");

@@ -207,3 +207,55 @@ def spectral_gate_fused(anchors: torch.Tensor, bias: torch.Tensor, eps: float, s
     a.stream = torch.cuda.current_stream(anchors.device).cuda_stream
     _native.check(lib.spectre_gate_fwd(ctypes.byref(a)), "spectre_gate_fwd")
     return gate
+
+
+def _gate_operands(anchors, bias, size, pos_phase):
+    if not anchors.is_cuda:
+        raise RuntimeError("the fused gate producer runs on a HIP device only (no CPU path)")
+    if anchors.dim() != 3 or anchors.dtype != torch.complex64:
+        raise ValueError(f"anchors must be (B, G, K) complex64, got {tuple(anchors.shape)} {anchors.dtype}")
+    B, G, K = anchors.shape
+    if bias.dtype != torch.float32 or bias.numel() != G * size or bias.device != anchors.device:
+        raise ValueError(f"bias must be ({G * size},) float32 on {anchors.device}")
+    phase, phase_sb = None, 0
+    if pos_phase is not None:
+        phase = pos_phase.to(torch.complex64)
+        if phase.device != anchors.device:
+            raise RuntimeError("pos_phase must be on the same device as the anchors")
+        if phase.dim() == 1 and phase.shape[0] == size:
+            pass
+        elif phase.dim() == 2 and phase.shape[1] == size and phase.shape[0] in (1, B):
+            phase_sb = size if (phase.shape[0] == B and B > 1) else 0
+        else:
+            raise ValueError(f"pos_phase must be ({size},), (1, {size}) or ({B}, {size}), got {tuple(pos_phase.shape)}")
+        phase = phase.contiguous()
+    return anchors.contiguous(), bias.contiguous(), phase, phase_sb
+
+
+def spectral_gate_backward(anchors: torch.Tensor, bias: torch.Tensor, eps: float, size: int, pos_phase: Optional[torch.Tensor],
+                           grad_gate: torch.Tensor, need_dphase: bool = False):
+    """Gradients of `spectral_gate_fused` for an upstream gradient `grad_gate` (B, G, size) complex64: (d_anchors (B, G, K) complex64,
+    d_bias (G * size,) float32, d_pos_phase in pos_phase's shape or None) — C ABI `spectre_gate_bwd`, two launches; what autograd
+    derives through /root/reference/spectre.py:518-524, :530-531, :534-536."""
+    lib = _native.load()
+    anchors, bias, phase, phase_sb = _gate_operands(anchors, bias, size, pos_phase)
+    B, G, K = anchors.shape
+    if tuple(grad_gate.shape) != (B, G, size) or grad_gate.dtype != torch.complex64:
+        raise ValueError(f"grad_gate must be ({B}, {G}, {size}) complex64")
+    grad_gate = grad_gate.contiguous()
+    d_anchors = torch.empty_like(anchors)
+    d_bias = torch.empty(G * size, dtype=torch.float32, device=anchors.device)
+    d_phase = torch.zeros_like(phase) if (need_dphase and phase is not None) else None
+    ws = torch.empty(B * G * size, dtype=torch.complex64, device=anchors.device)
+    a = _native.SpectreGateBwdArgs()
+    a.anchors, a.bias, a.dgate, a.workspace = anchors.data_ptr(), bias.data_ptr(), grad_gate.data_ptr(), ws.data_ptr()
+    a.phase = phase.data_ptr() if phase is not None else None
+    a.danchors, a.dbias = d_anchors.data_ptr(), d_bias.data_ptr()
+    a.dphase = d_phase.data_ptr() if d_phase is not None else None
+    a.B, a.G, a.K, a.F, a.phase_sb, a.eps = B, G, K, size, phase_sb, float(eps)
+    a.device = anchors.device.index if anchors.device.index is not None else torch.cuda.current_device()
+    a.stream = torch.cuda.current_stream(anchors.device).cuda_stream
+    _native.check(lib.spectre_gate_bwd(ctypes.byref(a)), "spectre_gate_bwd")
+    if d_phase is not None and pos_phase is not None:
+        d_phase = d_phase.reshape(pos_phase.shape).to(pos_phase.dtype)
+    return d_anchors, d_bias, d_phase

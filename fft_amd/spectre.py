@@ -26,7 +26,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .functional import spectral_gate_fused, spectral_mix, spectral_mix_backward
+from .functional import spectral_gate_backward, spectral_gate_fused, spectral_mix, spectral_mix_backward
 
 try:  # optional, exactly as the reference treats it (spectre.py:10-14)
     import torch_dct as _dct
@@ -139,6 +139,24 @@ class _SpectralMixFn(torch.autograd.Function):
         return dv, dgate, None, None
 
 
+class _SpectralGateFn(torch.autograd.Function):
+    """autograd node of the fused gate producer (cubic resample -> modReLU -> positional phase): one launch forward, two backward
+    (fft_amd.functional.spectral_gate_fused / spectral_gate_backward) instead of the ~12 + ~20 ATen launches of spectre.py:518-536."""
+
+    @staticmethod
+    def forward(ctx, anchors, bias, pos_phase, eps, size):
+        ctx.save_for_backward(anchors, bias, pos_phase)
+        ctx.eps, ctx.size = eps, size
+        return spectral_gate_fused(anchors, bias, eps, size, pos_phase)
+
+    @staticmethod
+    def backward(ctx, grad_gate):
+        anchors, bias, pos_phase = ctx.saved_tensors
+        da, db, dp = spectral_gate_backward(anchors, bias, ctx.eps, ctx.size, pos_phase, grad_gate.to(torch.complex64),
+                                            need_dphase=pos_phase is not None and ctx.needs_input_grad[2])
+        return (da if ctx.needs_input_grad[0] else None, db if ctx.needs_input_grad[1] else None, dp, None, None)
+
+
 # --------------------------------------------------------------------------------------------------
 # the layer
 # --------------------------------------------------------------------------------------------------
@@ -146,6 +164,7 @@ class SpectreHead(nn.Module):
     """Frequency-domain token mixer for one head — same surface as spectre.py:400-557."""
 
     fold_mean_pooling = True       # on HIP devices, pool x before W_q when the pooling is the plain mean (see spectral_gate)
+    fused_gate_autograd = True     # on HIP devices, run the gate producer tail as one autograd node (False: the reference's PyTorch ops)
 
     def __init__(self, embed_dim: int, fft_size: int, *, num_groups: int = 4, num_buckets: Optional[int] = None,
                  d_gate: int = 256, use_toeplitz: bool = False, toeplitz_bw: int = 4, dropout_p: float = 0.0,
@@ -205,6 +224,10 @@ class SpectreHead(nn.Module):
             # inference: resample -> modReLU -> phase as one HIP launch (row N2); training keeps the ops autograd sees (also when
             # only modrelu.bias or a learnable pos_phase needs a gradient: the fused launch builds no graph)
             return V, spectral_gate_fused(anchors, self.modrelu.bias.detach(), self.modrelu.eps_value, self.F_half, pos_phase), q_pool
+        if (self.fused_gate_autograd and x.is_cuda and anchors.dtype == torch.complex64 and self.modrelu.bias.dtype == torch.float32
+                and (pos_phase is None or pos_phase.is_complex())):
+            # training: the same launch, as an autograd node with its own two-launch backward (row N2 under autograd)
+            return V, _SpectralGateFn.apply(anchors, self.modrelu.bias, pos_phase, self.modrelu.eps_value, self.F_half), q_pool
         gate = resample_complex(anchors, self.F_half, mode="cubic")
         gate = self.modrelu(gate.reshape(Bsz, -1)).view_as(gate)
         if pos_phase is not None:

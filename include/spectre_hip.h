@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SPECTRE_ABI_VERSION 5
+#define SPECTRE_ABI_VERSION 6
 
 enum {
   SPECTRE_OK = 0,
@@ -131,7 +131,7 @@ int spectre_mix_time(const SpectreMixArgs* args, int warmup, int iters, float* m
  *   bias    (G * F)    f32: ComplexModReLU.bias, indexed g * F + k (the reference flattens (G, F) per batch element)
  *   phase   (F) or (B, F) complex64 or NULL; phase_sb = 0 (shared) or F (per batch element)
  *   gate    (B, G, F)  complex64 out — the tensor spectre_mix_fwd consumes
- * Forward only (inference); training keeps the PyTorch ops so that autograd sees them.
+ * spectre_gate_bwd below is its backward; the drop-in module wires both into an autograd.Function.
  */
 typedef struct SpectreGateArgs {
   const void* anchors;
@@ -146,6 +146,30 @@ typedef struct SpectreGateArgs {
 } SpectreGateArgs;
 
 int spectre_gate_fwd(const SpectreGateArgs* args);
+
+/* Backward of spectre_gate_fwd (what autograd derives through spectre.py:518-524, :530-531, :534-536): two launches.
+ *   dgate     (B, G, F) complex64: upstream gradient (PyTorch convention: real / imaginary part = derivative w.r.t. the
+ *             real / imaginary part of gate)
+ *   workspace B * G * F * 8 bytes
+ *   danchors  (B, G, K) complex64 out;  dbias (G * F) f32 out;  dphase: NULL, or zero-initialised by the CALLER, shape of phase
+ * Deterministic except for dphase (a sum over the G groups through atomics). */
+typedef struct SpectreGateBwdArgs {
+  const void* anchors;
+  const void* bias;
+  const void* phase;
+  const void* dgate;
+  void* workspace;
+  void* danchors;
+  void* dbias;
+  void* dphase;
+  int64_t B, G, K, F;
+  int64_t phase_sb;
+  float eps;
+  int32_t device;
+  void* stream;
+} SpectreGateBwdArgs;
+
+int spectre_gate_bwd(const SpectreGateBwdArgs* args);
 
 /* Prefill: replaces PrefixFFTCache.prefill's `torch.fft.rfft(F.pad(V, ...), dim=0)`
  * (spectre.py:775-776), batched: spec[b, k, c] = sum_n v[b, n, c] exp(-2 pi i k n / n_fft), k <= n_fft/2, rows beyond N_in

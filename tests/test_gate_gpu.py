@@ -6,6 +6,7 @@ import pytest
 import torch
 
 from conftest import load_golden
+from oracle.spectral_mix_oracle import assert_close
 from test_module_cpu import MODULE_CASES, _build
 
 pytestmark = pytest.mark.gpu
@@ -88,3 +89,67 @@ def test_bad_arguments_fail_loudly():
         spectral_gate_fused(a, b[:5], 1e-4, 9)
     with pytest.raises(ValueError):
         spectral_gate_fused(a, b, 1e-4, 9, torch.zeros(3, 9, dtype=torch.complex64, device=DEV))
+
+
+# ------------------------------------------------------------------------------------------------------
+# backward of the fused tail (row N2 under autograd): against autograd through the reference's own ops
+# (grid_sample bicubic / abs / relu / sqrt / mul — fft_amd.spectre.resample_complex + ComplexModReLU restate spectre.py:38-61, :109-121)
+# ------------------------------------------------------------------------------------------------------
+def _ops_gate(anchors, bias, eps, F_, phase):
+    from fft_amd.spectre import resample_complex
+    gate = resample_complex(anchors, F_, mode="cubic")
+    B = anchors.shape[0]
+    z = gate.reshape(B, -1)
+    mag = torch.abs(z)
+    z = z * (torch.relu(mag + bias) / torch.sqrt(mag.square() + eps * eps))
+    gate = z.view_as(gate)
+    if phase is not None:
+        gate = gate * phase.unsqueeze(1 if phase.dim() == 2 else 0)
+    return gate
+
+
+@pytest.mark.parametrize("B,G,K,F_,ph", [(3, 2, 8, 129, None), (2, 4, 45, 2049, "shared"), (1, 1, 4, 17, "batch"), (5, 3, 11, 513, "batch"),
+                                         (2, 2, 4, 33, "shared"), (4, 4, 64, 1025, None)])
+def test_fused_gate_backward_matches_autograd_through_the_reference_ops(B, G, K, F_, ph):
+    from fft_amd.spectre import _SpectralGateFn
+    g = torch.Generator().manual_seed(B * 100 + K)
+    anchors = torch.complex(torch.randn(B, G, K, generator=g), torch.randn(B, G, K, generator=g)).to("cuda:0")
+    bias = (torch.randn(G * F_, generator=g) * 0.5 - 0.1).to("cuda:0")       # mixed signs: both sides of the relu
+    phase = None
+    if ph == "shared":
+        phase = torch.exp(1j * torch.randn(F_, generator=g)).to(torch.complex64).to("cuda:0")
+    elif ph == "batch":
+        phase = torch.exp(1j * torch.randn(B, F_, generator=g)).to(torch.complex64).to("cuda:0")
+    up = torch.complex(torch.randn(B, G, F_, generator=g), torch.randn(B, G, F_, generator=g)).to("cuda:0")
+    grads = []
+    for fused in (True, False):
+        a = anchors.clone().requires_grad_(True)
+        b = bias.clone().requires_grad_(True)
+        p = phase.clone().requires_grad_(True) if phase is not None else None
+        out = _SpectralGateFn.apply(a, b, p, 1e-4, F_) if fused else _ops_gate(a, b, 1e-4, F_, p)
+        (out * up.conj()).real.sum().backward()                              # a generic real loss: every component gets its own weight
+        grads.append((out.detach(), a.grad, b.grad, None if p is None else p.grad))
+    torch.cuda.synchronize()
+    (of, af, bf, pf), (oo, ao, bo, po) = grads
+    assert_close(torch.view_as_real(of).cpu().numpy(), torch.view_as_real(oo).cpu().numpy(), rtol=1e-4, atol_rms=1e-5, what="gate")
+    assert_close(torch.view_as_real(af).cpu().numpy(), torch.view_as_real(ao).cpu().numpy(), rtol=1e-4, atol_rms=2e-5, what="d anchors")
+    assert_close(bf.cpu().numpy(), bo.cpu().numpy(), rtol=1e-4, atol_rms=2e-5, what="d bias")
+    if pf is not None:
+        assert_close(torch.view_as_real(pf).cpu().numpy(), torch.view_as_real(po).cpu().numpy(), rtol=1e-4, atol_rms=2e-5, what="d phase")
+
+
+def test_module_training_gradients_agree_with_and_without_the_fused_gate_node():
+    import copy
+    from fft_amd import SpectreHead
+    torch.manual_seed(3)
+    head = SpectreHead(32, 512, num_groups=2, pooling_type="mean").to("cuda:0")
+    ref = copy.deepcopy(head)
+    ref.fused_gate_autograd = False
+    x = torch.randn(3, 512, 32, device="cuda:0")
+    w = torch.randn(3, 512, 32, device="cuda:0")
+    for m in (head, ref):
+        (m(x) * w).sum().backward()
+    torch.cuda.synchronize()
+    for (n, p), (_, q) in zip(head.named_parameters(), ref.named_parameters()):
+        assert p.grad is not None and q.grad is not None, n
+        assert_close(p.grad.cpu().numpy(), q.grad.cpu().numpy(), rtol=2e-4, atol_rms=5e-5, what=n)
