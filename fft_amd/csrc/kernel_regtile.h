@@ -40,6 +40,9 @@
 
 namespace sfft {
 
+typedef unsigned int rt_u32x2 __attribute__((ext_vector_type(2)));
+constexpr int kRsrcFlags = 0x00020000;       // raw buffer resource, dword 3 (gfx90a / gfx942 / gfx950)
+
 struct RegtileArgs {
   const void* v;
   const float2* gate;   // (B, G, F) complex64
@@ -250,46 +253,43 @@ spectre_mix_regtile(const RegtileArgs a) {
   {
     const char* vb = reinterpret_cast<const char*>(a.v) + ((size_t)b * a.v_sb + (size_t)ct * (2 * kPC)) * ES_IN;
     const uint32_t voff = (uint32_t)(((long long)u * v_sn + 2 * p) * ES_IN);
+    // General modes: rows >= N_in (rfft's zero padding) and the lanes of a ragged last tile beyond D are the out-of-range case of the
+    // buffer instructions — loads return 0, stores are dropped — instead of 2 * RF predicates, pointer selects and their spills.
+    // The range check covers the VGPR offset only, so the row-block offset is added there; an invalid lane starts at 2^31.
+    [[maybe_unused]] __amdgpu_buffer_rsrc_t rs_in;
+    [[maybe_unused]] uint32_t voff_c = voff;
+    if constexpr (GENERAL) {
+      const int rows = a.N_in < N ? a.N_in : N;
+      rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(vb), 0, (int)((long long)rows * v_sn * ES_IN), kRsrcFlags);
+      voff_c = cvalid ? voff : 0x80000000u;
+    }
     static_for<0, RF>([&](auto ic) {
       // issue order = order of use: stage 1 of F1 works on {q0 + RBF*q1}, q0 = 0, 1, ..., so its first butterflies
       // start while the tail of the tile is still in flight
       constexpr int q = (decltype(ic)::value / RAF) + RBF * (decltype(ic)::value % RAF);
-      const char* ptr = vb + (size_t)q * RS * v_sn * ES_IN + voff;
-      bool ok = true;
-      if constexpr (GENERAL) {                     // rows >= N_in read as zero (rfft's zero padding), branch-free:
-        ok = cvalid && (u + RS * q) < a.N_in;      // load an address that exists, then select
-        ptr = ok ? ptr : vb;
-      }
       if constexpr (NO_IO) {
         z[q] = make_float2(1.0f + q + u, 0.5f * p - q);
+      } else if constexpr (GENERAL) {
+        const uint32_t off = voff_c + (uint32_t)((long long)q * RS * v_sn * ES_IN);
+        if constexpr (IN_BF16) {
+          const uint32_t wv = __builtin_amdgcn_raw_buffer_load_b32(rs_in, off, 0, 0);
+          z[q] = make_float2(__uint_as_float(wv << 16), __uint_as_float(wv & 0xffff0000u));
+        } else {
+          const rt_u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs_in, off, 0, 0);
+          z[q] = make_float2(__uint_as_float(t.x), __uint_as_float(t.y));
+        }
       } else {
-        float2 val;
+        const char* ptr = vb + (size_t)q * RS * v_sn * ES_IN + voff;
         if constexpr (IN_BF16) {
           const uint32_t wv = *reinterpret_cast<const uint32_t*>(ptr);
-          val = make_float2(__uint_as_float(wv << 16), __uint_as_float(wv & 0xffff0000u));
+          z[q] = make_float2(__uint_as_float(wv << 16), __uint_as_float(wv & 0xffff0000u));
         } else {
-          val = *reinterpret_cast<const float2*>(ptr);
+          z[q] = *reinterpret_cast<const float2*>(ptr);
         }
-        z[q] = ok ? val : make_float2(0.f, 0.f);
       }
     });
   }
 
-  if constexpr ((ABL & 256) != 0) {   // L2 / Infinity-Cache prefetch: one dword per row segment, result discarded (AGPR a0)
-    const int pt = tile + a.pf_dist;
-    if (pt < a.n_tiles) {
-      const int pb = pt / a.tiles_per_row, pct = pt - pb * a.tiles_per_row;
-      const char* pv = reinterpret_cast<const char*>(a.v) + ((size_t)pb * a.v_sb + (size_t)pct * (2 * kPC)) * ES_IN;
-      static_for<0, N / (kPC * RS)>([&](auto ic) {
-        const char* ptr = pv + (size_t)(tid + decltype(ic)::value * kPC * RS) * v_sn * ES_IN;
-        asm volatile("global_load_dword a0, %0, off" :: "v"(ptr) : "a0");
-      });
-    }
-  }
-  if constexpr ((ABL & 128) != 0) {   // this wave's loads have landed: one eighth of a slot is free again
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&a.sem[(blockIdx.x % 8) * 64 + 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
   if constexpr (TRACE) { stamp(1); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(2); }
   // ---- F1: RF-point forward transform over n1, then W_N^(u*k1) ---------------------------------------
   if constexpr (!NO_MATH) {
@@ -438,16 +438,31 @@ spectre_mix_regtile(const RegtileArgs a) {
   {
     char* ob = reinterpret_cast<char*>(a.out) + ((size_t)b * a.out_sb + (size_t)ct * (2 * kPC)) * ES_OUT;
     const uint32_t ooff = (uint32_t)(((long long)u * out_sn + 2 * p) * ES_OUT);
+    [[maybe_unused]] __amdgpu_buffer_rsrc_t rs_out;
+    [[maybe_unused]] uint32_t ooff_c = ooff;
+    if constexpr (GENERAL) {
+      const int rows = a.N_in < N ? a.N_in : N;                // spectre.py:553 keeps rows < min(N, n_fft)
+      rs_out = __builtin_amdgcn_make_buffer_rsrc(ob, 0, (int)((long long)rows * out_sn * ES_OUT), kRsrcFlags);
+      ooff_c = cvalid ? ooff : 0x80000000u;
+    }
     static_for<0, RF>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
       // the last butterfly stage runs group by group; each group's rows are stored as soon as they exist
       if constexpr (!NO_MATH && (j % RBF) == 0) fftA_stage2_group<RAF, RBF, true, j / RBF>(z);
       constexpr int n1 = (j / RBF) + RAF * (j % RBF);
-      char* ptr = ob + (size_t)n1 * RS * out_sn * ES_OUT + ooff;
-      bool ok = true;
-      if constexpr (GENERAL) ok = cvalid && (u + RS * n1) < a.N_in;
-      if constexpr (NO_IO) ok = (z[j].x == 1.2345e-30f);   // keeps the math alive, never true
-      if (ok) {
+      if constexpr (NO_IO) {
+        if (z[j].x == 1.2345e-30f) *reinterpret_cast<float2*>(ob + (size_t)n1 * RS * out_sn * ES_OUT + ooff) = z[j];   // keeps the math alive, never true
+      } else if constexpr (GENERAL) {
+        const uint32_t off = ooff_c + (uint32_t)((long long)n1 * RS * out_sn * ES_OUT);
+        if constexpr (OUT_BF16) {
+          __builtin_amdgcn_raw_buffer_store_b32(f32_to_bf16_rne(z[j].x) | (f32_to_bf16_rne(z[j].y) << 16), rs_out, off, 0, 0);
+        } else {
+          rt_u32x2 t;
+          t.x = __float_as_uint(z[j].x); t.y = __float_as_uint(z[j].y);
+          __builtin_amdgcn_raw_buffer_store_b64(t, rs_out, off, 0, 0);
+        }
+      } else {
+        char* ptr = ob + (size_t)n1 * RS * out_sn * ES_OUT + ooff;
         if constexpr (OUT_BF16) {
           *reinterpret_cast<uint32_t*>(ptr) = f32_to_bf16_rne(z[j].x) | (f32_to_bf16_rne(z[j].y) << 16);
         } else {
