@@ -31,7 +31,7 @@ template <int RF, int RS> constexpr int mixed_lds_total() { return mixed_image_b
 // only fit a CU together when no SIMD needs more than 4 slots; at 130-140 VGPRs (3 slots) the second workgroup usually
 // does not fit and the kernel runs one workgroup per CU.  Fast mode only: the general modes would spill ~200 registers.
 template <int RF, int RS, bool IN_BF16, bool OUT_BF16, int MODE>
-__global__ void __launch_bounds__(kPC * (RF > RS ? RF : RS), (MODE == 0 && (RF > RS ? RF : RS) <= 50 ? 4 : 1))
+__global__ void __launch_bounds__(kPC * (RF > RS ? RF : RS), ((MODE == 0 || MODE == 3) && (RF > RS ? RF : RS) <= 50 ? 4 : 1))
 spectre_mix_regtile_mixed(const RegtileArgs a) {
   constexpr bool GENERAL = MODE != 0, WITH_MEM = MODE == 2, GATE_LDS = MODE == 0 || MODE == 3;
   constexpr int N = RF * RS, NZ = mixed_team<RF, RS>(), NT = mixed_threads<RF, RS>();
@@ -78,22 +78,35 @@ spectre_mix_regtile_mixed(const RegtileArgs a) {
   if (rows) {
     const char* vb = reinterpret_cast<const char*>(a.v) + ((size_t)b * a.v_sb + (size_t)ct * (2 * kPC)) * ES_IN;
     const uint32_t voff = (uint32_t)(((long long)u * a.v_sn + 2 * p) * ES_IN);
+    // general modes: rows >= N_in and the lanes of a ragged last tile are the out-of-range case of the buffer instructions
+    // (kernel_regtile.h): loads return rfft's zero padding, stores are dropped — no predicates, no pointer selects
+    [[maybe_unused]] __amdgpu_buffer_rsrc_t rs_in;
+    [[maybe_unused]] uint32_t voff_c = voff;
+    if constexpr (GENERAL) {
+      const int nrow = a.N_in < N ? a.N_in : N;
+      rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(vb), 0, (int)((long long)nrow * a.v_sn * ES_IN), kRsrcFlags);
+      voff_c = cvalid ? voff : 0x80000000u;
+    }
     static_for<0, RF>([&](auto ic) {
       constexpr int q = (decltype(ic)::value / RAF) + RBF * (decltype(ic)::value % RAF);   // order of use in stage 1
-      const char* ptr = vb + (size_t)q * RS * a.v_sn * ES_IN + voff;
-      bool ok = true;
       if constexpr (GENERAL) {
-        ok = cvalid && (u + RS * q) < a.N_in;
-        ptr = ok ? ptr : vb;
-      }
-      float2 val;
-      if constexpr (IN_BF16) {
-        const uint32_t wv = *reinterpret_cast<const uint32_t*>(ptr);
-        val = make_float2(__uint_as_float(wv << 16), __uint_as_float(wv & 0xffff0000u));
+        const uint32_t off = voff_c + (uint32_t)((long long)q * RS * a.v_sn * ES_IN);
+        if constexpr (IN_BF16) {
+          const uint32_t wv = __builtin_amdgcn_raw_buffer_load_b32(rs_in, off, 0, 0);
+          z[q] = make_float2(__uint_as_float(wv << 16), __uint_as_float(wv & 0xffff0000u));
+        } else {
+          const rt_u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs_in, off, 0, 0);
+          z[q] = make_float2(__uint_as_float(t.x), __uint_as_float(t.y));
+        }
       } else {
-        val = *reinterpret_cast<const float2*>(ptr);
+        const char* ptr = vb + (size_t)q * RS * a.v_sn * ES_IN + voff;
+        if constexpr (IN_BF16) {
+          const uint32_t wv = *reinterpret_cast<const uint32_t*>(ptr);
+          z[q] = make_float2(__uint_as_float(wv << 16), __uint_as_float(wv & 0xffff0000u));
+        } else {
+          z[q] = *reinterpret_cast<const float2*>(ptr);
+        }
       }
-      z[q] = ok ? val : make_float2(0.f, 0.f);
     });
     fft_ct<RF, false, IdentityMap, NZ>(z);
     float2 wa[RAF], wb[RBF];
@@ -173,12 +186,26 @@ spectre_mix_regtile_mixed(const RegtileArgs a) {
     fft_ct<RF, true, IdentityMap, NZ>(z);
     char* ob = reinterpret_cast<char*>(a.out) + ((size_t)b * a.out_sb + (size_t)ct * (2 * kPC)) * ES_OUT;
     const uint32_t ooff = (uint32_t)(((long long)u * a.out_sn + 2 * p) * ES_OUT);
+    [[maybe_unused]] __amdgpu_buffer_rsrc_t rs_out;
+    [[maybe_unused]] uint32_t ooff_c = ooff;
+    if constexpr (GENERAL) {
+      const int nrow = a.N_in < N ? a.N_in : N;              // spectre.py:553 keeps rows < min(N, n_fft)
+      rs_out = __builtin_amdgcn_make_buffer_rsrc(ob, 0, (int)((long long)nrow * a.out_sn * ES_OUT), kRsrcFlags);
+      ooff_c = cvalid ? ooff : 0x80000000u;
+    }
     static_for<0, RF>([&](auto nc) {
       constexpr int n1 = decltype(nc)::value, pos = out_pos<RF>(n1);
-      char* ptr = ob + (size_t)n1 * RS * a.out_sn * ES_OUT + ooff;
-      bool ok = true;
-      if constexpr (GENERAL) ok = cvalid && (u + RS * n1) < a.N_in;
-      if (ok) {
+      if constexpr (GENERAL) {
+        const uint32_t off = ooff_c + (uint32_t)((long long)n1 * RS * a.out_sn * ES_OUT);
+        if constexpr (OUT_BF16) {
+          __builtin_amdgcn_raw_buffer_store_b32(f32_to_bf16_rne(z[pos].x) | (f32_to_bf16_rne(z[pos].y) << 16), rs_out, off, 0, 0);
+        } else {
+          rt_u32x2 t;
+          t.x = __float_as_uint(z[pos].x); t.y = __float_as_uint(z[pos].y);
+          __builtin_amdgcn_raw_buffer_store_b64(t, rs_out, off, 0, 0);
+        }
+      } else {
+        char* ptr = ob + (size_t)n1 * RS * a.out_sn * ES_OUT + ooff;
         if constexpr (OUT_BF16) {
           *reinterpret_cast<uint32_t*>(ptr) = f32_to_bf16_rne(z[pos].x) | (f32_to_bf16_rne(z[pos].y) << 16);
         } else {

@@ -321,7 +321,7 @@ int choose(const SpectreMixArgs* a, const Plan* plan, Choice* c) {
   else if (a->mem && (reinterpret_cast<uintptr_t>(a->mem) % 16)) why = "mem not 16-byte aligned";
   else if (reinterpret_cast<uintptr_t>(a->gate) % 8) why = "gate not 8-byte aligned";
   else if (a->v_sn * 255 * 4 + 64 >= ((int64_t)1 << 31) || a->out_sn * 255 * 4 + 64 >= ((int64_t)1 << 31)) why = "row stride too large";
-  else if (!ts->mixed && ts->tile_ch == 16 && (n * a->v_sn * es_in >= ((int64_t)1 << 31) || n * a->out_sn * es_out >= ((int64_t)1 << 31)))
+  else if (ts->tile_ch == 16 && (n * a->v_sn * es_in >= ((int64_t)1 << 31) || n * a->out_sn * es_out >= ((int64_t)1 << 31)))
     why = "row stride too large for the 32-bit buffer offsets of the register-tile kernels";
   else if (ts->tile_ch < 16 && (a->v_sn * (n - 1) * es_in + 64 >= ((int64_t)1 << 32) || a->out_sn * (n - 1) * es_out + 64 >= ((int64_t)1 << 32)))
     why = "row stride too large for the 32-bit row offsets of the lane-pair / lane-quad kernels";
