@@ -299,6 +299,23 @@ int main(int argc, char** argv) {
       rep("hipMemcpy", 0, 0, 0, ms);
     }
   }
+  if (has('E')) {   // copy ceiling, second sweep: few blocks per CU, 1-2 loads in flight per thread, larger blocks
+    const size_t n4 = n / 4;
+    auto rep = [&](const char* nm, int u, int nt, int grid, int bs, float ms) { printf("E %-6s U=%d nt=%d grid=%6d block=%4d : %7.3f ms  %7.1f GB/s\n", nm, u, nt, grid, bs, ms, 2.0 * n * 4 / ms / 1e6); fflush(stdout); };
+    for (int g : {256, 512, 768, 1024, 1280, 1536, 2048, 3072}) {
+      rep("stride", 1, 0, g, 256, timeit([&] { copy4<1, 0><<<g, 256>>>((const f32x4*)in, (f32x4*)out, n4); }));
+      rep("stride", 1, 1, g, 256, timeit([&] { copy4<1, 1><<<g, 256>>>((const f32x4*)in, (f32x4*)out, n4); }));
+      rep("stride", 2, 0, g, 256, timeit([&] { copy4<2, 0><<<g, 256>>>((const f32x4*)in, (f32x4*)out, n4); }));
+      rep("stride", 2, 1, g, 256, timeit([&] { copy4<2, 1><<<g, 256>>>((const f32x4*)in, (f32x4*)out, n4); }));
+    }
+    for (int g : {16384, 32768, 65536, 131072}) {
+      const size_t pb = (n4 + g - 1) / g;
+      rep("chunk", 1, 0, g, 256, timeit([&] { copy4_chunk<1, 0><<<g, 256>>>((const f32x4*)in, (f32x4*)out, n4, pb); }));
+      rep("chunk", 1, 1, g, 256, timeit([&] { copy4_chunk<1, 1><<<g, 256>>>((const f32x4*)in, (f32x4*)out, n4, pb); }));
+      rep("chunk", 2, 1, g, 256, timeit([&] { copy4_chunk<2, 1><<<g, 256>>>((const f32x4*)in, (f32x4*)out, n4, pb); }));
+      rep("chunk", 4, 1, g, 256, timeit([&] { copy4_chunk<4, 1><<<g, 256>>>((const f32x4*)in, (f32x4*)out, n4, pb); }));
+    }
+  }
   if (has('B')) {
     for (int delay : {0, 86}) {
       runB<8, 0, 0>(in, out, delay, 0); runB<16, 0, 0>(in, out, delay, 0);
