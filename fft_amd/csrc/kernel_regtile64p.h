@@ -1,5 +1,5 @@
-// kernel_regtile64p.h — persistent, software-pipelined spectral mix for n_fft = 4096 = 64 x 64 on gfx950 (no memory_fft, every
-// 16-channel tile inside one gate group, 16-byte aligned fp32 rows; ANY sequence length: rows beyond N_in are the buffer
+// kernel_regtile64p.h — persistent, software-pipelined spectral mix for n_fft = 4096 = 64 x 64 on gfx950 (every 16-channel tile
+// inside one gate group, 16-byte aligned fp32 rows; optional memory_fft; ANY sequence length: rows beyond N_in are the buffer
 // instructions' out-of-range case — loads return 0 = rfft's zero padding (spectre.py:506), stores are dropped (spectre.py:553) —
 // so a padded sequence costs exactly what a full one costs, without a single predicate).
 //
@@ -7,12 +7,15 @@
 // twiddle -> E1 -> F2 -> gate -> I1 -> E2 -> conj twiddle -> I2; replaces /root/reference/spectre.py:506 + :542-553), rebuilt
 // around what the round-2 measurements showed (tools/trace_bench.hip, tools/iolab.hip, profiles/r02_*):
 //
-//  * all 256 CUs run in lock-step — everybody loads, then everybody computes — and that state is an attractor (a CU that
-//    loads while the others compute finishes early and drifts back into the pack), so HBM idles while the chip computes.
-//    Loads of tile t+1 therefore have to be in flight while tile t is still being computed on the SAME CU;
+//  * with one workgroup per tile all 256 CUs run in lock-step — everybody loads, then everybody computes — and that state is an
+//    attractor (a CU that loads while the others compute finishes early and drifts back into the pack), so HBM idles while the
+//    chip computes.  Loads of tile t+1 therefore have to be in flight while tile t is still being computed on the SAME CU
+//    (the persistent workgroups of this kernel do drift apart: 115 +- 14 of 256 are in their store/load burst at any instant);
+//  * what bounds that burst is the number of 64-byte row-segment requests a CU can have in flight (8192 per tile, ~3 ns each
+//    under load), not bytes;
 //  * a wave's stores and loads retire through one in-order counter (vmcnt): loads issued behind the stores of the previous
 //    tile cannot be consumed before those stores are acknowledged.  The next tile's first half is therefore requested BEFORE
-//    the stores, as LDS-DMA (global_load_lds_dwordx4, no VGPR needed) into the exchange image, which is idle between the last
+//    the stores, as LDS-DMA (buffer_load_dwordx4 ... lds, no VGPR needed) into the exchange image, which is idle between the last
 //    exchange of tile t and the first exchange of tile t+1.  Every lane reads back exactly the 16 bytes it requested, so the
 //    staging needs no barrier of its own;
 //  * the second half is loaded straight into the registers that the stores of I2 have just released (store register group g of
