@@ -59,6 +59,7 @@ struct RegtileArgs {
   int stagger_ticks, stagger_classes, stagger_first;   // first-generation phase stagger (100 MHz ticks per class), see kernel
   unsigned* sem; int sem_k;    // load-admission semaphore per XCD (ABL bit7): [x*64] tickets issued, [x*64+32] loads completed
   int pf_dist;                 // ABL bit8: touch the 64-B row segments of tile + pf_dist (the tile a CU of this XCD loads one generation later)
+  unsigned* gang_cnt;          // kernel_regtile64p.h ABL bit5 (tools/p64_ab_bench.hip): zeroed rendezvous counters, 4 words per wave pair
 };
 
 constexpr int kPC = 8;                       // pair-columns per tile: 16 channels, 64-byte fp32 row segments

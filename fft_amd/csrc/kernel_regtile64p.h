@@ -34,7 +34,13 @@
 namespace sfft {
 
 constexpr int kP64ImageBytes = regtile_image_bytes<64, 64, 1>();
-constexpr int kP64LdsTotal = regtile_lds_total<64, 64, 1>();
+// LDS: exchange image | half-spectrum gate | the two twiddle vectors of every team index u (W^(u j), W^(8 u j), j = 1..7): 64 x 14 x 8 B.
+// The twiddles are read twice per tile; as global loads they queue (one in-order vmcnt) behind the LDS-DMA requests of the next tile at
+// the start of the store/load burst and behind the last stores at the start of F1, i.e. every tile paid a full HBM round trip for
+// 112 bytes that never change.  From LDS they cost 7 ds_read_b128 and no vmcnt.
+constexpr int kP64TwOff = (regtile_lds_total<64, 64, 1>() + 15) & ~15;
+constexpr int kP64LdsTotal = kP64TwOff + 64 * 14 * 8;
+static_assert(kP64LdsTotal <= 160 * 1024, "LDS budget");
 
 typedef unsigned int p64_u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kP64RsrcFlags = 0x00020000;        // raw buffer, 32-bit data format (gfx90a / gfx942 / gfx950 dword 3)
@@ -92,6 +98,20 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* img = reinterpret_cast<float*>(smem);
   float2* glds = reinterpret_cast<float2*>(smem + kP64ImageBytes);
+  float2* twl = reinterpret_cast<float2*>(smem + kP64TwOff);
+  for (int i = threadIdx.x; i < 64 * 14; i += 512) {
+    const int uu = i / 14, e = i - 14 * uu, j = (e % 7) + 1;
+    twl[i] = a.tw[e < 7 ? uu * j : uu * 8 * j];
+  }
+  __syncthreads();
+  auto load_twiddles = [&](float2 (&wa)[8], float2 (&wb)[8], int uu) {
+    const float4* t = reinterpret_cast<const float4*>(twl + 14 * uu);
+    const float4 q0 = t[0], q1 = t[1], q2 = t[2], q3 = t[3], q4 = t[4], q5 = t[5], q6 = t[6];
+    wa[1] = make_float2(q0.x, q0.y); wa[2] = make_float2(q0.z, q0.w); wa[3] = make_float2(q1.x, q1.y); wa[4] = make_float2(q1.z, q1.w);
+    wa[5] = make_float2(q2.x, q2.y); wa[6] = make_float2(q2.z, q2.w); wa[7] = make_float2(q3.x, q3.y); wb[1] = make_float2(q3.z, q3.w);
+    wb[2] = make_float2(q4.x, q4.y); wb[3] = make_float2(q4.z, q4.w); wb[4] = make_float2(q5.x, q5.y); wb[5] = make_float2(q5.z, q5.w);
+    wb[6] = make_float2(q6.x, q6.y); wb[7] = make_float2(q6.z, q6.w);
+  };
 
   // Only threadIdx.x stays live across the tile loop; the lane coordinates are re-derived from an opaque copy per tile
   // (otherwise LICM hoists every per-lane address out of the loop and the allocator spills them).
@@ -110,8 +130,48 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
   coords();
 
   const int wg_lin = xcd_contiguous(blockIdx.x, a.n_wg);
-  const int pair_base = (wg_lin >> 1) * a.tpw * 2 + (wg_lin & 1);   // workgroups 2m, 2m+1 walk through adjacent tiles in step
+  // ABL bit12 (tools/p64_ab_bench.hip): the whole chip sweeps the tiles front to back (tile = workgroup + n_wg * iteration, every XCD
+  // on 32 adjacent tiles) instead of every pair of workgroups walking through its own 2 * tpw tiles
+  constexpr bool SWEEP = (ABL & 4096) != 0;
+  const int tile_step = SWEEP ? a.n_wg : 2;
+  const int pair_base = SWEEP ? wg_lin : (wg_lin >> 1) * a.tpw * 2 + (wg_lin & 1);   // workgroups 2m, 2m+1 walk through adjacent tiles in step
   if (pair_base >= a.n_tiles) return;
+
+  // ABL bit5 (tools/p64_ab_bench.hip only; measured and NOT shipped: profiles/r02_p64_ab_rendezvous.log).  A 64-byte row segment is
+  // half an L2 line.  Reads: the L2 fetches the whole line on a miss and the neighbour workgroup's request a few microseconds later
+  // hits (FETCH_SIZE = the algorithmic bytes).  Writes: in a pure copy the two halves of a line leave the L2 as one DRAM burst only if
+  // they were written within about a microsecond of each other (tools/iolab3.hip: 64-byte segments 3.4 TB/s, halves together 5.4).
+  // Here wave w of workgroup 2m and wave w of workgroup 2m+1 — the owners of the two halves of the same lines — meet before every group
+  // of 4 store instructions: s_atomic_add to arrive (before the group's butterflies), s_load_dword glc to poll; scalar unit only, no
+  // VGPR, no vmcnt, no workgroup barrier; a wave whose partner does not show up within 24 polls drops out for the rest of the launch.
+  // Result: the rendezvous works (all 1024 wave pairs stay together, ~0.4 failed polls per meeting) and the kernel gets 2-4 % SLOWER.
+  [[maybe_unused]] unsigned* gcnt = nullptr;
+  [[maybe_unused]] bool gang_live = false;
+  [[maybe_unused]] unsigned gang_done = 0, gang_polls = 0;
+  if constexpr ((ABL & 32) != 0) {
+    gcnt = a.gang_cnt + ((wg_lin >> 1) * 8 + __builtin_amdgcn_readfirstlane(tid0 >> 6)) * 4;
+    gang_live = true;
+  }
+  auto gang_arrive = [&]() {
+    if constexpr ((ABL & 32) != 0) {
+      if (gang_live) { const unsigned one = 1; asm volatile("s_atomic_add %0, %1, 0x0" :: "s"(one), "s"(gcnt) : "memory"); }
+    }
+  };
+  auto gang_await = [&]([[maybe_unused]] unsigned members) {   // members = workgroups of the pair that have a tile in this iteration
+    if constexpr ((ABL & 32) != 0) {
+      gang_done += members;
+      if (gang_live && members > 1) {
+        int spin = 0;
+        for (;;) {
+          unsigned now;
+          asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(now) : "s"(gcnt) : "memory");
+          if ((int)(now - gang_done) >= 0) break;
+          ++gang_polls;
+          if (++spin > 24) { gang_live = false; break; }
+        }
+      }
+    }
+  };
 
   // ABL (tools/trace64p_bench.hip only; 0 in the library): bit4 = phase timestamps (100 MHz) into a.trace, 8 per (workgroup, tile)
   [[maybe_unused]] auto stamp = [&](int it, int slot) {
@@ -126,18 +186,24 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
     const int b = tile / a.tiles_per_row, ct = tile - b * a.tiles_per_row;
     vb = reinterpret_cast<const char*>(a.v) + ((size_t)b * a.v_sb + (size_t)ct * 16) * 4;
     ob = reinterpret_cast<char*>(a.out) + ((size_t)b * a.out_sb + (size_t)ct * 16) * 4;
+    // ABL bit10 / bit11 (tools/p64_ab_bench.hip): every workgroup of an XCD stores to / loads from ONE dense 256-KiB tile (row stride
+    // 64 bytes, see v_sn / out_sn in the tile loop) — real requests and acknowledgements that never leave the L2
+    if constexpr ((ABL & 1024) != 0) ob = reinterpret_cast<char*>(a.out) + (size_t)(blockIdx.x % 8) * (4096 * 64);
+    if constexpr ((ABL & 2048) != 0) vb = reinterpret_cast<const char*>(a.v) + (size_t)(blockIdx.x % 8) * (4096 * 64);
     gp = a.gate + ((size_t)b * a.G + (ct * 16) / a.d_g) * a.F;
   };
   // row of this lane in load / store instruction (g, m):  u + 512 h + 64 g + 1024 m; addresses = workgroup-uniform base of the
   // instruction (SGPRs) + one 32-bit lane offset (spectre_hip.hip bounds 4095 * row stride * 4 + 64 below 2^31)
   // Buffer resources: base = the tile's first row, num_records = the bytes of its rows below N_in.  The range check covers the
   // VGPR offset (lane offset + row-block offset; the SGPR offset operand is not checked on gfx9), so both go there.
+  // ABL bit8 / bit9 (tools/p64_ab_bench.hip): an empty range for the stores / the loads — the same instruction stream without the
+  // memory traffic (out-of-range stores are dropped, out-of-range loads return 0 before they leave the CU)
   auto rsrc_in = [&](const char* vb, long long sn) {
-    const int rows = a.N_in < 4096 ? a.N_in : 4096;
+    const int rows = (ABL & 512) != 0 ? 0 : a.N_in < 4096 ? a.N_in : 4096;
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(vb), 0, (int)((long long)rows * sn * 4), kP64RsrcFlags);
   };
   auto rsrc_out = [&](char* ob, long long sn) {
-    const int rows = a.N_in < 4096 ? a.N_in : 4096;
+    const int rows = (ABL & 256) != 0 ? 0 : a.N_in < 4096 ? a.N_in : 4096;
     return __builtin_amdgcn_make_buffer_rsrc(ob, 0, (int)((long long)rows * sn * 4), kP64RsrcFlags);
   };
   auto load_group = [&](__amdgpu_buffer_rsrc_t rs, uint32_t voff, long long sn, auto gc) {       // straight into the registers of group g
@@ -211,16 +277,20 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
   }
 
   for (int it = 0; it < a.tpw; ++it) {
-    const int tile = pair_base + 2 * it;
+    // ABL bit13 (tools/p64_ab_bench.hip; shapes whose tile count is a multiple of 2 * tpw): every pair starts its walk at a different
+    // position of its range, so that pairs that run in step are never at the same offset of their (25 MB-aligned) ranges
+    [[maybe_unused]] const int rot = (ABL & 8192) != 0 ? ((wg_lin >> 1) * a.pf_dist) % a.tpw : 0;
+    const int tile = (ABL & 8192) != 0 ? pair_base + 2 * ((it + rot) % a.tpw) : pair_base + tile_step * it;
     if (tile >= a.n_tiles) break;                  // workgroup-uniform
-    const bool more = (it + 1 < a.tpw) && (tile + 2 < a.n_tiles);
+    const bool more = (it + 1 < a.tpw) && (tile + tile_step < a.n_tiles);
+    [[maybe_unused]] const unsigned members = (unsigned)min(2, a.n_tiles - (tile & ~1));   // workgroups of the pair that have a tile in this iteration
     coords();
-    long long v_sn = a.v_sn, out_sn = a.out_sn;
+    long long v_sn = (ABL & 2048) != 0 ? 16 : a.v_sn, out_sn = (ABL & 1024) != 0 ? 16 : a.out_sn;
     asm volatile("" : "+s"(v_sn), "+s"(out_sn));
     const char* vb; char* ob; const float2* gp;
     tile_ptrs(tile, vb, ob, gp);
     const char* vbn = vb; char* obn = ob; const float2* gpn = gp;
-    if (more) tile_ptrs(tile + 2, vbn, obn, gpn);
+    if (more) tile_ptrs((ABL & 8192) != 0 ? pair_base + 2 * ((it + 1 + rot) % a.tpw) : tile + tile_step, vbn, obn, gpn);
     const __amdgpu_buffer_rsrc_t rs_next = rsrc_in(vbn, v_sn), rs_out = rsrc_out(ob, out_sn);
 
     stamp(it, 0);
@@ -231,6 +301,21 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
       static_for<0, SPLIT>([&](auto gc) { read_group(gc); });
     }
 
+    [[maybe_unused]] const uint32_t pf_ooff = (uint32_t)(((long long)(u + 512 * h) * out_sn + 4 * pp) * 4);
+    [[maybe_unused]] const uint32_t pf_voff = (uint32_t)(((long long)(u + 512 * h) * v_sn + 4 * pp) * 4);
+    [[maybe_unused]] auto pf_store = [&](auto ic) {
+      constexpr int g = GP + decltype(ic)::value / 4, m = decltype(ic)::value % 4;
+      store16(rsrc_out(obp, out_sn), pf_ooff + (uint32_t)((64 * g + 1024 * m) * out_sn * 4), dfr[decltype(ic)::value]);
+    };
+    [[maybe_unused]] auto pf_load = [&](auto ic) {
+      constexpr int g = GP + decltype(ic)::value / 4, m = decltype(ic)::value % 4;
+      const p64_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_next, pf_voff + (uint32_t)((64 * g + 1024 * m) * v_sn * 4), 0, 0);
+      dfr[decltype(ic)::value] = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
+    };
+    [[maybe_unused]] auto pf_block = [&]() {
+      if (it > 0) static_for<0, 4 * PF>([&](auto ic) { pf_store(ic); });
+      if (more) static_for<0, 4 * PF>([&](auto ic) { pf_load(ic); });
+    };
     stamp(it, 1);
     // ---- F1: 64-point forward transform over n1 (register position 8g + e holds row g + 8e), then W_N^(u*k1) ------------
     static_for<0, 8>([&](auto gc) {
@@ -240,11 +325,10 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
       static_for<1, 8>([&](auto kac) { constexpr int ka = decltype(kac)::value; z[8 * g + ka] = twid64<g * ka, false>(z[8 * g + ka]); });
       if constexpr (FEN) { pin8<8 * g, 1>(z); __builtin_amdgcn_sched_barrier(0); }
     });
-    gate_commit();                                 // this tile's gate bins (fetched behind the previous tile's stores) -> LDS
     {
       float2 wa[8], wb[8];
       __builtin_amdgcn_sched_barrier(0);           // keep the base loads (and their registers) out of stage 1
-      static_for<1, 8>([&](auto jc) { constexpr int j = decltype(jc)::value; wa[j] = a.tw[u * j]; wb[j] = a.tw[u * 8 * j]; });
+      load_twiddles(wa, wb, u);
       static_for<0, 8>([&](auto kac) {                                                        // over g -> kb at position 8kb + ka: k1 = position
         bfly<8, false, decltype(kac)::value, 8, 64>(z);
         if constexpr (FEN) { pin8<decltype(kac)::value, 8>(z); __builtin_amdgcn_sched_barrier(0); }
@@ -256,27 +340,13 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
         if constexpr (FEN && ka == 7) { pin8<8 * kb, 1>(z); __builtin_amdgcn_sched_barrier(0); }   // one wb at a time
       });
     }
+    // ---- the quiet part of the tile starts: the deferred results of the previous tile leave, the same row groups of the next tile
+    //      are requested into the registers they vacate
+    if constexpr (PF > 0) pf_block();
 
-    // ---- the quiet part of the tile starts: flush the deferred results of the previous tile, request the same row groups
-    //      of the next tile into the registers they leave
-    if constexpr (PF > 0) {
-      const uint32_t ooff = (uint32_t)(((long long)(u + 512 * h) * out_sn + 4 * pp) * 4);
-      const uint32_t voff = (uint32_t)(((long long)(u + 512 * h) * v_sn + 4 * pp) * 4);
-      if (it > 0) {
-        static_for<0, 4 * PF>([&](auto ic) {
-          constexpr int g = GP + decltype(ic)::value / 4, m = decltype(ic)::value % 4;
-          store16(rsrc_out(obp, out_sn), ooff + (uint32_t)((64 * g + 1024 * m) * out_sn * 4), dfr[decltype(ic)::value]);
-        });
-      }
-      if (more) {
-        static_for<0, 4 * PF>([&](auto ic) {
-          constexpr int g = GP + decltype(ic)::value / 4, m = decltype(ic)::value % 4;
-          const p64_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_next, voff + (uint32_t)((64 * g + 1024 * m) * v_sn * 4), 0, 0);
-          dfr[decltype(ic)::value] = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
-        });
-      }
-    }
-
+    // this tile's gate bins -> LDS.  They were requested behind the previous tile's last stores, so waiting for them means waiting
+    // for every store of that tile to be acknowledged: as late as possible (the bins are first read after E1's barriers)
+    gate_commit();
     // ---- E1: position k1 -> image row k1, column (p, u); thread (p, s = u) reads row u, slot n2 ---------------------------
     stamp(it, 2);
     __syncthreads();                               // every wave has emptied its landing slots / finished E2's reads of the previous tile
@@ -360,7 +430,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
     // ---- conj twiddle, I2, stores (spectre.py:553) interleaved with the loads that refill the released registers -----------
     {
       float2 wa[8], wb[8];
-      static_for<1, 8>([&](auto jc) { constexpr int j = decltype(jc)::value; wa[j] = a.tw[u * j]; wb[j] = a.tw[u * 8 * j]; });
+      load_twiddles(wa, wb, u);
       static_for<1, 64>([&](auto jc) {
         constexpr int j = decltype(jc)::value, ja = j % 8, jb = j / 8;   // position j carries k1 = j
         if constexpr (ja > 0) z[j] = cmulc(z[j], wa[ja]);
@@ -374,9 +444,12 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
       const uint32_t ooff = (uint32_t)(((long long)(u + 512 * h) * out_sn + 4 * pp) * 4);
       static_for<0, 8>([&](auto ic) {
         constexpr int g = (decltype(ic)::value + SPLIT) % 8;             // register-loaded groups first: their reloads start earliest
+        constexpr bool stores_now = g < GP && ((ABL & 64) == 0 || decltype(ic)::value % 2 == 0) && ((ABL & 128) == 0 || decltype(ic)::value % 4 == 0);                               // (deferred groups are stored before the next E1)
+        if constexpr (stores_now) gang_arrive();
         fftA_stage2_group<8, 8, true, g>(z);                              // rows g + 8e at positions 8g + e
         if constexpr (FEN) pin8<8 * g, 1>(z);
         swap_group(std::integral_constant<int, g>{});
+        if constexpr (stores_now) gang_await(members);
         static_for<0, 4>([&](auto mc) {
           constexpr int m = decltype(mc)::value;
           const float4 res = make_float4(z[8 * g + 2 * m].x, z[8 * g + 2 * m].y, z[8 * g + 2 * m + 1].x, z[8 * g + 2 * m + 1].y);
@@ -402,6 +475,9 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
                                                    // a harmless re-read of this tile's bins — keeps the staging registers out of a loop-carried phi)
     stamp(it, 5);
   }  // tile loop
+  if constexpr ((ABL & 32) != 0) {
+    if (gcnt != nullptr && (tid0 & 63) == 0) { gcnt[1] = gang_polls; gcnt[2] = gang_live ? 1u : 0u; }
+  }
 }
 
 hipError_t launch_regtile64p(const RegtileArgs& a, hipStream_t stream);

@@ -6,13 +6,14 @@ namespace sfft {
 hipError_t launch_regtile64p(const RegtileArgs& a, hipStream_t stream) {
   const bool with_mem = a.mem != nullptr;
   static std::atomic<bool> lds_opt_in[16][2];   // [device]: > 64 KiB of dynamic LDS needs a one-time opt-in (idempotent; the flag only saves the call)
-  // PF = row groups whose stores / loads are moved into the exchange / middle phase.  Interleaved A/B on one box
-  // (tools/p64_ab_bench.hip, profiles/r02_p64_ab.log): PF = 0 1.792 ms, PF = 1 1.761 ms, PF = 2 1.823 ms (register pressure in the
-  // middle phase); SPLIT = 4 / 3 / 2 groups through LDS: 1.792 / 1.822 / 2.007 ms; round-1 kernel 1.918 ms.  SPECTRE_P64_PF overrides.
-  static const int pf = [] { const char* e = getenv("SPECTRE_P64_PF"); return e ? atoi(e) : 1; }();
-  auto kern = pf == 2 ? spectre_mix_regtile64p<4, 2> : pf == 1 ? spectre_mix_regtile64p<4, 1> : pf == -1 ? spectre_mix_regtile64p<4, 0, 0, true>
-                                                                                                          : spectre_mix_regtile64p<4, 0>;
-  if (with_mem) kern = spectre_mix_regtile64p<4, 0, 0, true, true>;   // + memory_fft (spectre.py:548-549)
+  // PF = row groups whose stores / loads are moved out of the store/load burst to the end of F1 (16 registers each).  Interleaved A/B on
+  // one box (tools/p64_ab_bench.hip, profiles/r02_p64_ab_lds_twiddles.log): round-1 kernel 1.859 ms, PF = 1 1.680, PF = 2 1.637,
+  // PF = 3 1.621 (248 VGPRs), PF = 4 1.882 (spills).  Before the twiddle vectors moved into LDS (216 instead of 244 VGPRs at PF = 1)
+  // only PF = 1 fitted.  SPECTRE_P64_PF overrides (0 .. 3; -1 = PF 0 with scheduling fences).
+  static const int pf = [] { const char* e = getenv("SPECTRE_P64_PF"); return e ? atoi(e) : 3; }();
+  auto kern = pf == 3 ? spectre_mix_regtile64p<4, 3> : pf == 2 ? spectre_mix_regtile64p<4, 2> : pf == 1 ? spectre_mix_regtile64p<4, 1>
+              : pf == -1 ? spectre_mix_regtile64p<4, 0, 0, true> : spectre_mix_regtile64p<4, 0>;
+  if (with_mem) kern = spectre_mix_regtile64p<4, 1, 0, true, true>;   // + memory_fft (spectre.py:548-549)
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev < 0 || dev >= 16 || !lds_opt_in[dev][with_mem]) {

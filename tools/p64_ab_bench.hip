@@ -53,15 +53,36 @@ int main() {
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     vs.push_back({"round-1 regtile<64,64> (one tile per workgroup)", [=] { hipLaunchKernelGGL(kern, dim3(o.n_wg), dim3(512), lds, 0, o); }, {}});
   }
-  vs.push_back({"pipelined SPLIT=4 PF=0           tpw=48", make(spectre_mix_regtile64p<4, 0, 0, false>, a, 48, kP64LdsTotal), {}});
-  vs.push_back({"pipelined SPLIT=4 PF=0 fenced    tpw=48", make(spectre_mix_regtile64p<4, 0, 0, true>, a, 48, kP64LdsTotal), {}});
-  vs.push_back({"pipelined SPLIT=4 PF=1           tpw=48", make(spectre_mix_regtile64p<4, 1, 0, true>, a, 48, kP64LdsTotal), {}});
-  vs.push_back({"pipelined SPLIT=4 PF=2           tpw=48", make(spectre_mix_regtile64p<4, 2, 0, true>, a, 48, kP64LdsTotal), {}});
-  vs.push_back({"pipelined SPLIT=3 PF=0           tpw=48", make(spectre_mix_regtile64p<3, 0, 0, false>, a, 48, kP64LdsTotal), {}});
-  vs.push_back({"pipelined SPLIT=2 PF=0           tpw=48", make(spectre_mix_regtile64p<2, 0, 0, false>, a, 48, kP64LdsTotal), {}});
-  vs.push_back({"pipelined SPLIT=4 PF=0           tpw=2 ", make(spectre_mix_regtile64p<4, 0, 0, false>, a, 2, kP64LdsTotal), {}});
-  vs.push_back({"pipelined SPLIT=4 PF=0           tpw=1 ", make(spectre_mix_regtile64p<4, 0, 0, false>, a, 1, kP64LdsTotal), {}});
-  vs.push_back({"pipelined SPLIT=4 PF=0 fenced    tpw=2 ", make(spectre_mix_regtile64p<4, 0, 0, true>, a, 2, kP64LdsTotal), {}});
+  unsigned* cnt; CK(hipMalloc(&cnt, 256 * 128));
+  auto with_sync = [&](auto kern, RegtileArgs x, int tpw) {
+    auto f = make(kern, x, tpw, kP64LdsTotal);
+    return std::function<void()>([=] { CK(hipMemsetAsync(cnt, 0, 256 * 128)); f(); });
+  };
+  RegtileArgs as = a; as.gang_cnt = cnt;
+  vs.push_back({"pipelined PF=1                      tpw=48", make(spectre_mix_regtile64p<4, 1, 0, true>, a, 48, kP64LdsTotal), {}});
+  vs.push_back({"pipelined PF=2                      tpw=48", make(spectre_mix_regtile64p<4, 2, 0, true>, a, 48, kP64LdsTotal), {}});
+  vs.push_back({"pipelined PF=3                      tpw=48", make(spectre_mix_regtile64p<4, 3, 0, true>, a, 48, kP64LdsTotal), {}});
+  vs.push_back({"pipelined PF=4                      tpw=48", make(spectre_mix_regtile64p<4, 4, 0, true>, a, 48, kP64LdsTotal), {}});
+  vs.push_back({"pipelined SPLIT=3 PF=3              tpw=48", make(spectre_mix_regtile64p<3, 3, 0, true>, a, 48, kP64LdsTotal), {}});
+  vs.push_back({"pipelined PF=1 + wave-pair rendezvous tpw=48", with_sync(spectre_mix_regtile64p<4, 1, 32, true>, as, 48), {}});
+  vs.push_back({"pipelined PF=1, stores dropped (empty range) ", make(spectre_mix_regtile64p<4, 1, 256, true>, a, 48, kP64LdsTotal), {}});
+  vs.push_back({"pipelined PF=1, loads answered with 0        ", make(spectre_mix_regtile64p<4, 1, 512, true>, a, 48, kP64LdsTotal), {}});
+  vs.push_back({"pipelined PF=1, neither (VALU + LDS only)    ", make(spectre_mix_regtile64p<4, 1, 768, true>, a, 48, kP64LdsTotal), {}});
+  vs.push_back({"pipelined PF=1, stores stay in the L2        ", make(spectre_mix_regtile64p<4, 1, 1024, true>, a, 48, kP64LdsTotal), {}});
+  vs.push_back({"pipelined PF=1, loads hit the L2             ", make(spectre_mix_regtile64p<4, 1, 2048, true>, a, 48, kP64LdsTotal), {}});
+  vs.push_back({"pipelined PF=1, both inside the L2           ", make(spectre_mix_regtile64p<4, 1, 3072, true>, a, 48, kP64LdsTotal), {}});
+  vs.push_back({"pipelined PF=1, loads hit the L2, no stores  ", make(spectre_mix_regtile64p<4, 1, 2048 + 256, true>, a, 48, kP64LdsTotal), {}});
+  vs.push_back({"pipelined PF=1, stores stay in the L2, no loads", make(spectre_mix_regtile64p<4, 1, 1024 + 512, true>, a, 48, kP64LdsTotal), {}});
+  for (int step : {1, 5, 7, 11, 17}) {
+    RegtileArgs ar = a; ar.pf_dist = step;
+    vs.push_back({"pipelined PF=1, pairs start " + std::to_string(step) + " tiles apart in their ranges", make(spectre_mix_regtile64p<4, 1, 8192, true>, ar, 48, kP64LdsTotal), {}});
+  }
+  vs.push_back({"pipelined PF=1, chip-wide sweep              ", make(spectre_mix_regtile64p<4, 1, 4096, true>, a, 48, kP64LdsTotal), {}});
+  vs.push_back({"pipelined PF=1, chip-wide sweep + rendezvous ", with_sync(spectre_mix_regtile64p<4, 1, 4096 + 32, true>, as, 48), {}});
+  vs.push_back({"pipelined PF=1 + rendezvous every 2nd group", with_sync(spectre_mix_regtile64p<4, 1, 32 + 64, true>, as, 48), {}});
+  vs.push_back({"pipelined PF=1 + rendezvous every 4th group", with_sync(spectre_mix_regtile64p<4, 1, 32 + 128, true>, as, 48), {}});
+  vs.push_back({"pipelined PF=0 fenced               tpw=48", make(spectre_mix_regtile64p<4, 0, 0, true>, a, 48, kP64LdsTotal), {}});
+  vs.push_back({"pipelined PF=0 fenced + rendezvous  tpw=48", with_sync(spectre_mix_regtile64p<4, 0, 32, true>, as, 48), {}});
 
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (auto& x : vs) { x.launch(); x.launch(); }
@@ -78,6 +99,16 @@ int main() {
     std::sort(x.ms.begin(), x.ms.end());
     const float med = x.ms[x.ms.size() / 2];
     printf("%-52s min %.3f  median %.3f  max %.3f ms   %.0f GB/s  frac %.3f\n", x.name.c_str(), x.ms.front(), med, x.ms.back(), bytes / med / 1e6, bytes / med / 1e6 / 8000);
+  }
+  // rendezvous statistics of one launch: arrivals per wave pair (2 x rendezvous per wave if nobody dropped out), failed polls, survivors
+  for (int pf : {1, 0}) {
+    auto f = pf ? with_sync(spectre_mix_regtile64p<4, 1, 32, true>, as, 48) : with_sync(spectre_mix_regtile64p<4, 0, 32, true>, as, 48);
+    f(); CK(hipDeviceSynchronize());
+    std::vector<unsigned> h(256 * 32);
+    CK(hipMemcpy(h.data(), cnt, 256 * 128, hipMemcpyDeviceToHost));
+    unsigned lo = ~0u, hi = 0, live = 0; double polls = 0;
+    for (int i = 0; i < 128 * 8; ++i) { lo = std::min(lo, h[i * 4]); hi = std::max(hi, h[i * 4]); polls += h[i * 4 + 1]; live += h[i * 4 + 2]; }
+    printf("PF=%d: arrivals per wave pair min %u max %u; failed polls per wave and launch %.1f (last writer of each pair); pairs whose last writer was still live %u / 1024\n", pf, lo, hi, polls / 1024, live);
   }
   return 0;
 }

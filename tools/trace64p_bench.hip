@@ -12,9 +12,9 @@
 using namespace sfft;
 static double pct(std::vector<double> v, double p) { if (v.empty()) return 0; std::sort(v.begin(), v.end()); return v[(size_t)(p * (v.size() - 1))]; }
 
-template <int SPLIT, int PF = 0, bool FEN = (PF > 0)>
+template <int SPLIT, int PF = 0, bool FEN = (PF > 0), int ABLX = 0>
 void run(const char* name, RegtileArgs a, int tpw) {
-  auto kern = spectre_mix_regtile64p<SPLIT, PF, 16, FEN>;
+  auto kern = spectre_mix_regtile64p<SPLIT, PF, 16 | ABLX, FEN>;
   a.tiles_per_row = a.D / 16; a.n_tiles = a.B * a.tiles_per_row;
   a.tpw = tpw; a.n_wg = 2 * ((a.n_tiles + 2 * tpw - 1) / (2 * tpw));
   unsigned long long* tr;
@@ -81,5 +81,10 @@ int main() {
   run<4, 0, true>("pipelined fenced", a, 48);
   run<4, 1>("pipelined", a, 48);
   run<4, 2>("pipelined", a, 48);
+  // the same instruction stream with part of the traffic kept out of HBM (kernel_regtile64p.h ABL bits 8-11)
+  run<4, 1, true, 1024>("stores stay in the L2", a, 48);
+  run<4, 1, true, 2048>("loads hit the L2", a, 48);
+  run<4, 1, true, 3072>("loads and stores inside the L2", a, 48);
+  run<4, 1, true, 768>("no loads, no stores", a, 48);
   return 0;
 }
