@@ -82,6 +82,51 @@ __device__ __forceinline__ void p64_stageB2(float2 (&z)[64]) {      // type B st
   });
 }
 
+// The two exchanges of this kernel (kernel_regtile.h exchange_planes_b128 with wr(j) = j * RW + p * PS + u, rd4(m) = u * RW + p * PS + m),
+// with the 64 scattered dword writes of a plane issued as 32 ds_write2st64_b32: the LDS takes a store's address and data registers at
+// 2 cycles per dword, so one instruction with two data dwords (6 cycles) beats two ds_write_b32 (8 cycles), and the writes are 80 % of
+// an exchange's LDS time.  Rows j and j + 2 are 2 * 2176 = 17 * 256 bytes apart — a multiple of the instruction's 256-byte offset unit;
+// its 8-bit offsets reach 30 rows, hence four opaque base addresses (even / odd rows below and above 32) instead of one.
+template <bool LAST_BARRIER>
+__device__ __forceinline__ void p64_exchange(float2 (&z)[64], float* img, int p, int u) {
+  constexpr int RW = 8 * 68, PS = 68;
+  typedef __attribute__((address_space(3))) float lds_float;
+  lds_float* w0 = (lds_float*)(img + p * PS + u);
+  lds_float *w1 = w0 + RW, *w2 = w0 + 32 * RW, *w3 = w0 + 33 * RW;
+  asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3));       // keep them apart: base + 16-bit offset would fold them back together
+  const float* rd = img + u * RW + p * PS;
+  auto write_plane = [&](auto is_im) {
+    static_for<0, 16>([&](auto ic) {                                  // rows (4i, 4i + 2) and (4i + 1, 4i + 3)
+      constexpr int j = 4 * decltype(ic)::value, jw = j % 32;
+      lds_float* we = j < 32 ? w0 : w2;
+      lds_float* wo = j < 32 ? w1 : w3;
+      if constexpr (decltype(is_im)::value) {
+        we[jw * RW] = z[j].y; we[(jw + 2) * RW] = z[j + 2].y;
+        wo[jw * RW] = z[j + 1].y; wo[(jw + 2) * RW] = z[j + 3].y;
+      } else {
+        we[jw * RW] = z[j].x; we[(jw + 2) * RW] = z[j + 2].x;
+        wo[jw * RW] = z[j + 1].x; wo[(jw + 2) * RW] = z[j + 3].x;
+      }
+    });
+  };
+  auto read_plane = [&](auto is_im) {
+    static_for<0, 16>([&](auto ic) {
+      constexpr int i = decltype(ic)::value, m = 4 * ((i / 8) + 2 * (i % 8));   // the chunk order of exchange_planes_b128<64, 8, 8>
+      const float4 v = *reinterpret_cast<const float4*>(rd + m);
+      if constexpr (decltype(is_im)::value) { z[m].y = v.x; z[m + 1].y = v.y; z[m + 2].y = v.z; z[m + 3].y = v.w; }
+      else { z[m].x = v.x; z[m + 1].x = v.y; z[m + 2].x = v.z; z[m + 3].x = v.w; }
+    });
+  };
+  write_plane(std::false_type{});
+  __syncthreads();
+  read_plane(std::false_type{});
+  __syncthreads();
+  write_plane(std::true_type{});
+  __syncthreads();
+  read_plane(std::true_type{});
+  if constexpr (LAST_BARRIER) __syncthreads();     // image free again
+}
+
 // SPLIT = row groups (of 8) of the next tile that travel through LDS (0: everything is loaded behind the stores).
 // PF    = row groups whose I/O is moved out of the store/load burst into the exchange / middle phase, when no other memory
 //         traffic of this CU (and, the chip running in lock-step, of hardly any CU) is in flight: the results of the last PF
@@ -350,9 +395,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
     // ---- E1: position k1 -> image row k1, column (p, u); thread (p, s = u) reads row u, slot n2 ---------------------------
     stamp(it, 2);
     __syncthreads();                               // every wave has emptied its landing slots / finished E2's reads of the previous tile
-    exchange_planes_b128<64, 8, 8>(z, img,
-        [&](auto jc) { return decltype(jc)::value * RW + p * PS + u; },
-        [&](auto mc) { return u * RW + p * PS + decltype(mc)::value; });
+    p64_exchange<true>(z, img, p, u);
 
     stamp(it, 3);
     // ---- middle: F2 -> gate -> I1 (kernel_regtile.h; bin of register (ka, kb): k = k1 + 64 k2, k2 = ka + 8 kb) -------------
@@ -415,9 +458,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
     }
 
     // ---- E2: position n2 -> image row n2, column (p, k1 = u); thread (p, u) reads row u, slot k1 --------------------------
-    exchange_planes_b128<64, 8, 8, (SPLIT > 0)>(z, img,
-        [&](auto jc) { return decltype(jc)::value * RW + p * PS + u; },
-        [&](auto mc) { return u * RW + p * PS + decltype(mc)::value; });
+    p64_exchange<(SPLIT > 0)>(z, img, p, u);
 
     stamp(it, 4);
     // ---- the image is idle until the next E1: let the first row groups of the next tile land in it, and fetch its gate -----
