@@ -134,9 +134,8 @@ __global__ void __launch_bounds__(kPC * RS) spectre_gate_grad_regtile(const Gate
     // ---- E1 (identical to the forward kernel) ------------------------------------------------------------------
     if constexpr (XV) {
       constexpr int PS = RS + 4, RW = kPC * PS;
-      exchange_planes_b128<RF, RAS, RBS>(z, img,
-          [&](auto jc) { constexpr int j = decltype(jc)::value; constexpr int k1 = (j / RBF) + RAF * (j % RBF);
-                         return k1 * RW + p * PS + u; },
+      exchange_planes_b128_w2<RF, RAS, RBS, true, RF, 1, 0, RW>(z, img, p * PS + u,
+          [](auto rc, auto) { constexpr int k1 = decltype(rc)::value; return std::integral_constant<int, RBF * (k1 % RAF) + k1 / RAF>{}; },
           [&](auto mc) { constexpr int m = decltype(mc)::value; constexpr int t = m / RS, n2 = m % RS;
                          return (u + RS * t) * RW + p * PS + n2; });
     } else {
