@@ -77,43 +77,50 @@ __global__ void __launch_bounds__(kPC * RS) spectre_gate_grad_regtile(const Gate
 
   for (int k = tid; k <= N / 2; k += kPC * RS) acc[k] = make_float2(0.f, 0.f);   // ordered by E1's barriers
 
+  // Loads: buffer instructions — workgroup-uniform base of the tile (SGPRs) + one 32-bit lane offset + the row-block offset.  Fast
+  // mode: the row-block offset is the instruction's scalar offset (no VALU at all).  GENERAL: it is added to the lane offset, because
+  // the range check covers only that operand: rows >= N_in and the lanes of a ragged last tile (lane offset 0x80000000) are the
+  // out-of-range case, which returns 0 = rfft's zero padding — no predicates, no pointer selects.
+  float2 z[RF];
+  auto load_row = [&](int jt_, auto qc, long long v_sn, long long d_sn, int p, int u) {
+    constexpr int q = decltype(qc)::value;
+    const int c0 = g * a.d_g + kPC * jt_;            // first channel of the tile
+    const int rows = a.N_in < N ? a.N_in : N;
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(a.v)) + ((size_t)b * a.v_sb + c0) * ES, 0, GENERAL ? (int)(rows * v_sn * ES) : 0x7fffffff, kRsrcFlags);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(a.dout)) + ((size_t)b * a.dout_sb + c0) * ES, 0, GENERAL ? (int)(rows * d_sn * ES) : 0x7fffffff, kRsrcFlags);
+    uint32_t vo = (uint32_t)(((long long)u * v_sn + p) * ES), dof = (uint32_t)(((long long)u * d_sn + p) * ES);
+    uint32_t vs = (uint32_t)((long long)q * RS * v_sn * ES), ds = (uint32_t)((long long)q * RS * d_sn * ES);
+    if constexpr (GENERAL) {
+      const bool cok = kPC * jt_ + p < a.d_g;
+      vo = cok ? vo + vs : 0x80000000u; dof = cok ? dof + ds : 0x80000000u;
+      vs = 0; ds = 0;
+    }
+    float x, dy;
+    if constexpr (IO_BF16) {
+      x = __uint_as_float((uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rv, vo, vs, 0) << 16);
+      dy = __uint_as_float((uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rd, dof, ds, 0) << 16);
+    } else {
+      x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rv, vo, vs, 0));
+      dy = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, dof, ds, 0));
+    }
+    z[q] = make_float2(x, dy);
+  };
+  {  // the first tile of this workgroup; every later one is requested inside the previous iteration
+    long long v_sn = a.v_sn, d_sn = a.dout_sn;
+    static_for<0, RF>([&](auto ic) {
+      constexpr int q = (decltype(ic)::value / RAF) + RBF * (decltype(ic)::value % RAF);   // order of use in F1
+      load_row(s, std::integral_constant<int, q>{}, v_sn, d_sn, p0, u0);
+    });
+  }
+
   for (int jt = s; jt < a.T; jt += a.S) {
     int p = p0, u = u0;
     asm volatile("" : "+v"(p), "+v"(u));            // see kernel_regtile.h: keeps per-lane addresses out of LICM
     long long v_sn = a.v_sn, d_sn = a.dout_sn;
     asm volatile("" : "+s"(v_sn), "+s"(d_sn));
-    const int cl = kPC * jt + p;                     // channel inside the group
-    bool cok = true;
-    if constexpr (GENERAL) cok = cl < a.d_g;
-    const int c = g * a.d_g + (cok ? cl : 0);
-
-    float2 z[RF];
-    // ---- load z = x + i*dy, rows u + RS*q (zero rows beyond N_in: rfft's padding, and dOut has no such rows) ----
-    {
-      const char* vb = reinterpret_cast<const char*>(a.v) + ((size_t)b * a.v_sb + c) * ES;
-      const char* db = reinterpret_cast<const char*>(a.dout) + ((size_t)b * a.dout_sb + c) * ES;
-      const uint32_t voff = (uint32_t)((long long)u * v_sn * ES), doff = (uint32_t)((long long)u * d_sn * ES);
-      static_for<0, RF>([&](auto ic) {
-        constexpr int q = (decltype(ic)::value / RAF) + RBF * (decltype(ic)::value % RAF);   // order of use in F1
-        const char* pv = vb + (size_t)q * RS * v_sn * ES + voff;
-        const char* pd = db + (size_t)q * RS * d_sn * ES + doff;
-        bool ok = true;
-        if constexpr (GENERAL) {
-          ok = cok && (u + RS * q) < a.N_in;
-          pv = ok ? pv : vb;
-          pd = ok ? pd : db;
-        }
-        float x, dy;
-        if constexpr (IO_BF16) {
-          x = __uint_as_float((uint32_t)(*reinterpret_cast<const uint16_t*>(pv)) << 16);
-          dy = __uint_as_float((uint32_t)(*reinterpret_cast<const uint16_t*>(pd)) << 16);
-        } else {
-          x = *reinterpret_cast<const float*>(pv);
-          dy = *reinterpret_cast<const float*>(pd);
-        }
-        z[q] = ok ? make_float2(x, dy) : make_float2(0.f, 0.f);
-      });
-    }
+    const bool more = jt + a.S < a.T;                // workgroup-uniform
 
     // ---- F1 + W_N^(u*k1) ------------------------------------------------------------------------------------
     {
@@ -149,7 +156,10 @@ __global__ void __launch_bounds__(kPC * RS) spectre_gate_grad_regtile(const Gate
     // ---- F2: position t*RS + RBS*ka + kb holds A[k1 + RF*k2], k1 = u + RS*t, k2 = ka + RAS*kb ------------------
     static_for<0, NS>([&](auto tc) { fftA<RAS, RBS, false, decltype(tc)::value * RS, RF>(z); });
 
-    // ---- partner exchange: upper half (k2 >= RS/2, i.e. kb >= RBS/2) of every set goes to LDS --------------------
+    // ---- partner exchange: upper half (k2 >= RS/2, i.e. kb >= RBS/2) of every set goes to LDS.  A register that has been written
+    //      is dead: the row of the NEXT tile that lives at its position is requested into it right away, so that half of the next
+    //      tile is in flight while the products are formed (and the other half follows register by register as they are consumed).
+    const float nyq = z[RBS / 2].x * z[RBS / 2].y;   // Nyquist (set 0, ka = 0, kb = RBS/2): needed after its register is reused
     static_for<0, NS>([&](auto tc) {
       constexpr int t = decltype(tc)::value;
       float* wre = img + (u + RS * t) * RW2 + p * PS2;
@@ -162,6 +172,16 @@ __global__ void __launch_bounds__(kPC * RS) spectre_gate_grad_regtile(const Gate
         });
       });
     });
+    if (more) {
+      static_for<0, NS>([&](auto tc) {
+        static_for<0, RAS>([&](auto kac) {
+          static_for<RBS / 2, RBS>([&](auto kbc) {
+            constexpr int j = decltype(tc)::value * RS + RBS * decltype(kac)::value + decltype(kbc)::value;
+            load_row(jt + a.S, std::integral_constant<int, j>{}, v_sn, d_sn, p, u);
+          });
+        });
+      });
+    }
     __syncthreads();
     static_for<0, NS>([&](auto tc) {
       constexpr int t = decltype(tc)::value;
@@ -186,11 +206,11 @@ __global__ void __launch_bounds__(kPC * RS) spectre_gate_grad_regtile(const Gate
             cur.x += sr; cur.y += si;
             acc[k1 + RF * k2] = cur;
           }
+          if (more) load_row(jt + a.S, std::integral_constant<int, j>{}, v_sn, d_sn, p, u);   // z[j] is dead
         });
       });
       if constexpr (t == 0) {                         // Nyquist: k1 = 0, k2 = RS/2 (ka = 0, kb = RBS/2): Re(A) Im(A)
-        constexpr int j = RBS / 2;
-        const float sr = team_sum8(k1z ? z[j].x * z[j].y : 0.f);
+        const float sr = team_sum8(k1z ? nyq : 0.f);
         if (p == 0 && k1z) acc[N / 2].x += sr;
       }
     });

@@ -611,8 +611,9 @@ int spectre_mix_bwd(const SpectreMixBwdArgs* a) {
     const int64_t n = a->n_fft, D = a->D, d_g = D / a->G_tot;
     const TileSize* ts = find_tile_size(n);
     static const bool force_stockham = [] { const char* e = getenv("SPECTRE_GATE_GRAD"); return e && !strcmp(e, "stockham"); }();
-    if (ts && ts->grad && !force_stockham && a->v_sn * 128 * 4 < ((int64_t)1 << 31) && a->dout_sn * 128 * 4 < ((int64_t)1 << 31) &&
-        a->B * a->G_tot * 8 < ((int64_t)1 << 31)) {
+    // (32-bit buffer offsets: a tile's last row has to lie below 2^31 bytes from its first; wider views take the Stockham path)
+    if (ts && ts->grad && !force_stockham && std::max<int64_t>(n, 128) * a->v_sn * 4 < ((int64_t)1 << 31) &&
+        std::max<int64_t>(n, 128) * a->dout_sn * 4 < ((int64_t)1 << 31) && a->B * a->G_tot * 8 < ((int64_t)1 << 31)) {
       // register-tile gate gradient (kernel_regtile_grad.h / kernel_regtile_mixed_grad.h): 8-channel tiles, S workgroups
       // per (batch, group)
       sfft::GateGradArgs k{};

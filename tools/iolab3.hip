@@ -136,7 +136,7 @@ int main() {
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   char *in, *out; CK(hipMalloc(&in, n)); CK(hipMalloc(&out, n)); CK(hipMemset(in, 0x3c, n)); CK(hipMemset(out, 0, n));
   CK(hipMalloc(&g_cnt, 65536 * 4));
-  for (int S : {64, 128, 256, 512, 1024, 0}) { run<0>(in, out, S, 1); run<1>(in, out, S, 1); run<2>(in, out, S, 1); }
+  for (int S : {16, 32, 64, 128, 256, 512, 1024, 0}) { run<0>(in, out, S, 1); run<1>(in, out, S, 1); run<2>(in, out, S, 1); }
   printf("-- the halves of a line requested by one workgroup, at a distance in time --\n");
   for (int sp : {1, 4, 5, 6, 2, 3}) { run<0>(in, out, 64, 1, sp); run<1>(in, out, 64, 1, sp); run<2>(in, out, 64, 1, sp); }
   printf("-- groups of neighbouring workgroups released together --\n");
