@@ -11,19 +11,26 @@
 //    attractor (a CU that loads while the others compute finishes early and drifts back into the pack), so HBM idles while the
 //    chip computes.  Loads of tile t+1 therefore have to be in flight while tile t is still being computed on the SAME CU
 //    (the persistent workgroups of this kernel do drift apart: 115 +- 14 of 256 are in their store/load burst at any instant);
-//  * what bounds that burst is the number of 64-byte row-segment requests a CU can have in flight (8192 per tile, ~3 ns each
-//    under load), not bytes;
 //  * a wave's stores and loads retire through one in-order counter (vmcnt): loads issued behind the stores of the previous
 //    tile cannot be consumed before those stores are acknowledged.  The next tile's first half is therefore requested BEFORE
 //    the stores, as LDS-DMA (buffer_load_dwordx4 ... lds, no VGPR needed) into the exchange image, which is idle between the last
 //    exchange of tile t and the first exchange of tile t+1.  Every lane reads back exactly the 16 bytes it requested, so the
 //    staging needs no barrier of its own;
-//  * the second half is loaded straight into the registers that the stores of I2 have just released (store register group g of
-//    tile t, then load row group g of tile t+1 into it: same 8 x 8 register <-> row pattern on both sides);
+//  * three of the other four row groups (PF = 3) are deferred: their results stay in 48 registers through F1 of the next tile, are
+//    stored at the end of F1, and the same registers then prefetch those groups of the tile after — 3/8 of the traffic travels while
+//    the CU exchanges and multiplies; the last group is loaded straight into the registers that the stores of I2 have just released;
+//  * for the same vmcnt reason nothing that is needed "now" may be a global load: the twiddle vectors live in LDS (written once per
+//    workgroup), the gate bins are requested a tile ahead and committed to LDS as late as possible;
 //  * 16-byte global accesses: a lane moves the 4 channels (2 packed sequences) of one row; v_permlane16_swap hands the
 //    second sequence to the partner lane (lane ^ 16) and receives the partner's row of this lane's sequence, so a lane still
 //    owns ONE sequence.  The lane <-> (sequence, row class) map is chosen so that the existing conflict-free LDS image layout
-//    stays conflict-free (checked with the bank model of MI355X_MICROARCH.md: write banks 4p + rc, b128 read groups distinct).
+//    stays conflict-free (checked with the bank model of MI355X_MICROARCH.md: write banks 4p + rc, b128 read groups distinct);
+//  * requests are issued as early and as bunched as the registers allow (spreading them over the arithmetic was slower), and pairs
+//    of workgroups walk through adjacent tiles: a 64-byte row segment is half an L2 line, the L2 fetches whole lines, and the
+//    neighbour's request a few microseconds later hits.  Larger gangs of neighbours collide on DRAM channels and were slower.
+// Where it stands: the same instruction stream without memory traffic takes 0.94 ms, with every request answered
+// by the L2 1.03 ms, the product 1.58-1.65 ms; the difference is HBM latency beyond what 128 KiB of staging + 48 registers cover and
+// the DRAM efficiency of half-line segments (tools/iolab3.hip).
 //
 // Thread <-> data:  lane = (pp = lane & 3, rcl = (lane >> 2) & 3, h = (lane >> 4) & 1, rch = lane >> 5);
 //   sequence p = 2 pp + h, team index u = rcl + 4 rch + 8 wave  (n2 in F1 / I2, k1 in the middle phase);
@@ -128,10 +135,12 @@ __device__ __forceinline__ void p64_exchange(float2 (&z)[64], float* img, int p,
 }
 
 // SPLIT = row groups (of 8) of the next tile that travel through LDS (0: everything is loaded behind the stores).
-// PF    = row groups whose I/O is moved out of the store/load burst into the exchange / middle phase, when no other memory
-//         traffic of this CU (and, the chip running in lock-step, of hardly any CU) is in flight: the results of the last PF
-//         groups of tile t stay in 16 PF registers through F1 of tile t+1 and are stored right before E1; the same registers
-//         then receive those groups of tile t+2, which trade places with the next results at the end of I2.
+// PF    = row groups whose I/O is moved out of the store/load burst into the exchange / middle phase, when this CU has no other
+//         memory traffic in flight: the results of the last PF groups of tile t stay in 16 PF registers through F1 of tile t+1 and
+//         are stored right before E1; the same registers then receive those groups of tile t+2, which trade places with the next
+//         results at the end of I2.  (3 in the library: 250 VGPRs; 4 spills.)
+// ABL   = experiments of tools/p64_ab_bench.hip / trace64p_bench.hip, 0 in the library: bit4 phase timestamps, bit5 wave-pair
+//         rendezvous, bits 8-11 traffic switched off or kept inside the L2, bit12 chip-wide sweep, bit13 rotated pair ranges.
 template <int SPLIT, int PF = 0, int ABL = 0, bool FEN = (PF > 0), bool WITH_MEM = false>
 __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileArgs a) {
   constexpr int RW = 8 * 68, PS = 68;              // image row / column strides in floats (kernel_regtile.h, 16-byte layout)
