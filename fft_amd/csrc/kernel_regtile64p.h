@@ -94,6 +94,8 @@ __device__ __forceinline__ void p64_stageB2(float2 (&z)[64]) {      // type B st
 // 2 cycles per dword, so one instruction with two data dwords (6 cycles) beats two ds_write_b32 (8 cycles), and the writes are 80 % of
 // an exchange's LDS time.  Rows j and j + 2 are 2 * 2176 = 17 * 256 bytes apart — a multiple of the instruction's 256-byte offset unit;
 // its 8-bit offsets reach 30 rows, hence four opaque base addresses (even / odd rows below and above 32) instead of one.
+template <bool IN_BF16> constexpr int kP64Gang = IN_BF16 ? 4 : 2;   // workgroups per 128-byte line (launch: n_wg is a multiple of it)
+
 template <bool LAST_BARRIER>
 __device__ __forceinline__ void p64_exchange(float2 (&z)[64], float* img, int p, int u) {
   constexpr int RW = 8 * 68, PS = 68;
@@ -141,9 +143,14 @@ __device__ __forceinline__ void p64_exchange(float2 (&z)[64], float* img, int p,
 //         results at the end of I2.  (3 in the library: 250 VGPRs; 4 spills.)
 // ABL   = experiments of tools/p64_ab_bench.hip / trace64p_bench.hip, 0 in the library: bit4 phase timestamps, bit5 wave-pair
 //         rendezvous, bits 8-11 traffic switched off or kept inside the L2, bit12 chip-wide sweep, bit13 rotated pair ranges.
-template <int SPLIT, int PF = 0, int ABL = 0, bool FEN = (PF > 0), bool WITH_MEM = false>
+// IN_BF16 = bf16 rows in (spectre.py's activations under autocast), fp32 arithmetic and fp32 rows out: a lane still moves the 4
+//         channels of a row — 8 bytes, two packed dwords = its two sequences — so the lane map, the swap and everything after it are
+//         the fp32 kernel's; only the staging differs (8-byte LDS-DMA does not exist: a DMA instruction fetches 8 whole 32-byte row
+//         segments, lane = (row, dword), and every lane reads its 8 bytes back out of its wave's slot).
+template <int SPLIT, int PF = 0, int ABL = 0, bool FEN = (PF > 0), bool WITH_MEM = false, bool IN_BF16 = false>
 __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileArgs a) {
   constexpr int RW = 8 * 68, PS = 68;              // image row / column strides in floats (kernel_regtile.h, 16-byte layout)
+  constexpr int ESI = IN_BF16 ? 2 : 4;             // bytes per input element
   constexpr float inv_n = 1.0f / 4096.0f;
   static_assert(SPLIT >= 0 && SPLIT <= 4 && SPLIT * 4 * 1024 * 8 <= kP64ImageBytes, "staging lives in the exchange image");
   static_assert(PF >= 0 && SPLIT + PF <= 8, "row groups: SPLIT through LDS, PF deferred / prefetched in registers, the rest behind their stores");
@@ -187,8 +194,11 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
   // ABL bit12 (tools/p64_ab_bench.hip): the whole chip sweeps the tiles front to back (tile = workgroup + n_wg * iteration, every XCD
   // on 32 adjacent tiles) instead of every pair of workgroups walking through its own 2 * tpw tiles
   constexpr bool SWEEP = (ABL & 4096) != 0;
-  const int tile_step = SWEEP ? a.n_wg : 2;
-  const int pair_base = SWEEP ? wg_lin : (wg_lin >> 1) * a.tpw * 2 + (wg_lin & 1);   // workgroups 2m, 2m+1 walk through adjacent tiles in step
+  // GANG neighbouring workgroups (same L2) walk through GANG adjacent tiles in step = one 128-byte line per row: the L2 fetches a
+  // line once and the neighbours' requests hit (fp32: two 64-byte halves; bf16: four 32-byte quarters)
+  constexpr int GANG = kP64Gang<IN_BF16>;
+  const int tile_step = SWEEP ? a.n_wg : GANG;
+  const int pair_base = SWEEP ? wg_lin : (wg_lin / GANG) * a.tpw * GANG + (wg_lin % GANG);
   if (pair_base >= a.n_tiles) return;
 
   // ABL bit5 (tools/p64_ab_bench.hip only; measured and NOT shipped: profiles/r02_p64_ab_rendezvous.log).  A 64-byte row segment is
@@ -236,9 +246,14 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
   char* obp = nullptr;                             // output tile of the deferred results
   float2 gstage[5];      // the next tile's gate bins on their way to LDS (4097 bins / 512 threads, rounded up; + 1 for the last)
 
+  // lane offset of an LDS-DMA request: fp32 = the lane's own 16 bytes (the register-load offset); bf16 = (row l >> 3, dword l & 7)
+  auto dma_voff = [&](uint32_t voff, long long sn) -> uint32_t {
+    if constexpr (IN_BF16) return (uint32_t)(((long long)((lane >> 3) + 8 * (u >> 3)) * sn) * ESI + (lane & 7) * 4);
+    else return voff;
+  };
   auto tile_ptrs = [&](int tile, const char*& vb, char*& ob, const float2*& gp) {
     const int b = tile / a.tiles_per_row, ct = tile - b * a.tiles_per_row;
-    vb = reinterpret_cast<const char*>(a.v) + ((size_t)b * a.v_sb + (size_t)ct * 16) * 4;
+    vb = reinterpret_cast<const char*>(a.v) + ((size_t)b * a.v_sb + (size_t)ct * 16) * ESI;
     ob = reinterpret_cast<char*>(a.out) + ((size_t)b * a.out_sb + (size_t)ct * 16) * 4;
     // ABL bit10 / bit11 (tools/p64_ab_bench.hip): every workgroup of an XCD stores to / loads from ONE dense 256-KiB tile (row stride
     // 64 bytes, see v_sn / out_sn in the tile loop) — real requests and acknowledgements that never leave the L2
@@ -254,27 +269,44 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
   // memory traffic (out-of-range stores are dropped, out-of-range loads return 0 before they leave the CU)
   auto rsrc_in = [&](const char* vb, long long sn) {
     const int rows = (ABL & 512) != 0 ? 0 : a.N_in < 4096 ? a.N_in : 4096;
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(vb), 0, (int)((long long)rows * sn * 4), kP64RsrcFlags);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(vb), 0, (int)((long long)rows * sn * ESI), kP64RsrcFlags);
   };
   auto rsrc_out = [&](char* ob, long long sn) {
     const int rows = (ABL & 256) != 0 ? 0 : a.N_in < 4096 ? a.N_in : 4096;
     return __builtin_amdgcn_make_buffer_rsrc(ob, 0, (int)((long long)rows * sn * 4), kP64RsrcFlags);
   };
+  auto unpack_lo = [](uint32_t d) { return make_float2(__uint_as_float(d << 16), __uint_as_float(d & 0xffff0000u)); };   // two bf16 -> (re, im)
   auto load_group = [&](__amdgpu_buffer_rsrc_t rs, uint32_t voff, long long sn, auto gc) {       // straight into the registers of group g
     constexpr int g = decltype(gc)::value;
     static_for<0, 4>([&](auto mc) {
       constexpr int m = decltype(mc)::value;
-      const p64_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + (uint32_t)((64 * g + 1024 * m) * sn * 4), 0, 0);
-      z[8 * g + 2 * m] = make_float2(__uint_as_float(t.x), __uint_as_float(t.y));
-      z[8 * g + 2 * m + 1] = make_float2(__uint_as_float(t.z), __uint_as_float(t.w));
+      if constexpr (IN_BF16) {
+        const rt_u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, voff + (uint32_t)((64 * g + 1024 * m) * sn * ESI), 0, 0);
+        z[8 * g + 2 * m] = unpack_lo(t.x);
+        z[8 * g + 2 * m + 1] = unpack_lo(t.y);
+      } else {
+        const p64_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + (uint32_t)((64 * g + 1024 * m) * sn * 4), 0, 0);
+        z[8 * g + 2 * m] = make_float2(__uint_as_float(t.x), __uint_as_float(t.y));
+        z[8 * g + 2 * m + 1] = make_float2(__uint_as_float(t.z), __uint_as_float(t.w));
+      }
     });
   };
-  auto dma_group = [&](__amdgpu_buffer_rsrc_t rs, uint32_t voff, long long sn, auto gc) {        // into this wave's LDS slots (1 KiB per instruction)
+  // fp32: 1 KiB per instruction, lane l's 16 bytes at slot + 16 l.  bf16: 256 B per instruction = the 8 rows (rcl + 4 rch) of one h,
+  // lane l = (row l >> 3, dword l & 7); dvoff = that lane's offset inside row block 0 (computed per tile by the caller).
+  auto dma_group = [&](__amdgpu_buffer_rsrc_t rs, uint32_t voff, long long sn, auto gc) {        // into this wave's LDS slots
     constexpr int g = decltype(gc)::value;
     static_for<0, 4>([&](auto mc) {
       constexpr int m = decltype(mc)::value;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(slot + (4 * g + m) * 1024), 16,
-                                               voff + (uint32_t)((64 * g + 1024 * m) * sn * 4), 0, 0, 0);
+      if constexpr (IN_BF16) {
+        static_for<0, 2>([&](auto hc) {
+          constexpr int hh = decltype(hc)::value;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(slot + ((4 * g + m) * 2 + hh) * 256), 4,
+                                                   voff + (uint32_t)((64 * g + 1024 * m + 512 * hh) * sn * ESI), 0, 0, 0);
+        });
+      } else {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(slot + (4 * g + m) * 1024), 16,
+                                                 voff + (uint32_t)((64 * g + 1024 * m) * sn * 4), 0, 0, 0);
+      }
     });
   };
   auto store16 = [&](__amdgpu_buffer_rsrc_t rs, uint32_t off, const float4 v) {
@@ -282,13 +314,19 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
     t.x = __float_as_uint(v.x); t.y = __float_as_uint(v.y); t.z = __float_as_uint(v.z); t.w = __float_as_uint(v.w);
     __builtin_amdgcn_raw_buffer_store_b128(t, rs, off, 0, 0);
   };
-  auto read_group = [&](auto gc) {                                       // this lane's 16 bytes back out of the slot
+  auto read_group = [&](auto gc) {                                       // this lane's bytes back out of the slot
     constexpr int g = decltype(gc)::value;
     static_for<0, 4>([&](auto mc) {
       constexpr int m = decltype(mc)::value;
-      const float4 t = *reinterpret_cast<const float4*>(slot + (4 * g + m) * 1024 + lane * 16);
-      z[8 * g + 2 * m] = make_float2(t.x, t.y);
-      z[8 * g + 2 * m + 1] = make_float2(t.z, t.w);
+      if constexpr (IN_BF16) {
+        const rt_u32x2 t = *reinterpret_cast<const rt_u32x2*>(slot + ((4 * g + m) * 2 + h) * 256 + (((lane >> 2) & 3) + 4 * (lane >> 5)) * 32 + pp * 8);
+        z[8 * g + 2 * m] = unpack_lo(t.x);
+        z[8 * g + 2 * m + 1] = unpack_lo(t.y);
+      } else {
+        const float4 t = *reinterpret_cast<const float4*>(slot + (4 * g + m) * 1024 + lane * 16);
+        z[8 * g + 2 * m] = make_float2(t.x, t.y);
+        z[8 * g + 2 * m + 1] = make_float2(t.z, t.w);
+      }
     });
   };
   auto swap_group = [&](auto gc) {      // rows (g + 16 m, g + 16 m + 8) of sequences (2pp, 2pp+1)  <->  both rows of sequence p
@@ -322,9 +360,9 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
   {
     const char* vb; char* ob; const float2* gp;
     tile_ptrs(pair_base, vb, ob, gp);
-    const uint32_t voff = (uint32_t)(((long long)(u + 512 * h) * a.v_sn + 4 * pp) * 4);
+    const uint32_t voff = (uint32_t)(((long long)(u + 512 * h) * a.v_sn + 4 * pp) * ESI);
     const __amdgpu_buffer_rsrc_t rs = rsrc_in(vb, a.v_sn);
-    static_for<0, SPLIT>([&](auto gc) { dma_group(rs, voff, a.v_sn, gc); });
+    static_for<0, SPLIT>([&](auto gc) { dma_group(rs, dma_voff(voff, a.v_sn), a.v_sn, gc); });
     asm volatile("" ::: "memory");
     static_for<SPLIT, 8>([&](auto gc) { load_group(rs, voff, a.v_sn, gc); });
     gate_fetch(gp);
@@ -356,15 +394,20 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
     }
 
     [[maybe_unused]] const uint32_t pf_ooff = (uint32_t)(((long long)(u + 512 * h) * out_sn + 4 * pp) * 4);
-    [[maybe_unused]] const uint32_t pf_voff = (uint32_t)(((long long)(u + 512 * h) * v_sn + 4 * pp) * 4);
+    [[maybe_unused]] const uint32_t pf_voff = (uint32_t)(((long long)(u + 512 * h) * v_sn + 4 * pp) * ESI);
     [[maybe_unused]] auto pf_store = [&](auto ic) {
       constexpr int g = GP + decltype(ic)::value / 4, m = decltype(ic)::value % 4;
       store16(rsrc_out(obp, out_sn), pf_ooff + (uint32_t)((64 * g + 1024 * m) * out_sn * 4), dfr[decltype(ic)::value]);
     };
     [[maybe_unused]] auto pf_load = [&](auto ic) {
       constexpr int g = GP + decltype(ic)::value / 4, m = decltype(ic)::value % 4;
-      const p64_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_next, pf_voff + (uint32_t)((64 * g + 1024 * m) * v_sn * 4), 0, 0);
-      dfr[decltype(ic)::value] = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
+      if constexpr (IN_BF16) {                       // stays packed (two dwords) until it trades places with the results in I2
+        const rt_u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs_next, pf_voff + (uint32_t)((64 * g + 1024 * m) * v_sn * ESI), 0, 0);
+        dfr[decltype(ic)::value].x = __uint_as_float(t.x); dfr[decltype(ic)::value].y = __uint_as_float(t.y);
+      } else {
+        const p64_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_next, pf_voff + (uint32_t)((64 * g + 1024 * m) * v_sn * 4), 0, 0);
+        dfr[decltype(ic)::value] = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
+      }
     };
     [[maybe_unused]] auto pf_block = [&]() {
       if (it > 0) static_for<0, 4 * PF>([&](auto ic) { pf_store(ic); });
@@ -471,9 +514,9 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
 
     stamp(it, 4);
     // ---- the image is idle until the next E1: let the first row groups of the next tile land in it, and fetch its gate -----
-    const uint32_t voff = (uint32_t)(((long long)(u + 512 * h) * v_sn + 4 * pp) * 4);
+    const uint32_t voff = (uint32_t)(((long long)(u + 512 * h) * v_sn + 4 * pp) * ESI);
     if (more) {
-      static_for<0, SPLIT>([&](auto gc) { dma_group(rs_next, voff, v_sn, gc); });
+      static_for<0, SPLIT>([&](auto gc) { dma_group(rs_next, dma_voff(voff, v_sn), v_sn, gc); });
       asm volatile("" ::: "memory");               // the vmcnt() above counts on these being older than every store below
     }
 
@@ -507,8 +550,13 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
             if (more) {                              // trade places: results wait for the next quiet part, the prefetched rows move in
               const float4 nx = dfr[4 * (g - GP) + m];
               dfr[4 * (g - GP) + m] = res;
-              z[8 * g + 2 * m] = make_float2(nx.x, nx.y);
-              z[8 * g + 2 * m + 1] = make_float2(nx.z, nx.w);
+              if constexpr (IN_BF16) {
+                z[8 * g + 2 * m] = unpack_lo(__float_as_uint(nx.x));
+                z[8 * g + 2 * m + 1] = unpack_lo(__float_as_uint(nx.y));
+              } else {
+                z[8 * g + 2 * m] = make_float2(nx.x, nx.y);
+                z[8 * g + 2 * m + 1] = make_float2(nx.z, nx.w);
+              }
             } else {
               store16(rs_out, ooff + (uint32_t)((64 * g + 1024 * m) * out_sn * 4), res);
             }
@@ -530,6 +578,6 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
   }
 }
 
-hipError_t launch_regtile64p(const RegtileArgs& a, hipStream_t stream);
+hipError_t launch_regtile64p(const RegtileArgs& a, bool in_bf16, hipStream_t stream);
 
 }  // namespace sfft

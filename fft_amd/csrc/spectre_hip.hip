@@ -31,7 +31,7 @@ template <> hipError_t launch_regtile<32, 16>(const RegtileArgs&, bool, bool, in
 template <> hipError_t launch_regtile<32, 32>(const RegtileArgs&, bool, bool, int, hipStream_t);
 template <> hipError_t launch_regtile<64, 32>(const RegtileArgs&, bool, bool, int, hipStream_t);
 template <> hipError_t launch_regtile<64, 64>(const RegtileArgs&, bool, bool, int, hipStream_t);
-hipError_t launch_regtile64p(const RegtileArgs&, hipStream_t);                           // regtile_n4096p.hip (persistent, pipelined)
+hipError_t launch_regtile64p(const RegtileArgs&, bool in_bf16, hipStream_t);                           // regtile_n4096p.hip (persistent, pipelined)
 hipError_t launch_regtile_long_8192(const RegtileArgs&, bool, bool, int, hipStream_t);   // regtile_n8192.hip, regtile_n6144.hip
 hipError_t launch_regtile_long_6144(const RegtileArgs&, bool, bool, int, hipStream_t);
 hipError_t launch_regtile_quad_16384(const RegtileArgs&, bool, bool, int, hipStream_t);   // regtile_n16384.hip, regtile_n12288.hip
@@ -337,8 +337,18 @@ int choose(const SpectreMixArgs* a, const Plan* plan, Choice* c) {
     else if (!ts->mixed) mode = (d_g % 16 != 0) ? (a->mem ? 2 : 1) : a->mem ? 4 : (a->N_in < a->n_fft) ? 3 : 0;   // 3, 4: gate still in LDS
     else mode = a->mem ? 2 : (d_g % 16 != 0) ? 1 : (a->N_in < a->n_fft) ? 3 : 0;
   }
+  static const bool p64_off = [] { const char* e = getenv("SPECTRE_P64"); return e && atoi(e) == 0; }();   // A/B switch (tuning aid)
+  // fast mode, padded sequences (mode 3: rows >= N_in are the buffer instructions' out-of-range case) and memory_fft (mode 4);
+  // 32-bit byte offsets
+  static const bool p64_bf16_off = [] { const char* e = getenv("SPECTRE_P64_BF16"); return e && atoi(e) == 0; }();
+  const bool in_bf = a->in_dtype == SPECTRE_BF16;     // a lane moves the 4 channels of a row: 16 bytes of fp32, 8 of bf16
+  const bool pipelined_ok = can_regtile && ts && !ts->mixed && ts->tile_ch == 16 && !p64_off && n == 4096 && (mode == 0 || mode == 3 || mode == 4) && a->out_dtype == SPECTRE_F32 &&
+                   (!in_bf || (mode != 4 && !p64_bf16_off)) &&
+                   reinterpret_cast<uintptr_t>(a->v) % (in_bf ? 8 : 16) == 0 && reinterpret_cast<uintptr_t>(a->out) % 16 == 0 &&
+                   a->v_sn % 4 == 0 && a->v_sb % 4 == 0 && a->out_sn % 4 == 0 && a->out_sb % 4 == 0 &&
+                   a->v_sn * 4096 * 4 + 64 < ((int64_t)1 << 32) && a->out_sn * 4096 * 4 + 64 < ((int64_t)1 << 32);
   bool can = can_regtile;
-  if (can && mode != 0 && a->in_dtype != a->out_dtype) {   // differing storage dtypes are built for the fast mode only
+  if (can && mode != 0 && a->in_dtype != a->out_dtype && !pipelined_ok) {   // differing storage dtypes are built for the fast mode only
     c->why_not_regtile = "storage dtypes differ (built for the fast mode only)";
     can = false;
     if (a->algo == SPECTRE_ALGO_REGTILE) return fail(SPECTRE_E_UNSUPPORTED, "register-tile kernel not applicable: %s", c->why_not_regtile);
@@ -347,13 +357,7 @@ int choose(const SpectreMixArgs* a, const Plan* plan, Choice* c) {
     c->regtile = true;
     c->tile = ts; c->RF = ts->RF; c->RS = ts->RS;
     c->mode = mode;
-    static const bool p64_off = [] { const char* e = getenv("SPECTRE_P64"); return e && atoi(e) == 0; }();   // A/B switch (tuning aid)
-    // fast mode, padded sequences (mode 3: rows >= N_in are the buffer instructions' out-of-range case) and memory_fft (mode 4);
-    // 32-bit byte offsets
-    c->pipelined = !p64_off && n == 4096 && (mode == 0 || mode == 3 || mode == 4) && a->in_dtype == SPECTRE_F32 && a->out_dtype == SPECTRE_F32 &&
-                   reinterpret_cast<uintptr_t>(a->v) % 16 == 0 && reinterpret_cast<uintptr_t>(a->out) % 16 == 0 &&
-                   a->v_sn % 4 == 0 && a->v_sb % 4 == 0 && a->out_sn % 4 == 0 && a->out_sb % 4 == 0 &&
-                   a->v_sn * 4096 * 4 + 64 < ((int64_t)1 << 32) && a->out_sn * 4096 * 4 + 64 < ((int64_t)1 << 32);
+    c->pipelined = pipelined_ok;
     return SPECTRE_OK;
   }
   // Stockham / Bluestein in LDS: one buffer of L points per slot; P slots per workgroup, limited by the LDS and by
@@ -430,9 +434,11 @@ int launch(const SpectreMixArgs* a, const Plan* plan, const Choice& c, bool conj
     if (c.pipelined) {   // one workgroup per CU walks through tpw tiles; pairs of workgroups stay on adjacent tiles
       const int ncu = cu_count(a->device);
       static const int forced = [] { const char* e = getenv("SPECTRE_P64_TPW"); return e ? atoi(e) : 0; }();
-      k.tpw = forced > 0 ? forced : std::max(1, (k.n_tiles + ncu - 1) / ncu);
-      k.n_wg = 2 * ((k.n_tiles + 2 * k.tpw - 1) / (2 * k.tpw));
-      e = sfft::launch_regtile64p(k, stream);
+      const int gang = ib ? 4 : 2;                  // kP64Gang: workgroups that share a 128-byte line walk through adjacent tiles
+      const int slots = std::max(gang, ncu / gang * gang);
+      k.tpw = forced > 0 ? forced : std::max(1, (k.n_tiles + slots - 1) / slots);
+      k.n_wg = gang * ((k.n_tiles + gang * k.tpw - 1) / (gang * k.tpw));
+      e = sfft::launch_regtile64p(k, ib, stream);
     } else {
       e = c.tile->launch(k, ib, ob, c.mode, stream);
     }

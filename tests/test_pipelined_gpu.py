@@ -128,3 +128,46 @@ def test_memory_fft_on_the_pipelined_kernel(B, N_in, D, G):
     y = spectral_mix(Vd, gd, md, N)
     torch.cuda.synchronize()
     assert_close(y.cpu().numpy(), spectral_mix_numpy(V.numpy(), gate.numpy(), mem.numpy(), N), what=f"memory_fft ({B},{N_in},{D})")
+
+
+# ---- bf16 rows in, fp32 rows out (BASELINE.json configs[2]: "bf16 in / fp32 compute"): the same kernel with 8-byte lane accesses,
+#      quads of workgroups on adjacent tiles.  The oracle is given the bf16-rounded input, so the tolerance is the fp32 one.
+@pytest.mark.parametrize("B,Nin,D,G", [(1, 4096, 16, 1), (3, 4096, 64, 4), (5, 4096, 80, 5), (37, 4096, 112, 7), (2, 4096, 48, 3),
+                                       (3, 4000, 64, 2), (2, 1000, 48, 3), (1, 1, 16, 1), (2, 5000, 32, 2)])
+def test_bf16_in_f32_out_matches_oracle(B, Nin, D, G):
+    from fft_amd import spectral_mix, describe
+    torch.manual_seed(B * 13 + D + Nin)
+    V = torch.randn(B, Nin, D, device=DEV).bfloat16()
+    gate = (torch.randn(B, G, N // 2 + 1, dtype=torch.complex64, device=DEV) * 0.3)
+    assert describe(V, gate, None, N, out_dtype=torch.float32).startswith("regtile-pipelined 64x64 in=bf16 out=f32")
+    y = spectral_mix(V, gate, None, N, out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    assert y.dtype == torch.float32 and y.shape == (B, min(Nin, N), D)
+    ref = spectral_mix_numpy(V.float().cpu().numpy(), gate.cpu().numpy(), None, N)
+    assert_close(y.cpu().numpy(), ref, what=f"bf16 in ({B},{Nin},{D})")
+
+
+def test_bf16_in_many_tiles_and_guard_rows():
+    """Headline width, quads spanning batch boundaries, a view with a larger row stride; rows beyond N_out stay untouched."""
+    from fft_amd import spectral_mix
+    torch.manual_seed(11)
+    B, Nin, D, G = 21, 3900, 768, 4
+    Vbig = torch.randn(B, Nin, D + 32, device=DEV).bfloat16()
+    V = Vbig[:, :, 16:16 + D]                                   # 32-byte offset, row stride D + 32: 8-byte aligned lanes
+    gate = (torch.randn(B, G, N // 2 + 1, dtype=torch.complex64, device=DEV) * 0.3)
+    out = torch.full((B, Nin + 3, D), 7.0, device=DEV)
+    y = spectral_mix(V, gate, None, N, out=out[:, :Nin], out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    assert torch.all(out[:, Nin:] == 7.0)
+    d_g = D // G
+    for (b, c) in [(0, 0), (B - 1, D - 2), (B // 2, 18), (7, D // 2 + 2), (B - 2, 16 * 13 + 4)]:
+        ref = spectral_mix_numpy(V[b:b + 1, :, c:c + 2].float().cpu().numpy(), gate[b:b + 1, c // d_g:c // d_g + 1].cpu().numpy(), None, N)
+        assert_close(y[b:b + 1, :, c:c + 2].cpu().numpy(), ref, what=f"bf16 in column ({b},{c})")
+
+
+def test_bf16_in_with_memory_fft_keeps_the_round1_kernel():
+    from fft_amd import describe
+    V = torch.randn(2, N, 32, device=DEV).bfloat16()
+    gate = torch.randn(2, 2, N // 2 + 1, dtype=torch.complex64, device=DEV)
+    mem = torch.randn(N // 2 + 1, 32, dtype=torch.complex64, device=DEV)
+    assert "pipelined" not in describe(V, gate, mem, N, out_dtype=torch.float32)
