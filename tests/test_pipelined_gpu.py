@@ -171,3 +171,22 @@ def test_bf16_in_with_memory_fft_keeps_the_round1_kernel():
     gate = torch.randn(2, 2, N // 2 + 1, dtype=torch.complex64, device=DEV)
     mem = torch.randn(N // 2 + 1, 32, dtype=torch.complex64, device=DEV)
     assert "pipelined" not in describe(V, gate, mem, N, out_dtype=torch.float32)
+
+
+def test_bf16_in_unaligned_view_falls_back_and_agrees():
+    """A bf16 channel slice that starts 4 bytes into a row is not 8-byte aligned: the round-1 kernel runs, same numbers (the two
+    kernels order their butterflies differently: fp32 rounding level, not bit-identical)."""
+    from fft_amd import describe, spectral_mix
+    torch.manual_seed(3)
+    Vd = torch.randn(3, N, 128, device=DEV).bfloat16()
+    gd = (torch.randn(3, 4, N // 2 + 1, dtype=torch.complex64, device=DEV) * 0.3)
+    big = torch.zeros(3, N, 128 + 8, device=DEV, dtype=torch.bfloat16)
+    big[:, :, 2:130] = Vd
+    view = big[:, :, 2:130]
+    assert describe(view, gd, None, N, out_dtype=torch.float32).startswith("regtile 64x64")
+    assert describe(Vd, gd, None, N, out_dtype=torch.float32).startswith("regtile-pipelined 64x64")
+    y_view = spectral_mix(view, gd, None, N, out_dtype=torch.float32)
+    y = spectral_mix(Vd, gd, None, N, out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    rms = float(y.square().mean().sqrt())
+    assert float((y - y_view).abs().max()) <= 1e-4 * rms
