@@ -386,12 +386,8 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
     const __amdgpu_buffer_rsrc_t rs_next = rsrc_in(vbn, v_sn), rs_out = rsrc_out(ob, out_sn);
 
     stamp(it, 0);
-    // ---- the tile arrives: LDS-staged groups first (requested before the previous tile's stores; completion is in order, so
-    //      everything but the 16 youngest stores and the 5 gate loads has retired), then the groups loaded straight into registers
-    if constexpr (SPLIT > 0) {
-      asm volatile("s_waitcnt vmcnt(21)" ::: "memory");
-      static_for<0, SPLIT>([&](auto gc) { read_group(gc); });
-    }
+    // ---- the tile arrives.  The LDS-staged groups were requested before the previous tile's stores and completion is in order, so
+    //      once everything but the 16 youngest stores and the 5 gate loads has retired (vmcnt(21) below) they are in the slots.
 
     [[maybe_unused]] const uint32_t pf_ooff = (uint32_t)(((long long)(u + 512 * h) * out_sn + 4 * pp) * 4);
     [[maybe_unused]] const uint32_t pf_voff = (uint32_t)(((long long)(u + 512 * h) * v_sn + 4 * pp) * ESI);
@@ -415,9 +411,18 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
     };
     stamp(it, 1);
     // ---- F1: 64-point forward transform over n1 (register position 8g + e holds row g + 8e), then W_N^(u*k1) ------------
-    static_for<0, 8>([&](auto gc) {
-      constexpr int g = decltype(gc)::value;
-      swap_group(gc);
+    //      Stage 1 works group by group, in the order the groups arrive: the deferred groups (prefetched a tile ago) first, then the
+    //      LDS-staged ones — only now does the wave wait for the LDS-DMA of the burst it has just left — and the group reloaded
+    //      behind the stores last.
+    static_for<0, 8>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      constexpr bool ARRIVAL = (ABL & 16384) == 0;                           // ABL bit14 (p64_ab_bench): groups 0..7 in index order
+      constexpr int g = !ARRIVAL ? i : i < PF ? GP + i : i - PF;             // [GP, 8), [0, SPLIT), [SPLIT, GP)
+      if constexpr (SPLIT > 0 && i == (ARRIVAL ? PF : 0)) {
+        asm volatile("s_waitcnt vmcnt(21)" ::: "memory");
+        static_for<0, SPLIT>([&](auto gc) { read_group(gc); });
+      }
+      swap_group(std::integral_constant<int, g>{});
       bfly<8, false, 8 * g, 1, 64>(z);             // over e -> ka at position 8g + ka
       static_for<1, 8>([&](auto kac) { constexpr int ka = decltype(kac)::value; z[8 * g + ka] = twid64<g * ka, false>(z[8 * g + ka]); });
       if constexpr (FEN) { pin8<8 * g, 1>(z); __builtin_amdgcn_sched_barrier(0); }
