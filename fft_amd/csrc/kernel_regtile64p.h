@@ -448,7 +448,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
 
     // this tile's gate bins -> LDS.  They were requested behind the previous tile's last stores, so waiting for them means waiting
     // for every store of that tile to be acknowledged: as late as possible (the bins are first read after E1's barriers)
-    gate_commit();
+    if ((ABL & 32768) == 0 || it == 0) gate_commit();   // ABL bit15 (p64_ab_bench): the first tile's gate for every tile = no wait for the stores
     // ---- E1: position k1 -> image row k1, column (p, u); thread (p, s = u) reads row u, slot n2 ---------------------------
     stamp(it, 2);
     __syncthreads();                               // every wave has emptied its landing slots / finished E2's reads of the previous tile
@@ -574,7 +574,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
       });
     }
     obp = ob;
-    gate_fetch(gpn);                               // committed to LDS after F1's first stage of the next tile (after the last tile:
+    if constexpr ((ABL & 32768) == 0) gate_fetch(gpn);   // committed to LDS after F1's first stage of the next tile (after the last tile:
                                                    // a harmless re-read of this tile's bins — keeps the staging registers out of a loop-carried phi)
     stamp(it, 5);
   }  // tile loop

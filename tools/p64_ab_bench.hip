@@ -64,6 +64,7 @@ int main() {
   vs.push_back({"pipelined PF=3                      tpw=48", make(spectre_mix_regtile64p<4, 3, 0, true>, a, 48, kP64LdsTotal), {}});
   vs.push_back({"pipelined PF=3, F1 groups in index order    ", make(spectre_mix_regtile64p<4, 3, 16384, true>, a, 48, kP64LdsTotal), {}});
   vs.push_back({"pipelined PF=2, F1 groups in index order    ", make(spectre_mix_regtile64p<4, 2, 16384, true>, a, 48, kP64LdsTotal), {}});
+  vs.push_back({"pipelined PF=3, gate of the first tile reused (no fetch, no commit)", make(spectre_mix_regtile64p<4, 3, 32768, true>, a, 48, kP64LdsTotal), {}});
   vs.push_back({"pipelined PF=4                      tpw=48", make(spectre_mix_regtile64p<4, 4, 0, true>, a, 48, kP64LdsTotal), {}});
   vs.push_back({"pipelined SPLIT=3 PF=3              tpw=48", make(spectre_mix_regtile64p<3, 3, 0, true>, a, 48, kP64LdsTotal), {}});
   vs.push_back({"pipelined PF=1 + wave-pair rendezvous tpw=48", with_sync(spectre_mix_regtile64p<4, 1, 32, true>, as, 48), {}});
