@@ -94,6 +94,12 @@ __device__ __forceinline__ void p64_stageB2(float2 (&z)[64]) {      // type B st
 // 2 cycles per dword, so one instruction with two data dwords (6 cycles) beats two ds_write_b32 (8 cycles), and the writes are 80 % of
 // an exchange's LDS time.  Rows j and j + 2 are 2 * 2176 = 17 * 256 bytes apart — a multiple of the instruction's 256-byte offset unit;
 // its 8-bit offsets reach 30 rows, hence four opaque base addresses (even / odd rows below and above 32) instead of one.
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence + s_barrier, and hipcc implements the
+// fence with s_waitcnt vmcnt(0): every barrier of the exchanges would drain the deferred stores and the prefetches that are meant to
+// travel DURING the exchanges.  Nothing that crosses waves goes through global memory here (a lane reads back only what its own wave
+// requested by LDS-DMA, after its own vmcnt wait), so the LDS counter is all a barrier has to wait for.
+__device__ __forceinline__ void p64_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <bool IN_BF16> constexpr int kP64Gang = IN_BF16 ? 4 : 2;   // workgroups per 128-byte line (launch: n_wg is a multiple of it)
 
 template <bool LAST_BARRIER>
@@ -127,13 +133,13 @@ __device__ __forceinline__ void p64_exchange(float2 (&z)[64], float* img, int p,
     });
   };
   write_plane(std::false_type{});
-  __syncthreads();
+  p64_barrier();
   read_plane(std::false_type{});
-  __syncthreads();
+  p64_barrier();
   write_plane(std::true_type{});
-  __syncthreads();
+  p64_barrier();
   read_plane(std::true_type{});
-  if constexpr (LAST_BARRIER) __syncthreads();     // image free again
+  if constexpr (LAST_BARRIER) p64_barrier();     // image free again
 }
 
 // SPLIT = row groups (of 8) of the next tile that travel through LDS (0: everything is loaded behind the stores).
@@ -243,6 +249,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
   };
   float2 z[64];
   float4 dfr[PF > 0 ? 4 * PF : 1];                 // deferred results of the previous tile / prefetched rows of the next one
+  static_for<0, (PF > 0 ? 4 * PF : 1)>([&](auto ic) { dfr[decltype(ic)::value] = make_float4(0.f, 0.f, 0.f, 0.f); });   // (stored into an empty range before the first tile)
   char* obp = nullptr;                             // output tile of the deferred results
   float2 gstage[5];      // the next tile's gate bins on their way to LDS (4097 bins / 512 threads, rounded up; + 1 for the last)
 
@@ -267,12 +274,16 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
   // VGPR offset (lane offset + row-block offset; the SGPR offset operand is not checked on gfx9), so both go there.
   // ABL bit8 / bit9 (tools/p64_ab_bench.hip): an empty range for the stores / the loads — the same instruction stream without the
   // memory traffic (out-of-range stores are dropped, out-of-range loads return 0 before they leave the CU)
-  auto rsrc_in = [&](const char* vb, long long sn) {
-    const int rows = (ABL & 512) != 0 ? 0 : a.N_in < 4096 ? a.N_in : 4096;
+  // live = false: an empty range.  Every request of the tile loop is issued UNCONDITIONALLY — after the last tile (and, for the deferred
+  // stores, before the first) with an empty range, which costs nothing: hipcc computes its s_waitcnt vmcnt(N) from the requests that are
+  // GUARANTEED to be younger than the one waited for, so a request inside `if (more)` does not count, N comes out too small, and a wait
+  // for a prefetched register early in I2 turned into a wait for the LDS-DMA issued just before it (a full HBM round trip per tile).
+  auto rsrc_in = [&](const char* vb, long long sn, bool live = true) {
+    const int rows = (ABL & 512) != 0 || !live ? 0 : a.N_in < 4096 ? a.N_in : 4096;
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(vb), 0, (int)((long long)rows * sn * ESI), kP64RsrcFlags);
   };
-  auto rsrc_out = [&](char* ob, long long sn) {
-    const int rows = (ABL & 256) != 0 ? 0 : a.N_in < 4096 ? a.N_in : 4096;
+  auto rsrc_out = [&](char* ob, long long sn, bool live = true) {
+    const int rows = (ABL & 256) != 0 || !live ? 0 : a.N_in < 4096 ? a.N_in : 4096;
     return __builtin_amdgcn_make_buffer_rsrc(ob, 0, (int)((long long)rows * sn * 4), kP64RsrcFlags);
   };
   auto unpack_lo = [](uint32_t d) { return make_float2(__uint_as_float(d << 16), __uint_as_float(d & 0xffff0000u)); };   // two bf16 -> (re, im)
@@ -337,22 +348,30 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
       lane16_swap(z[j].y, z[j + 1].y);
     });
   };
+  // gate_fetch only REQUESTS the bins: the staging registers cross the loop's back edge, and anything computed from them before it
+  // (the edge rule, the conj, the 1/N scale) would have to wait for the loads right there, at the end of the burst — i.e. for every
+  // store of the tile (one in-order vmcnt).  All arithmetic happens in gate_commit, a phase and a half later.
   auto gate_fetch = [&](const float2* gp) {
     static_for<0, 5>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       const int k = lane + 64 * (u >> 3) + 512 * i;
-      float2 g = make_float2(0.f, 0.f);
-      if (i < 4 || k <= 2048) g = gp[k];
-      if (k == 0 || k == 2048) g.y = 0.f;          // irfft ignores Im(DC), Im(Nyquist) (spectre.py:551)
-      if (a.conj_gate) g.y = -g.y;
-      gstage[i] = make_float2(g.x * inv_n, g.y * inv_n);
+      // (every lane loads — the lanes beyond bin 2048 re-read it and gate_commit ignores them: a predicated fifth load becomes a
+      //  branch with `s_waitcnt vmcnt(0)` behind it, and the waves that skip it would have one request less in flight than the
+      //  vmcnt() at the top of the loop counts on)
+      gstage[i] = gp[i < 4 ? k : (k <= 2048 ? k : 2048)];
     });
   };
   auto gate_commit = [&]() {
     static_for<0, 5>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       const int k = lane + 64 * (u >> 3) + 512 * i;
-      if (i < 4 || k <= 2048) glds[k] = gstage[i];
+      float2 g = gstage[i];
+      asm volatile("" : "+v"(g.x), "+v"(g.y));     // consumed HERE by every wave: the fifth bin's write below is lane-predicated, and a wave
+                                                   // that branches around it would carry the pending load into the exchange, where hipcc then
+                                                   // protects a reused register with s_waitcnt vmcnt(0) — behind the deferred requests
+      if (k == 0 || k == 2048) g.y = 0.f;          // irfft ignores Im(DC), Im(Nyquist) (spectre.py:551)
+      if (a.conj_gate) g.y = -g.y;
+      if (i < 4 || k <= 2048) glds[k] = make_float2(g.x * inv_n, g.y * inv_n);
     });
   };
 
@@ -383,7 +402,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
     tile_ptrs(tile, vb, ob, gp);
     const char* vbn = vb; char* obn = ob; const float2* gpn = gp;
     if (more) tile_ptrs((ABL & 8192) != 0 ? pair_base + 2 * ((it + 1 + rot) % a.tpw) : tile + tile_step, vbn, obn, gpn);
-    const __amdgpu_buffer_rsrc_t rs_next = rsrc_in(vbn, v_sn), rs_out = rsrc_out(ob, out_sn);
+    const __amdgpu_buffer_rsrc_t rs_next = rsrc_in(vbn, v_sn, more), rs_out = rsrc_out(ob, out_sn);
 
     stamp(it, 0);
     // ---- the tile arrives.  The LDS-staged groups were requested before the previous tile's stores and completion is in order, so
@@ -393,7 +412,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
     [[maybe_unused]] const uint32_t pf_voff = (uint32_t)(((long long)(u + 512 * h) * v_sn + 4 * pp) * ESI);
     [[maybe_unused]] auto pf_store = [&](auto ic) {
       constexpr int g = GP + decltype(ic)::value / 4, m = decltype(ic)::value % 4;
-      store16(rsrc_out(obp, out_sn), pf_ooff + (uint32_t)((64 * g + 1024 * m) * out_sn * 4), dfr[decltype(ic)::value]);
+      store16(rsrc_out(obp, out_sn, it > 0), pf_ooff + (uint32_t)((64 * g + 1024 * m) * out_sn * 4), dfr[decltype(ic)::value]);
     };
     [[maybe_unused]] auto pf_load = [&](auto ic) {
       constexpr int g = GP + decltype(ic)::value / 4, m = decltype(ic)::value % 4;
@@ -406,8 +425,8 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
       }
     };
     [[maybe_unused]] auto pf_block = [&]() {
-      if (it > 0) static_for<0, 4 * PF>([&](auto ic) { pf_store(ic); });
-      if (more) static_for<0, 4 * PF>([&](auto ic) { pf_load(ic); });
+      static_for<0, 4 * PF>([&](auto ic) { pf_store(ic); });
+      static_for<0, 4 * PF>([&](auto ic) { pf_load(ic); });
     };
     stamp(it, 1);
     // ---- F1: 64-point forward transform over n1 (register position 8g + e holds row g + 8e), then W_N^(u*k1) ------------
@@ -419,7 +438,11 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
       constexpr bool ARRIVAL = (ABL & 16384) == 0;                           // ABL bit14 (p64_ab_bench): groups 0..7 in index order
       constexpr int g = !ARRIVAL ? i : i < PF ? GP + i : i - PF;             // [GP, 8), [0, SPLIT), [SPLIT, GP)
       if constexpr (SPLIT > 0 && i == (ARRIVAL ? PF : 0)) {
-        asm volatile("s_waitcnt vmcnt(21)" ::: "memory");
+        // younger than the last LDS-DMA request: the reloaded groups' 4 stores + 4 loads each, the 4 SPLIT stores of the staged
+        // groups, the 5 gate loads (first tile: the prologue's 4 (8 - SPLIT) loads and the 5 gate loads)
+        constexpr int YOUNGER = 8 * (GP - SPLIT) + 4 * SPLIT + 5, YOUNGER0 = 4 * (8 - SPLIT) + 5;
+        if (it == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(YOUNGER0 < 63 ? YOUNGER0 : 63) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(YOUNGER < 63 ? YOUNGER : 63) : "memory");
         static_for<0, SPLIT>([&](auto gc) { read_group(gc); });
       }
       swap_group(std::integral_constant<int, g>{});
@@ -442,16 +465,19 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
         if constexpr (FEN && ka == 7) { pin8<8 * kb, 1>(z); __builtin_amdgcn_sched_barrier(0); }   // one wb at a time
       });
     }
+    // this tile's gate bins -> LDS.  They were requested behind the previous tile's last stores, so waiting for them means waiting
+    // for every store of that tile to be acknowledged: as late as possible (the bins are first read after E1's barriers) — but BEFORE
+    // the deferred requests below: hipcc waits for registers that were loaded before the loop's back edge with vmcnt(0), which behind
+    // those requests would mean a full HBM round trip at the end of every F1.
+    if ((ABL & 32768) == 0 || it == 0) gate_commit();   // ABL bit15 (p64_ab_bench): the first tile's gate for every tile = no wait for the stores
+    __builtin_amdgcn_sched_barrier(0);
     // ---- the quiet part of the tile starts: the deferred results of the previous tile leave, the same row groups of the next tile
     //      are requested into the registers they vacate
     if constexpr (PF > 0) pf_block();
-
-    // this tile's gate bins -> LDS.  They were requested behind the previous tile's last stores, so waiting for them means waiting
-    // for every store of that tile to be acknowledged: as late as possible (the bins are first read after E1's barriers)
-    if ((ABL & 32768) == 0 || it == 0) gate_commit();   // ABL bit15 (p64_ab_bench): the first tile's gate for every tile = no wait for the stores
+    __builtin_amdgcn_sched_barrier(0);
     // ---- E1: position k1 -> image row k1, column (p, u); thread (p, s = u) reads row u, slot n2 ---------------------------
     stamp(it, 2);
-    __syncthreads();                               // every wave has emptied its landing slots / finished E2's reads of the previous tile
+    p64_barrier();                                 // every wave has emptied its landing slots / finished E2's reads of the previous tile
     p64_exchange<true>(z, img, p, u);
 
     stamp(it, 3);
@@ -520,15 +546,21 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
     stamp(it, 4);
     // ---- the image is idle until the next E1: let the first row groups of the next tile land in it, and fetch its gate -----
     const uint32_t voff = (uint32_t)(((long long)(u + 512 * h) * v_sn + 4 * pp) * ESI);
-    if (more) {
-      static_for<0, SPLIT>([&](auto gc) { dma_group(rs_next, dma_voff(voff, v_sn), v_sn, gc); });
-      asm volatile("" ::: "memory");               // the vmcnt() above counts on these being older than every store below
-    }
+    // (the twiddles of I2 are read BEFORE the LDS-DMA is issued: hipcc orders every LDS read behind a pending LDS-DMA with
+    //  s_waitcnt vmcnt(0) — the whole HBM round trip of the requests below, at the start of every burst)
+    float2 wa2[8], wb2[8];
+    load_twiddles(wa2, wb2, u);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    static_for<0, SPLIT>([&](auto gc) { dma_group(rs_next, dma_voff(voff, v_sn), v_sn, gc); });
+    asm volatile("" ::: "memory");                 // the vmcnt() above counts on these being older than every store below
+    // ABL bit16 (p64_ab_bench): the next tile's gate bins requested BEFORE the stores of this one (10 registers through I2), so that
+    // gate_commit waits for requests older than the burst's stores — measured: no difference, the default stays behind the stores
+    if constexpr ((ABL & 32768) == 0 && (ABL & 65536) != 0) gate_fetch(gpn);
+    asm volatile("" ::: "memory");
 
     // ---- conj twiddle, I2, stores (spectre.py:553) interleaved with the loads that refill the released registers -----------
     {
-      float2 wa[8], wb[8];
-      load_twiddles(wa, wb, u);
+      float2 (&wa)[8] = wa2, (&wb)[8] = wb2;
       static_for<1, 64>([&](auto jc) {
         constexpr int j = decltype(jc)::value, ja = j % 8, jb = j / 8;   // position j carries k1 = j
         if constexpr (ja > 0) z[j] = cmulc(z[j], wa[ja]);
@@ -569,13 +601,13 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
             store16(rs_out, ooff + (uint32_t)((64 * g + 1024 * m) * out_sn * 4), res);
           }
         });
-        if constexpr (g >= SPLIT && g < GP) { if (more) load_group(rs_next, voff, v_sn, std::integral_constant<int, g>{}); }
+        if constexpr (g >= SPLIT && g < GP) load_group(rs_next, voff, v_sn, std::integral_constant<int, g>{});
         if constexpr (FEN) __builtin_amdgcn_sched_barrier(0);
       });
     }
     obp = ob;
-    if constexpr ((ABL & 32768) == 0) gate_fetch(gpn);   // committed to LDS after F1's first stage of the next tile (after the last tile:
-                                                   // a harmless re-read of this tile's bins — keeps the staging registers out of a loop-carried phi)
+    if constexpr ((ABL & 32768) == 0 && (ABL & 65536) == 0) gate_fetch(gpn);   // committed to LDS at the end of the next tile's F1 (after the
+                                                   // last tile: a harmless re-read of this tile's bins)
     stamp(it, 5);
   }  // tile loop
   if constexpr ((ABL & 32) != 0) {

@@ -65,6 +65,14 @@ int main() {
   vs.push_back({"pipelined PF=3, F1 groups in index order    ", make(spectre_mix_regtile64p<4, 3, 16384, true>, a, 48, kP64LdsTotal), {}});
   vs.push_back({"pipelined PF=2, F1 groups in index order    ", make(spectre_mix_regtile64p<4, 2, 16384, true>, a, 48, kP64LdsTotal), {}});
   vs.push_back({"pipelined PF=3, gate of the first tile reused (no fetch, no commit)", make(spectre_mix_regtile64p<4, 3, 32768, true>, a, 48, kP64LdsTotal), {}});
+  vs.push_back({"pipelined PF=3, gate fetched before the stores   ", make(spectre_mix_regtile64p<4, 3, 65536, true>, a, 48, kP64LdsTotal), {}});
+  vs.push_back({"pipelined PF=2, gate fetched before the stores   ", make(spectre_mix_regtile64p<4, 2, 65536, true>, a, 48, kP64LdsTotal), {}});
+  vs.push_back({"pipelined SPLIT=3 PF=3, gate before the stores", make(spectre_mix_regtile64p<3, 3, 65536, true>, a, 48, kP64LdsTotal), {}});
+  vs.push_back({"pipelined SPLIT=2 PF=3, gate before the stores", make(spectre_mix_regtile64p<2, 3, 65536, true>, a, 48, kP64LdsTotal), {}});
+  vs.push_back({"pipelined SPLIT=3 PF=2, gate before the stores", make(spectre_mix_regtile64p<3, 2, 65536, true>, a, 48, kP64LdsTotal), {}});
+  vs.push_back({"pipelined SPLIT=2 PF=2, gate before the stores", make(spectre_mix_regtile64p<2, 2, 65536, true>, a, 48, kP64LdsTotal), {}});
+  vs.push_back({"pipelined SPLIT=1 PF=3, gate before the stores", make(spectre_mix_regtile64p<1, 3, 65536, true>, a, 48, kP64LdsTotal), {}});
+  vs.push_back({"pipelined SPLIT=3 PF=4                       ", make(spectre_mix_regtile64p<3, 4, 0, true>, a, 48, kP64LdsTotal), {}});
   vs.push_back({"pipelined PF=4                      tpw=48", make(spectre_mix_regtile64p<4, 4, 0, true>, a, 48, kP64LdsTotal), {}});
   vs.push_back({"pipelined SPLIT=3 PF=3              tpw=48", make(spectre_mix_regtile64p<3, 3, 0, true>, a, 48, kP64LdsTotal), {}});
   vs.push_back({"pipelined PF=1 + wave-pair rendezvous tpw=48", with_sync(spectre_mix_regtile64p<4, 1, 32, true>, as, 48), {}});
