@@ -16,7 +16,8 @@
 //    the stores, as LDS-DMA (buffer_load_dwordx4 ... lds, no VGPR needed) into the exchange image, which is idle between the last
 //    exchange of tile t and the first exchange of tile t+1.  Every lane reads back exactly the 16 bytes it requested, so the
 //    staging needs no barrier of its own;
-//  * three of the other four row groups (PF = 3) are deferred: their results stay in 48 registers through F1 of the next tile, are
+//  * (library: SPLIT = 3 row groups through LDS-DMA, PF = 3 deferred, 2 reloaded behind their own stores)
+//  * three of the other row groups (PF = 3) are deferred: their results stay in 48 registers through F1 of the next tile, are
 //    stored at the end of F1, and the same registers then prefetch those groups of the tile after — 3/8 of the traffic travels while
 //    the CU exchanges and multiplies; the last group is loaded straight into the registers that the stores of I2 have just released;
 //  * for the same vmcnt reason nothing that is needed "now" may be a global load: the twiddle vectors live in LDS (written once per
@@ -29,7 +30,7 @@
 //    of workgroups walk through adjacent tiles: a 64-byte row segment is half an L2 line, the L2 fetches whole lines, and the
 //    neighbour's request a few microseconds later hits.  Larger gangs of neighbours collide on DRAM channels and were slower.
 // Where it stands: the same instruction stream without memory traffic takes 0.94 ms, with every request answered
-// by the L2 1.03 ms, the product 1.58-1.65 ms; the difference is HBM latency beyond what 128 KiB of staging + 48 registers cover and
+// by the L2 1.0 ms, the product 1.51-1.62 ms; the difference is HBM latency beyond what 128 KiB of staging + 48 registers cover and
 // the DRAM efficiency of half-line segments (tools/iolab3.hip).
 //
 // Thread <-> data:  lane = (pp = lane & 3, rcl = (lane >> 2) & 3, h = (lane >> 4) & 1, rch = lane >> 5);
