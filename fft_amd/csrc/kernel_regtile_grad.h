@@ -44,6 +44,10 @@ template <int RF, int RS, int XV = SFFT_EXCHANGE_B128(RF, RS)> constexpr int gat
 }
 template <int RF, int RS> constexpr int gate_grad_lds_total() { return gate_grad_image_bytes<RF, RS>() + (RF * RS / 2 + 1) * 8; }
 
+// Workgroup barrier that orders LDS traffic only: __syncthreads() is a fence + s_barrier and hipcc implements the fence with
+// s_waitcnt vmcnt(0), which would wait for the next tile's rows requested just before it (kernel_regtile64p.h has the long story).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // sum over the 8 lanes of a team (lanes 8r .. 8r+7): quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror
 __device__ __forceinline__ float team_sum8(float v) {
   v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
@@ -82,14 +86,16 @@ __global__ void __launch_bounds__(kPC * RS) spectre_gate_grad_regtile(const Gate
   // the range check covers only that operand: rows >= N_in and the lanes of a ragged last tile (lane offset 0x80000000) are the
   // out-of-range case, which returns 0 = rfft's zero padding — no predicates, no pointer selects.
   float2 z[RF];
-  auto load_row = [&](int jt_, auto qc, long long v_sn, long long d_sn, int p, int u) {
+  // live = false (after the workgroup's last tile): an empty range.  The requests for the next tile are issued unconditionally — hipcc
+  // counts only requests that are guaranteed to be younger when it computes a wait, see kernel_regtile64p.h.
+  auto load_row = [&](int jt_, auto qc, long long v_sn, long long d_sn, int p, int u, bool live = true) {
     constexpr int q = decltype(qc)::value;
-    const int c0 = g * a.d_g + kPC * jt_;            // first channel of the tile
+    const int c0 = live ? g * a.d_g + kPC * jt_ : 0; // first channel of the tile
     const int rows = a.N_in < N ? a.N_in : N;
     const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(reinterpret_cast<const char*>(a.v)) + ((size_t)b * a.v_sb + c0) * ES, 0, GENERAL ? (int)(rows * v_sn * ES) : 0x7fffffff, kRsrcFlags);
+        const_cast<char*>(reinterpret_cast<const char*>(a.v)) + ((size_t)b * a.v_sb + c0) * ES, 0, !live ? 0 : GENERAL ? (int)(rows * v_sn * ES) : 0x7fffffff, kRsrcFlags);
     const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(reinterpret_cast<const char*>(a.dout)) + ((size_t)b * a.dout_sb + c0) * ES, 0, GENERAL ? (int)(rows * d_sn * ES) : 0x7fffffff, kRsrcFlags);
+        const_cast<char*>(reinterpret_cast<const char*>(a.dout)) + ((size_t)b * a.dout_sb + c0) * ES, 0, !live ? 0 : GENERAL ? (int)(rows * d_sn * ES) : 0x7fffffff, kRsrcFlags);
     uint32_t vo = (uint32_t)(((long long)u * v_sn + p) * ES), dof = (uint32_t)(((long long)u * d_sn + p) * ES);
     uint32_t vs = (uint32_t)((long long)q * RS * v_sn * ES), ds = (uint32_t)((long long)q * RS * d_sn * ES);
     if constexpr (GENERAL) {
@@ -172,17 +178,15 @@ __global__ void __launch_bounds__(kPC * RS) spectre_gate_grad_regtile(const Gate
         });
       });
     });
-    if (more) {
-      static_for<0, NS>([&](auto tc) {
-        static_for<0, RAS>([&](auto kac) {
-          static_for<RBS / 2, RBS>([&](auto kbc) {
-            constexpr int j = decltype(tc)::value * RS + RBS * decltype(kac)::value + decltype(kbc)::value;
-            load_row(jt + a.S, std::integral_constant<int, j>{}, v_sn, d_sn, p, u);
-          });
+    static_for<0, NS>([&](auto tc) {
+      static_for<0, RAS>([&](auto kac) {
+        static_for<RBS / 2, RBS>([&](auto kbc) {
+          constexpr int j = decltype(tc)::value * RS + RBS * decltype(kac)::value + decltype(kbc)::value;
+          load_row(jt + a.S, std::integral_constant<int, j>{}, v_sn, d_sn, p, u, more);
         });
       });
-    }
-    __syncthreads();
+    });
+    lds_barrier();                                    // (not __syncthreads(): its fence would wait for the requests just issued)
     static_for<0, NS>([&](auto tc) {
       constexpr int t = decltype(tc)::value;
       const int k1 = u + RS * t;
@@ -206,7 +210,7 @@ __global__ void __launch_bounds__(kPC * RS) spectre_gate_grad_regtile(const Gate
             cur.x += sr; cur.y += si;
             acc[k1 + RF * k2] = cur;
           }
-          if (more) load_row(jt + a.S, std::integral_constant<int, j>{}, v_sn, d_sn, p, u);   // z[j] is dead
+          load_row(jt + a.S, std::integral_constant<int, j>{}, v_sn, d_sn, p, u, more);       // z[j] is dead
         });
       });
       if constexpr (t == 0) {                         // Nyquist: k1 = 0, k2 = RS/2 (ka = 0, kb = RBS/2): Re(A) Im(A)
@@ -214,7 +218,7 @@ __global__ void __launch_bounds__(kPC * RS) spectre_gate_grad_regtile(const Gate
         if (p == 0 && k1z) acc[N / 2].x += sr;
       }
     });
-    __syncthreads();                                  // partner image is read; next tile's E1 may overwrite it
+    lds_barrier();                                    // partner image is read; next tile's E1 may overwrite it
   }
 
   __syncthreads();
