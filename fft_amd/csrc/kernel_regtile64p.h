@@ -429,6 +429,8 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
       static_for<0, 4 * PF>([&](auto ic) { pf_store(ic); });
       static_for<0, 4 * PF>([&](auto ic) { pf_load(ic); });
     };
+    constexpr bool PF_TOP = (ABL & 131072) != 0;   // ABL bit17 (p64_ab_bench): the deferred requests at the top of the tile instead of the end of F1
+    if constexpr (PF > 0 && PF_TOP) { pf_block(); asm volatile("" ::: "memory"); }
     stamp(it, 1);
     // ---- F1: 64-point forward transform over n1 (register position 8g + e holds row g + 8e), then W_N^(u*k1) ------------
     //      Stage 1 works group by group, in the order the groups arrive: the deferred groups (prefetched a tile ago) first, then the
@@ -441,7 +443,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
       if constexpr (SPLIT > 0 && i == (ARRIVAL ? PF : 0)) {
         // younger than the last LDS-DMA request: the reloaded groups' 4 stores + 4 loads each, the 4 SPLIT stores of the staged
         // groups, the 5 gate loads (first tile: the prologue's 4 (8 - SPLIT) loads and the 5 gate loads)
-        constexpr int YOUNGER = 8 * (GP - SPLIT) + 4 * SPLIT + 5, YOUNGER0 = 4 * (8 - SPLIT) + 5;
+        constexpr int YOUNGER = 8 * (GP - SPLIT) + 4 * SPLIT + 5 + (PF_TOP ? 8 * PF : 0), YOUNGER0 = 4 * (8 - SPLIT) + 5 + (PF_TOP ? 8 * PF : 0);
         if (it == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(YOUNGER0 < 63 ? YOUNGER0 : 63) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(YOUNGER < 63 ? YOUNGER : 63) : "memory");
         static_for<0, SPLIT>([&](auto gc) { read_group(gc); });
@@ -474,7 +476,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
     __builtin_amdgcn_sched_barrier(0);
     // ---- the quiet part of the tile starts: the deferred results of the previous tile leave, the same row groups of the next tile
     //      are requested into the registers they vacate
-    if constexpr (PF > 0) pf_block();
+    if constexpr (PF > 0 && !PF_TOP) pf_block();
     __builtin_amdgcn_sched_barrier(0);
     // ---- E1: position k1 -> image row k1, column (p, u); thread (p, s = u) reads row u, slot n2 ---------------------------
     stamp(it, 2);

@@ -72,6 +72,8 @@ int main() {
   vs.push_back({"pipelined SPLIT=3 PF=2, gate before the stores", make(spectre_mix_regtile64p<3, 2, 65536, true>, a, 48, kP64LdsTotal), {}});
   vs.push_back({"pipelined SPLIT=2 PF=2, gate before the stores", make(spectre_mix_regtile64p<2, 2, 65536, true>, a, 48, kP64LdsTotal), {}});
   vs.push_back({"pipelined SPLIT=1 PF=3, gate before the stores", make(spectre_mix_regtile64p<1, 3, 65536, true>, a, 48, kP64LdsTotal), {}});
+  vs.push_back({"pipelined SPLIT=3 PF=3, deferred requests at the top of the tile", make(spectre_mix_regtile64p<3, 3, 131072, true>, a, 48, kP64LdsTotal), {}});
+  vs.push_back({"pipelined SPLIT=3 PF=2, deferred requests at the top of the tile", make(spectre_mix_regtile64p<3, 2, 131072, true>, a, 48, kP64LdsTotal), {}});
   vs.push_back({"pipelined SPLIT=3 PF=4                       ", make(spectre_mix_regtile64p<3, 4, 0, true>, a, 48, kP64LdsTotal), {}});
   vs.push_back({"pipelined PF=4                      tpw=48", make(spectre_mix_regtile64p<4, 4, 0, true>, a, 48, kP64LdsTotal), {}});
   vs.push_back({"pipelined SPLIT=3 PF=3              tpw=48", make(spectre_mix_regtile64p<3, 3, 0, true>, a, 48, kP64LdsTotal), {}});
