@@ -426,6 +426,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
       }
     };
     [[maybe_unused]] auto pf_block = [&]() {
+      if constexpr ((ABL & 32) != 0) gang_await(members);   // (rendezvous experiment: the deferred stores leave an otherwise idle request queue)
       static_for<0, 4 * PF>([&](auto ic) { pf_store(ic); });
       static_for<0, 4 * PF>([&](auto ic) { pf_load(ic); });
     };
@@ -453,6 +454,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
       static_for<1, 8>([&](auto kac) { constexpr int ka = decltype(kac)::value; z[8 * g + ka] = twid64<g * ka, false>(z[8 * g + ka]); });
       if constexpr (FEN) { pin8<8 * g, 1>(z); __builtin_amdgcn_sched_barrier(0); }
     });
+    if constexpr ((ABL & 32) != 0 && PF > 0) gang_arrive();
     {
       float2 wa[8], wb[8];
       __builtin_amdgcn_sched_barrier(0);           // keep the base loads (and their registers) out of stage 1
@@ -577,7 +579,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
       const uint32_t ooff = (uint32_t)(((long long)(u + 512 * h) * out_sn + 4 * pp) * 4);
       static_for<0, 8>([&](auto ic) {
         constexpr int g = (decltype(ic)::value + SPLIT) % 8;             // register-loaded groups first: their reloads start earliest
-        constexpr bool stores_now = g < GP && ((ABL & 64) == 0 || decltype(ic)::value % 2 == 0) && ((ABL & 128) == 0 || decltype(ic)::value % 4 == 0);                               // (deferred groups are stored before the next E1)
+        constexpr bool stores_now = g < GP && (ABL & 262144) == 0 && ((ABL & 64) == 0 || decltype(ic)::value % 2 == 0) && ((ABL & 128) == 0 || decltype(ic)::value % 4 == 0);                               // (deferred groups are stored before the next E1)
         if constexpr (stores_now) gang_arrive();
         fftA_stage2_group<8, 8, true, g>(z);                              // rows g + 8e at positions 8g + e
         if constexpr (FEN) pin8<8 * g, 1>(z);

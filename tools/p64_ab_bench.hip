@@ -77,6 +77,9 @@ int main() {
   vs.push_back({"pipelined SPLIT=3 PF=4                       ", make(spectre_mix_regtile64p<3, 4, 0, true>, a, 48, kP64LdsTotal), {}});
   vs.push_back({"pipelined PF=4                      tpw=48", make(spectre_mix_regtile64p<4, 4, 0, true>, a, 48, kP64LdsTotal), {}});
   vs.push_back({"pipelined SPLIT=3 PF=3              tpw=48", make(spectre_mix_regtile64p<3, 3, 0, true>, a, 48, kP64LdsTotal), {}});
+  vs.push_back({"pipelined (3,3) + rendezvous at the deferred stores only", with_sync(spectre_mix_regtile64p<3, 3, 32 + 262144, true>, as, 48), {}});
+  vs.push_back({"pipelined (3,3) + rendezvous everywhere", with_sync(spectre_mix_regtile64p<3, 3, 32, true>, as, 48), {}});
+  vs.push_back({"pipelined (4,4)=spills + rendezvous at the deferred stores only", with_sync(spectre_mix_regtile64p<4, 4, 32 + 262144, true>, as, 48), {}});
   vs.push_back({"pipelined PF=1 + wave-pair rendezvous tpw=48", with_sync(spectre_mix_regtile64p<4, 1, 32, true>, as, 48), {}});
   vs.push_back({"pipelined PF=1, stores dropped (empty range) ", make(spectre_mix_regtile64p<4, 1, 256, true>, a, 48, kP64LdsTotal), {}});
   vs.push_back({"pipelined PF=1, loads answered with 0        ", make(spectre_mix_regtile64p<4, 1, 512, true>, a, 48, kP64LdsTotal), {}});
