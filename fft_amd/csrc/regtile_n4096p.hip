@@ -16,7 +16,8 @@ hipError_t launch_regtile64p(const RegtileArgs& a, bool in_bf16, hipStream_t str
   auto kern = pf == 33 ? spectre_mix_regtile64p<3, 3> : pf == 3 ? spectre_mix_regtile64p<4, 3> : pf == 2 ? spectre_mix_regtile64p<4, 2>
               : pf == 1 ? spectre_mix_regtile64p<4, 1> : pf == -1 ? spectre_mix_regtile64p<4, 0, 0, true> : spectre_mix_regtile64p<4, 0>;
   if (with_mem) kern = spectre_mix_regtile64p<4, 1, 0, true, true>;   // + memory_fft (spectre.py:548-549)
-  if (in_bf16) kern = pf == 2 ? spectre_mix_regtile64p<4, 2, 0, true, false, true> : spectre_mix_regtile64p<4, 3, 0, true, false, true>;   // bf16 rows in
+  if (in_bf16) kern = pf == 2 ? spectre_mix_regtile64p<4, 2, 0, true, false, true> : pf == 3 ? spectre_mix_regtile64p<4, 3, 0, true, false, true>
+                                : spectre_mix_regtile64p<3, 3, 0, true, false, true>;   // bf16 rows in
   const int variant = in_bf16 ? 2 : with_mem ? 1 : 0;
   int dev = 0;
   (void)hipGetDevice(&dev);
