@@ -1,5 +1,5 @@
 // kernel_regtile64p.h — persistent, software-pipelined spectral mix for n_fft = 4096 = 64 x 64 on gfx950 (every 16-channel tile
-// inside one gate group, 16-byte aligned fp32 rows; optional memory_fft; ANY sequence length: rows beyond N_in are the buffer
+// inside one gate group, 16-byte aligned fp32 rows or 8-byte aligned bf16 rows in, fp32 or (with bf16 in) bf16 rows out; optional memory_fft; ANY sequence length: rows beyond N_in are the buffer
 // instructions' out-of-range case — loads return 0 = rfft's zero padding (spectre.py:506), stores are dropped (spectre.py:553) —
 // so a padded sequence costs exactly what a full one costs, without a single predicate).
 //
@@ -154,10 +154,11 @@ __device__ __forceinline__ void p64_exchange(float2 (&z)[64], float* img, int p,
 //         channels of a row — 8 bytes, two packed dwords = its two sequences — so the lane map, the swap and everything after it are
 //         the fp32 kernel's; only the staging differs (8-byte LDS-DMA does not exist: a DMA instruction fetches 8 whole 32-byte row
 //         segments, lane = (row, dword), and every lane reads its 8 bytes back out of its wave's slot).
-template <int SPLIT, int PF = 0, int ABL = 0, bool FEN = (PF > 0), bool WITH_MEM = false, bool IN_BF16 = false>
+// OUT_BF16 = bf16 rows out (round to nearest even, like every other kernel here): a lane stores its 4 channels as 8 bytes.
+template <int SPLIT, int PF = 0, int ABL = 0, bool FEN = (PF > 0), bool WITH_MEM = false, bool IN_BF16 = false, bool OUT_BF16 = false>
 __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileArgs a) {
   constexpr int RW = 8 * 68, PS = 68;              // image row / column strides in floats (kernel_regtile.h, 16-byte layout)
-  constexpr int ESI = IN_BF16 ? 2 : 4;             // bytes per input element
+  constexpr int ESI = IN_BF16 ? 2 : 4, ESO = OUT_BF16 ? 2 : 4;   // bytes per input / output element
   constexpr float inv_n = 1.0f / 4096.0f;
   static_assert(SPLIT >= 0 && SPLIT <= 4 && SPLIT * 4 * 1024 * 8 <= kP64ImageBytes, "staging lives in the exchange image");
   static_assert(PF >= 0 && SPLIT + PF <= 8, "row groups: SPLIT through LDS, PF deferred / prefetched in registers, the rest behind their stores");
@@ -203,7 +204,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
   constexpr bool SWEEP = (ABL & 4096) != 0;
   // GANG neighbouring workgroups (same L2) walk through GANG adjacent tiles in step = one 128-byte line per row: the L2 fetches a
   // line once and the neighbours' requests hit (fp32: two 64-byte halves; bf16: four 32-byte quarters)
-  constexpr int GANG = kP64Gang<IN_BF16>;
+  constexpr int GANG = kP64Gang<(IN_BF16 || OUT_BF16)>;
   const int tile_step = SWEEP ? a.n_wg : GANG;
   const int pair_base = SWEEP ? wg_lin : (wg_lin / GANG) * a.tpw * GANG + (wg_lin % GANG);
   if (pair_base >= a.n_tiles) return;
@@ -262,7 +263,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
   auto tile_ptrs = [&](int tile, const char*& vb, char*& ob, const float2*& gp) {
     const int b = tile / a.tiles_per_row, ct = tile - b * a.tiles_per_row;
     vb = reinterpret_cast<const char*>(a.v) + ((size_t)b * a.v_sb + (size_t)ct * 16) * ESI;
-    ob = reinterpret_cast<char*>(a.out) + ((size_t)b * a.out_sb + (size_t)ct * 16) * 4;
+    ob = reinterpret_cast<char*>(a.out) + ((size_t)b * a.out_sb + (size_t)ct * 16) * ESO;
     // ABL bit10 / bit11 (tools/p64_ab_bench.hip): every workgroup of an XCD stores to / loads from ONE dense 256-KiB tile (row stride
     // 64 bytes, see v_sn / out_sn in the tile loop) — real requests and acknowledgements that never leave the L2
     if constexpr ((ABL & 1024) != 0) ob = reinterpret_cast<char*>(a.out) + (size_t)(blockIdx.x % 8) * (4096 * 64);
@@ -285,7 +286,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
   };
   auto rsrc_out = [&](char* ob, long long sn, bool live = true) {
     const int rows = (ABL & 256) != 0 || !live ? 0 : a.N_in < 4096 ? a.N_in : 4096;
-    return __builtin_amdgcn_make_buffer_rsrc(ob, 0, (int)((long long)rows * sn * 4), kP64RsrcFlags);
+    return __builtin_amdgcn_make_buffer_rsrc(ob, 0, (int)((long long)rows * sn * ESO), kP64RsrcFlags);
   };
   auto unpack_lo = [](uint32_t d) { return make_float2(__uint_as_float(d << 16), __uint_as_float(d & 0xffff0000u)); };   // two bf16 -> (re, im)
   auto load_group = [&](__amdgpu_buffer_rsrc_t rs, uint32_t voff, long long sn, auto gc) {       // straight into the registers of group g
@@ -321,10 +322,16 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
       }
     });
   };
-  auto store16 = [&](__amdgpu_buffer_rsrc_t rs, uint32_t off, const float4 v) {
-    p64_u32x4 t;
-    t.x = __float_as_uint(v.x); t.y = __float_as_uint(v.y); t.z = __float_as_uint(v.z); t.w = __float_as_uint(v.w);
-    __builtin_amdgcn_raw_buffer_store_b128(t, rs, off, 0, 0);
+  auto store16 = [&](__amdgpu_buffer_rsrc_t rs, uint32_t off, const float4 v) {   // this lane's 4 channels of one row
+    if constexpr (OUT_BF16) {
+      rt_u32x2 t;
+      t.x = f32_to_bf16_rne(v.x) | (f32_to_bf16_rne(v.y) << 16); t.y = f32_to_bf16_rne(v.z) | (f32_to_bf16_rne(v.w) << 16);
+      __builtin_amdgcn_raw_buffer_store_b64(t, rs, off, 0, 0);
+    } else {
+      p64_u32x4 t;
+      t.x = __float_as_uint(v.x); t.y = __float_as_uint(v.y); t.z = __float_as_uint(v.z); t.w = __float_as_uint(v.w);
+      __builtin_amdgcn_raw_buffer_store_b128(t, rs, off, 0, 0);
+    }
   };
   auto read_group = [&](auto gc) {                                       // this lane's bytes back out of the slot
     constexpr int g = decltype(gc)::value;
@@ -409,11 +416,11 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
     // ---- the tile arrives.  The LDS-staged groups were requested before the previous tile's stores and completion is in order, so
     //      once everything but the 16 youngest stores and the 5 gate loads has retired (vmcnt(21) below) they are in the slots.
 
-    [[maybe_unused]] const uint32_t pf_ooff = (uint32_t)(((long long)(u + 512 * h) * out_sn + 4 * pp) * 4);
+    [[maybe_unused]] const uint32_t pf_ooff = (uint32_t)(((long long)(u + 512 * h) * out_sn + 4 * pp) * ESO);
     [[maybe_unused]] const uint32_t pf_voff = (uint32_t)(((long long)(u + 512 * h) * v_sn + 4 * pp) * ESI);
     [[maybe_unused]] auto pf_store = [&](auto ic) {
       constexpr int g = GP + decltype(ic)::value / 4, m = decltype(ic)::value % 4;
-      store16(rsrc_out(obp, out_sn, it > 0), pf_ooff + (uint32_t)((64 * g + 1024 * m) * out_sn * 4), dfr[decltype(ic)::value]);
+      store16(rsrc_out(obp, out_sn, it > 0), pf_ooff + (uint32_t)((64 * g + 1024 * m) * out_sn * ESO), dfr[decltype(ic)::value]);
     };
     [[maybe_unused]] auto pf_load = [&](auto ic) {
       constexpr int g = GP + decltype(ic)::value / 4, m = decltype(ic)::value % 4;
@@ -576,7 +583,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
       p64_stageA1<true, FEN>(z);
     }
     {
-      const uint32_t ooff = (uint32_t)(((long long)(u + 512 * h) * out_sn + 4 * pp) * 4);
+      const uint32_t ooff = (uint32_t)(((long long)(u + 512 * h) * out_sn + 4 * pp) * ESO);
       static_for<0, 8>([&](auto ic) {
         constexpr int g = (decltype(ic)::value + SPLIT) % 8;             // register-loaded groups first: their reloads start earliest
         constexpr bool stores_now = g < GP && (ABL & 262144) == 0 && ((ABL & 64) == 0 || decltype(ic)::value % 2 == 0) && ((ABL & 128) == 0 || decltype(ic)::value % 4 == 0);                               // (deferred groups are stored before the next E1)
@@ -600,10 +607,10 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
                 z[8 * g + 2 * m + 1] = make_float2(nx.z, nx.w);
               }
             } else {
-              store16(rs_out, ooff + (uint32_t)((64 * g + 1024 * m) * out_sn * 4), res);
+              store16(rs_out, ooff + (uint32_t)((64 * g + 1024 * m) * out_sn * ESO), res);
             }
           } else {
-            store16(rs_out, ooff + (uint32_t)((64 * g + 1024 * m) * out_sn * 4), res);
+            store16(rs_out, ooff + (uint32_t)((64 * g + 1024 * m) * out_sn * ESO), res);
           }
         });
         if constexpr (g >= SPLIT && g < GP) load_group(rs_next, voff, v_sn, std::integral_constant<int, g>{});
@@ -620,6 +627,6 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
   }
 }
 
-hipError_t launch_regtile64p(const RegtileArgs& a, bool in_bf16, hipStream_t stream);
+hipError_t launch_regtile64p(const RegtileArgs& a, bool in_bf16, bool out_bf16, hipStream_t stream);
 
 }  // namespace sfft

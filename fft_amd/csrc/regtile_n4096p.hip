@@ -3,9 +3,9 @@
 #include <atomic>
 #include <cstdlib>
 namespace sfft {
-hipError_t launch_regtile64p(const RegtileArgs& a, bool in_bf16, hipStream_t stream) {
+hipError_t launch_regtile64p(const RegtileArgs& a, bool in_bf16, bool out_bf16, hipStream_t stream) {
   const bool with_mem = a.mem != nullptr;
-  static std::atomic<bool> lds_opt_in[16][3];   // [device]: > 64 KiB of dynamic LDS needs a one-time opt-in (idempotent; the flag only saves the call)
+  static std::atomic<bool> lds_opt_in[16][4];   // [device]: > 64 KiB of dynamic LDS needs a one-time opt-in (idempotent; the flag only saves the call)
   // SPLIT = row groups of the next tile that travel through LDS (LDS-DMA, requested before the stores), PF = row groups whose stores /
   // loads are moved out of the store/load burst to the end of F1 (16 registers each); the other 8 - SPLIT - PF groups are reloaded
   // behind their own stores.  Interleaved A/B on one box (tools/p64_ab_bench.hip, profiles/r02_p64_ab_waits.log): round-1 kernel
@@ -18,7 +18,8 @@ hipError_t launch_regtile64p(const RegtileArgs& a, bool in_bf16, hipStream_t str
   if (with_mem) kern = spectre_mix_regtile64p<4, 1, 0, true, true>;   // + memory_fft (spectre.py:548-549)
   if (in_bf16) kern = pf == 2 ? spectre_mix_regtile64p<4, 2, 0, true, false, true> : pf == 3 ? spectre_mix_regtile64p<4, 3, 0, true, false, true>
                                 : spectre_mix_regtile64p<3, 3, 0, true, false, true>;   // bf16 rows in
-  const int variant = in_bf16 ? 2 : with_mem ? 1 : 0;
+  if (in_bf16 && out_bf16) kern = spectre_mix_regtile64p<3, 3, 0, true, false, true, true>;   // bf16 rows in and out
+  const int variant = in_bf16 ? (out_bf16 ? 3 : 2) : with_mem ? 1 : 0;
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev < 0 || dev >= 16 || !lds_opt_in[dev][variant]) {

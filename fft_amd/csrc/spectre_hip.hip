@@ -31,7 +31,7 @@ template <> hipError_t launch_regtile<32, 16>(const RegtileArgs&, bool, bool, in
 template <> hipError_t launch_regtile<32, 32>(const RegtileArgs&, bool, bool, int, hipStream_t);
 template <> hipError_t launch_regtile<64, 32>(const RegtileArgs&, bool, bool, int, hipStream_t);
 template <> hipError_t launch_regtile<64, 64>(const RegtileArgs&, bool, bool, int, hipStream_t);
-hipError_t launch_regtile64p(const RegtileArgs&, bool in_bf16, hipStream_t);                           // regtile_n4096p.hip (persistent, pipelined)
+hipError_t launch_regtile64p(const RegtileArgs&, bool in_bf16, bool out_bf16, hipStream_t);                           // regtile_n4096p.hip (persistent, pipelined)
 hipError_t launch_regtile_long_8192(const RegtileArgs&, bool, bool, int, hipStream_t);   // regtile_n8192.hip, regtile_n6144.hip
 hipError_t launch_regtile_long_6144(const RegtileArgs&, bool, bool, int, hipStream_t);
 hipError_t launch_regtile_quad_16384(const RegtileArgs&, bool, bool, int, hipStream_t);   // regtile_n16384.hip, regtile_n12288.hip
@@ -342,9 +342,10 @@ int choose(const SpectreMixArgs* a, const Plan* plan, Choice* c) {
   // 32-bit byte offsets
   static const bool p64_bf16_off = [] { const char* e = getenv("SPECTRE_P64_BF16"); return e && atoi(e) == 0; }();
   const bool in_bf = a->in_dtype == SPECTRE_BF16;     // a lane moves the 4 channels of a row: 16 bytes of fp32, 8 of bf16
-  const bool pipelined_ok = can_regtile && ts && !ts->mixed && ts->tile_ch == 16 && !p64_off && n == 4096 && (mode == 0 || mode == 3 || mode == 4) && a->out_dtype == SPECTRE_F32 &&
-                   (!in_bf || (mode != 4 && !p64_bf16_off)) &&
-                   reinterpret_cast<uintptr_t>(a->v) % (in_bf ? 8 : 16) == 0 && reinterpret_cast<uintptr_t>(a->out) % 16 == 0 &&
+  const bool out_bf = a->out_dtype == SPECTRE_BF16;   // built: f32 -> f32 (+ memory_fft), bf16 -> f32, bf16 -> bf16
+  const bool pipelined_ok = can_regtile && ts && !ts->mixed && ts->tile_ch == 16 && !p64_off && n == 4096 && (mode == 0 || mode == 3 || mode == 4) &&
+                   (!out_bf || in_bf) && (!in_bf || (mode != 4 && !p64_bf16_off)) &&
+                   reinterpret_cast<uintptr_t>(a->v) % (in_bf ? 8 : 16) == 0 && reinterpret_cast<uintptr_t>(a->out) % (out_bf ? 8 : 16) == 0 &&
                    a->v_sn % 4 == 0 && a->v_sb % 4 == 0 && a->out_sn % 4 == 0 && a->out_sb % 4 == 0 &&
                    a->v_sn * 4096 * 4 + 64 < ((int64_t)1 << 32) && a->out_sn * 4096 * 4 + 64 < ((int64_t)1 << 32);
   bool can = can_regtile;
@@ -434,11 +435,11 @@ int launch(const SpectreMixArgs* a, const Plan* plan, const Choice& c, bool conj
     if (c.pipelined) {   // one workgroup per CU walks through tpw tiles; pairs of workgroups stay on adjacent tiles
       const int ncu = cu_count(a->device);
       static const int forced = [] { const char* e = getenv("SPECTRE_P64_TPW"); return e ? atoi(e) : 0; }();
-      const int gang = ib ? 4 : 2;                  // kP64Gang: workgroups that share a 128-byte line walk through adjacent tiles
+      const int gang = (ib || ob) ? 4 : 2;                  // kP64Gang: workgroups that share a 128-byte line walk through adjacent tiles
       const int slots = std::max(gang, ncu / gang * gang);
       k.tpw = forced > 0 ? forced : std::max(1, (k.n_tiles + slots - 1) / slots);
       k.n_wg = gang * ((k.n_tiles + gang * k.tpw - 1) / (gang * k.tpw));
-      e = sfft::launch_regtile64p(k, ib, stream);
+      e = sfft::launch_regtile64p(k, ib, ob, stream);
     } else {
       e = c.tile->launch(k, ib, ob, c.mode, stream);
     }

@@ -56,7 +56,9 @@ def test_native_library_is_the_thing_that_runs():
     V, gate, _ = _problem(0, 2, 4096, 32, 2, 4096)
     assert _describe(V.to(DEV), gate.to(DEV)).startswith("regtile-pipelined 64x64")   # fast mode, fp32, 16-byte aligned rows
     assert _describe(V.to(DEV)[:, :4000], gate.to(DEV), None, 4096).startswith("regtile-pipelined 64x64 in=f32 out=f32 mode=3")   # padded: same kernel
-    assert _describe(V.to(DEV).bfloat16(), gate.to(DEV), None, 4096).startswith("regtile 64x64")   # bf16 storage: row-predicated kernel
+    assert _describe(V.to(DEV).bfloat16(), gate.to(DEV), None, 4096).startswith("regtile-pipelined 64x64 in=bf16 out=bf16")   # bf16 rows in and out: same kernel
+    Vb = torch.zeros(2, 4096, 34, device=DEV, dtype=torch.bfloat16)[:, :, 2:]     # a bf16 view that is only 4-byte aligned: the round-1 kernel
+    assert _describe(Vb, gate.to(DEV), None, 4096).startswith("regtile 64x64 in=bf16 out=bf16")
     assert _describe(V.to(DEV), gate.to(DEV), algo="stockham").startswith("stockham")
     for n, tag in ((256, "16x16"), (512, "32x16"), (1024, "32x32"), (2048, "64x32")):
         Vn, gn, _ = _problem(0, 1, n, 16, 1, n)

@@ -190,3 +190,21 @@ def test_bf16_in_unaligned_view_falls_back_and_agrees():
     torch.cuda.synchronize()
     rms = float(y.square().mean().sqrt())
     assert float((y - y_view).abs().max()) <= 1e-4 * rms
+
+
+@pytest.mark.parametrize("B,Nin,D,G", [(1, 4096, 16, 1), (3, 4096, 64, 4), (37, 4096, 112, 7), (3, 4000, 64, 2), (2, 1000, 48, 3), (2, 5000, 32, 2)])
+def test_bf16_in_bf16_out_is_the_rounded_f32_result(B, Nin, D, G):
+    """bf16 rows out = round-to-nearest-even of what the bf16 -> f32 variant stores (same arithmetic, same kernel), bit for bit; and that
+    is within the fp32 tolerance of the oracle (checked above), so the bf16 result is the oracle's within one bf16 rounding."""
+    from fft_amd import spectral_mix, describe
+    torch.manual_seed(B + Nin + D)
+    V = torch.randn(B, Nin, D, device=DEV).bfloat16()
+    gate = (torch.randn(B, G, N // 2 + 1, dtype=torch.complex64, device=DEV) * 0.3)
+    assert describe(V, gate, None, N).startswith("regtile-pipelined 64x64 in=bf16 out=bf16")
+    yb = spectral_mix(V, gate, None, N)
+    yf = spectral_mix(V, gate, None, N, out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    assert yb.dtype == torch.bfloat16 and yb.shape == (B, min(Nin, N), D)
+    assert torch.equal(yb, yf.bfloat16())
+    ref = spectral_mix_numpy(V.float().cpu().numpy(), gate.cpu().numpy(), None, N)
+    assert_close(yb.float().cpu().numpy(), ref, rtol=1e-2, atol_rms=1e-2, what=f"bf16 out ({B},{Nin},{D})")
