@@ -1,0 +1,223 @@
+// kernel_regtile_mixedp.h — persistent, software-pipelined variant of kernel_regtile_mixed.h (n_fft = RF * RS, e.g. 3000 = 60 x 50) for
+// fp32 rows in and out, every 16-channel tile inside one gate group, any sequence length (rows >= N_in are the buffer instructions'
+// out-of-range case, as in kernel_regtile64p.h).  Same mathematics, same tile, same exchanges; replaces /root/reference/spectre.py:506,
+// :542-553.
+//
+// A mixed-radix tile needs 2 * max(RF, RS) data registers per thread (120 for 60 x 50) of the 256 a 400-thread workgroup may use, so —
+// unlike at n_fft = 4096, where the tile fills the register file — P row blocks can be DEFERRED the way kernel_regtile64p.h defers three
+// row groups: their results stay in 2 P registers through F1 of the next tile and are stored there (a quiet part of the tile), the same
+// registers then request those row blocks of the tile after, which trade places with the next results at the end of I2.  The other
+// RF - P row blocks are stored at the end of the tile and reloaded behind their stores.  One workgroup per CU walks through its tiles,
+// pairs of workgroups on adjacent tiles (one 128-byte line per row).  Everything learned there about hipcc's waits applies: LDS-only
+// barriers (a __syncthreads() would drain the deferred requests), every request unconditional (an empty buffer range when there is no
+// next / previous tile), the gate bins requested raw and fixed up at commit time, the twiddle bases requested BEFORE the deferred block.
+#pragma once
+#include "kernel_regtile_mixed.h"
+
+namespace sfft {
+
+__device__ __forceinline__ void rt_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int RF, int RS, int P, bool FIRST = false>
+__global__ void __launch_bounds__(kPC * (RF > RS ? RF : RS), 1) spectre_mix_regtile_mixedp(const RegtileArgs a) {
+  constexpr int D0 = FIRST ? 0 : RF - P;           // the deferred row blocks are [D0, D0 + P) of the order F1 uses them (the last ones: measured
+                                                   // 1 % better than the first ones, 1.586 vs 1.605 ms)
+  constexpr int N = RF * RS, NZ = mixed_team<RF, RS>(), NT = mixed_threads<RF, RS>();
+  static_assert(N % 2 == 0 && P >= 0 && P <= RF, "even n_fft; P deferred row blocks");
+  constexpr int RAF = Split<RF>::RA, RBF = Split<RF>::RB;
+  constexpr int ROW1 = mixed_row(RS), ROW2 = mixed_row(RF);
+  constexpr int GS = (N / 2 + 1 + NT - 1) / NT;     // gate bins per thread
+  constexpr float inv_n = 1.0f / (float)N;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* img = reinterpret_cast<float*>(smem);
+  float2* glds = reinterpret_cast<float2*>(smem + mixed_image_bytes<RF, RS>());
+
+  // Only threadIdx.x stays live across the tile loop; the lane coordinates are re-derived from an opaque copy per tile (otherwise LICM
+  // hoists every per-lane address out of the loop and the allocator spills them; kernel_regtile64p.h).
+  const int tid0 = threadIdx.x;
+  int tid, p, u;
+  bool rows, bins;
+  auto coords = [&]() {
+    int t = tid0;
+    asm volatile("" : "+v"(t));
+    tid = t; p = t & (kPC - 1); u = t / kPC;
+    rows = u < RS; bins = u < RF;
+  };
+  coords();
+
+  const int wg_lin = xcd_contiguous(blockIdx.x, a.n_wg);
+  const int pair_base = (wg_lin >> 1) * a.tpw * 2 + (wg_lin & 1);   // workgroups 2m, 2m+1 walk through adjacent tiles
+  if (pair_base >= a.n_tiles) return;
+
+  float2 z[NZ];
+  float2 dfr[P > 0 ? P : 1];                        // deferred results of the previous tile / prefetched row blocks of the next one
+  float2 gst[GS];
+  static_for<0, (P > 0 ? P : 1)>([&](auto ic) { dfr[decltype(ic)::value] = make_float2(0.f, 0.f); });
+  char* obp = nullptr;                              // output tile of the deferred results
+
+  auto tile_ptrs = [&](int tile, const char*& vb, char*& ob, const float2*& gp) {
+    const int b = tile / a.tiles_per_row, ct = tile - b * a.tiles_per_row;
+    vb = reinterpret_cast<const char*>(a.v) + ((size_t)b * a.v_sb + (size_t)ct * 16) * 4;
+    ob = reinterpret_cast<char*>(a.out) + ((size_t)b * a.out_sb + (size_t)ct * 16) * 4;
+    gp = a.gate + ((size_t)b * a.G + (ct * 16) / a.d_g) * a.F;
+  };
+  // Buffer resources: base = the tile's first row, num_records = the bytes of its rows below N_in (0 = nothing: no such tile).  The
+  // range check covers the VGPR offset, so the row-block offset goes there too; threads that own no row class (RF > RS) get an offset
+  // beyond every range, so every wave issues the same requests.
+  auto rsrc = [&](const void* base, long long sn, bool live) {
+    const int nrow = !live ? 0 : a.N_in < N ? a.N_in : N;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)((long long)nrow * sn * 4), kRsrcFlags);
+  };
+  // row blocks in the order F1 uses them
+  auto row_q = [](auto ic) { constexpr int i = decltype(ic)::value; return std::integral_constant<int, (i / RAF) + RBF * (i % RAF)>{}; };
+  auto load_row = [&](__amdgpu_buffer_rsrc_t rs, uint32_t voff, long long sn, auto qc) -> float2 {
+    const rt_u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, voff + (uint32_t)((long long)decltype(qc)::value * RS * sn * 4), 0, 0);
+    return make_float2(__uint_as_float(t.x), __uint_as_float(t.y));
+  };
+  auto store_row = [&](__amdgpu_buffer_rsrc_t rs, uint32_t ooff, long long sn, auto qc, float2 v) {
+    rt_u32x2 t;
+    t.x = __float_as_uint(v.x); t.y = __float_as_uint(v.y);
+    __builtin_amdgcn_raw_buffer_store_b64(t, rs, ooff + (uint32_t)((long long)decltype(qc)::value * RS * sn * 4), 0, 0);
+  };
+  auto gate_fetch = [&](const float2* gp) {          // raw; all arithmetic happens in gate_commit (nothing computed before the back edge)
+    static_for<0, GS>([&](auto ic) {
+      const int k = tid + NT * decltype(ic)::value;
+      gst[decltype(ic)::value] = gp[k <= N / 2 ? k : N / 2];
+    });
+  };
+  auto gate_commit = [&]() {
+    static_for<0, GS>([&](auto ic) {
+      const int k = tid + NT * decltype(ic)::value;
+      float2 g = gst[decltype(ic)::value];
+      asm volatile("" : "+v"(g.x), "+v"(g.y));       // consumed here by every wave (kernel_regtile64p.h)
+      if (k == 0 || k == N / 2) g.y = 0.f;           // irfft ignores Im(DC), Im(Nyquist) (spectre.py:551)
+      if (a.conj_gate) g.y = -g.y;
+      if (k <= N / 2) glds[k] = make_float2(g.x * inv_n, g.y * inv_n);
+    });
+  };
+  auto load_twiddle_bases = [&](float2 (&wa)[RAF], float2 (&wb)[RBF]) {   // W_N^(u ka), W_N^(u RAF kb)
+    const int uu = rows ? u : 0;
+    static_for<1, RAF>([&](auto jc) { constexpr int j = decltype(jc)::value; wa[j] = a.tw[uu * j]; });
+    static_for<1, RBF>([&](auto jc) { constexpr int j = decltype(jc)::value; wb[j] = a.tw[uu * RAF * j]; });
+  };
+
+  // ---- prologue: the whole first tile is loaded the way the non-deferred row blocks of every later tile are --------------------
+  {
+    const char* vb; char* ob; const float2* gp;
+    tile_ptrs(pair_base, vb, ob, gp);
+    const __amdgpu_buffer_rsrc_t rs = rsrc(vb, a.v_sn, true);
+    const uint32_t voff = rows ? (uint32_t)(((long long)u * a.v_sn + 2 * p) * 4) : 0x80000000u;
+    static_for<0, RF>([&](auto ic) { constexpr int q = decltype(row_q(ic))::value; z[q] = load_row(rs, voff, a.v_sn, std::integral_constant<int, q>{}); });
+    gate_fetch(gp);
+  }
+
+  for (int it = 0; it < a.tpw; ++it) {
+    const int tile = pair_base + 2 * it;
+    if (tile >= a.n_tiles) break;                    // workgroup-uniform
+    const bool more = (it + 1 < a.tpw) && (tile + 2 < a.n_tiles);
+    coords();
+    long long v_sn = a.v_sn, out_sn = a.out_sn;
+    asm volatile("" : "+s"(v_sn), "+s"(out_sn));
+    const char* vb; char* ob; const float2* gp;
+    tile_ptrs(tile, vb, ob, gp);
+    const char* vbn = vb; char* obn = ob; const float2* gpn = gp;
+    if (more) tile_ptrs(tile + 2, vbn, obn, gpn);
+    const __amdgpu_buffer_rsrc_t rs_next = rsrc(vbn, v_sn, more), rs_out = rsrc(ob, out_sn, true), rs_prev = rsrc(obp, out_sn, it > 0);
+    const uint32_t voff = rows ? (uint32_t)(((long long)u * v_sn + 2 * p) * 4) : 0x80000000u;
+    const uint32_t ooff = rows ? (uint32_t)(((long long)u * out_sn + 2 * p) * 4) : 0x80000000u;
+
+    // ---- rows u + RS*q, q < RF: F1 over q, W_N^(u k1) ---------------------------------------------------------------------
+    float2 wa[RAF], wb[RBF];
+    load_twiddle_bases(wa, wb);
+    if (rows) {
+      fft_ct<RF, false, IdentityMap, NZ>(z);
+      static_for<1, RF>([&](auto kc) {
+        constexpr int k1 = decltype(kc)::value, ka = k1 % RAF, kb = k1 / RAF, pos = out_pos<RF>(k1);
+        if constexpr (ka > 0) z[pos] = cmul(z[pos], wa[ka]);
+        if constexpr (kb > 0) z[pos] = cmul(z[pos], wb[kb]);
+      });
+    }
+    gate_commit();                                   // this tile's bins (requested behind the previous tile's stores) -> LDS
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- the quiet part of the tile starts: the deferred results of the previous tile leave, the same row blocks of the next tile
+    //      are requested into the registers they vacate
+    static_for<D0, D0 + P>([&](auto ic) { store_row(rs_prev, ooff, out_sn, row_q(ic), dfr[decltype(ic)::value - D0]); });
+    static_for<D0, D0 + P>([&](auto ic) { dfr[decltype(ic)::value - D0] = load_row(rs_next, voff, v_sn, row_q(ic)); });
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- E1 (kernel_regtile_mixed.h); the first barrier also separates it from the previous tile's E2 reads ---------------
+    rt_lds_barrier();
+    if (rows) static_for<0, RF>([&](auto kc) { constexpr int k1 = decltype(kc)::value; img[k1 * ROW1 + u * kPC + p] = z[out_pos<RF>(k1)].x; });
+    rt_lds_barrier();
+    if (bins) static_for<0, RS>([&](auto nc) { constexpr int n2 = decltype(nc)::value; z[n2].x = img[u * ROW1 + n2 * kPC + p]; });
+    rt_lds_barrier();
+    if (rows) static_for<0, RF>([&](auto kc) { constexpr int k1 = decltype(kc)::value; img[k1 * ROW1 + u * kPC + p] = z[out_pos<RF>(k1)].y; });
+    rt_lds_barrier();
+    if (bins) static_for<0, RS>([&](auto nc) { constexpr int n2 = decltype(nc)::value; z[n2].y = img[u * ROW1 + n2 * kPC + p]; });
+    rt_lds_barrier();
+
+    // ---- bins k = u + RF*k2: F2 over n2, gate, I1 over k2 ------------------------------------------------------------------
+    using BinMap = OutPosMap<RS>;
+    if (bins) {
+      fft_ct<RS, false, IdentityMap, NZ>(z);
+      static_for<0, RS>([&](auto kc) {
+        constexpr int k2 = decltype(kc)::value, pos = BinMap::at(k2);
+        const int k = u + RF * k2;
+        const bool upper = 2 * k > N;                // Hermitian extension: conj(g[N - k])
+        float2 g = glds[upper ? N - k : k];
+        if (upper) g.y = -g.y;
+        z[pos] = cmul(z[pos], g);                    // spectre.py:545
+      });
+      fft_ct<RS, true, BinMap, NZ>(z);
+    }
+
+    // ---- E2 ---------------------------------------------------------------------------------------------------------------
+    if (bins) static_for<0, RS>([&](auto nc) { constexpr int n2 = decltype(nc)::value; img[n2 * ROW2 + u * kPC + p] = z[BinMap::at(out_pos<RS>(n2))].x; });
+    rt_lds_barrier();
+    if (rows) static_for<0, RF>([&](auto kc) { constexpr int k1 = decltype(kc)::value; z[k1].x = img[u * ROW2 + k1 * kPC + p]; });
+    rt_lds_barrier();
+    if (bins) static_for<0, RS>([&](auto nc) { constexpr int n2 = decltype(nc)::value; img[n2 * ROW2 + u * kPC + p] = z[BinMap::at(out_pos<RS>(n2))].y; });
+    rt_lds_barrier();
+    if (rows) static_for<0, RF>([&](auto kc) { constexpr int k1 = decltype(kc)::value; z[k1].y = img[u * ROW2 + k1 * kPC + p]; });
+
+    // ---- conj twiddle, I2 over k1, store rows u + RS*n1 (spectre.py:553), reload / trade places -------------------------------
+    load_twiddle_bases(wa, wb);
+    if (rows) {
+      static_for<1, RF>([&](auto kc) {
+        constexpr int k1 = decltype(kc)::value, ka = k1 % RAF, kb = k1 / RAF;
+        if constexpr (ka > 0) z[k1] = cmulc(z[k1], wa[ka]);
+        if constexpr (kb > 0) z[k1] = cmulc(z[k1], wb[kb]);
+      });
+      fft_ct<RF, true, IdentityMap, NZ>(z);
+    }
+    // results: row block n1 lives at z[out_pos<RF>(n1)].  Everything is read out first (SSA values: no register moves), then the row
+    // blocks of the next tile move in: reloaded behind their stores, or — the deferred ones — out of the registers that now keep results
+    float2 res[RF];
+    static_for<0, RF>([&](auto nc) { constexpr int n1 = decltype(nc)::value; res[n1] = z[out_pos<RF>(n1)]; });
+    static_for<0, RF>([&](auto ic) {
+      constexpr int i = decltype(ic)::value, q = decltype(row_q(ic))::value;
+      if constexpr (i < D0 || i >= D0 + P) store_row(rs_out, ooff, out_sn, std::integral_constant<int, q>{}, res[q]);
+    });
+    if (more) {
+      static_for<D0, D0 + P>([&](auto ic) {
+        constexpr int q = decltype(row_q(ic))::value, i = decltype(ic)::value - D0;
+        const float2 nx = dfr[i];
+        dfr[i] = res[q];
+        z[q] = nx;
+      });
+    } else {
+      static_for<D0, D0 + P>([&](auto ic) { constexpr int q = decltype(row_q(ic))::value; store_row(rs_out, ooff, out_sn, std::integral_constant<int, q>{}, res[q]); });
+    }
+    static_for<0, RF>([&](auto ic) {
+      constexpr int i = decltype(ic)::value, q = decltype(row_q(ic))::value;
+      if constexpr (i < D0 || i >= D0 + P) z[q] = load_row(rs_next, voff, v_sn, std::integral_constant<int, q>{});
+    });
+    obp = ob;
+    gate_fetch(gpn);                                 // (after the last tile: a harmless re-read of this tile's bins)
+  }
+}
+
+template <int RF, int RS>
+hipError_t launch_regtile_mixedp(const RegtileArgs& a, hipStream_t stream);
+
+}  // namespace sfft

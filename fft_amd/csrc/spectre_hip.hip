@@ -32,6 +32,8 @@ template <> hipError_t launch_regtile<32, 32>(const RegtileArgs&, bool, bool, in
 template <> hipError_t launch_regtile<64, 32>(const RegtileArgs&, bool, bool, int, hipStream_t);
 template <> hipError_t launch_regtile<64, 64>(const RegtileArgs&, bool, bool, int, hipStream_t);
 hipError_t launch_regtile64p(const RegtileArgs&, bool in_bf16, bool out_bf16, hipStream_t);                           // regtile_n4096p.hip (persistent, pipelined)
+template <int RF, int RS> hipError_t launch_regtile_mixedp(const RegtileArgs&, hipStream_t);        // kernel_regtile_mixedp.h (persistent, deferred row blocks)
+template <> hipError_t launch_regtile_mixedp<60, 50>(const RegtileArgs&, hipStream_t);               // regtile_n3000p.hip
 hipError_t launch_regtile_long_8192(const RegtileArgs&, bool, bool, int, hipStream_t);   // regtile_n8192.hip, regtile_n6144.hip
 hipError_t launch_regtile_long_6144(const RegtileArgs&, bool, bool, int, hipStream_t);
 hipError_t launch_regtile_quad_16384(const RegtileArgs&, bool, bool, int, hipStream_t);   // regtile_n16384.hip, regtile_n12288.hip
@@ -282,6 +284,7 @@ struct Choice {
   const TileSize* tile = nullptr;
   int RF = 0, RS = 0;      // n_fft = RF * RS
   int mode = 0;            // 0 fast, 1 general (row predicates / gate from global), 2 general + memory_fft, 3 row predicates only
+  bool mixedp = false;     // n_fft = 3000, fp32 in/out, gate in LDS, 8-byte aligned rows: persistent kernel with deferred row blocks (kernel_regtile_mixedp.h)
   bool pipelined = false;  // n_fft = 4096 fast mode, fp32, 16-byte aligned rows: persistent software-pipelined kernel (kernel_regtile64p.h)
   // stockham
   int P = 0, S = 0, solo = 0;
@@ -359,6 +362,11 @@ int choose(const SpectreMixArgs* a, const Plan* plan, Choice* c) {
     c->tile = ts; c->RF = ts->RF; c->RS = ts->RS;
     c->mode = mode;
     c->pipelined = pipelined_ok;
+    static const bool mixedp_off = [] { const char* e = getenv("SPECTRE_MIXEDP"); return e && atoi(e) == 0; }();
+    c->mixedp = !mixedp_off && ts->mixed && n == 3000 && (mode == 0 || mode == 3) && a->in_dtype == SPECTRE_F32 && a->out_dtype == SPECTRE_F32 &&
+                reinterpret_cast<uintptr_t>(a->v) % 8 == 0 && reinterpret_cast<uintptr_t>(a->out) % 8 == 0 &&
+                a->v_sn % 2 == 0 && a->v_sb % 2 == 0 && a->out_sn % 2 == 0 && a->out_sb % 2 == 0 &&
+                a->v_sn * n * 4 < ((int64_t)1 << 31) && a->out_sn * n * 4 < ((int64_t)1 << 31);
     return SPECTRE_OK;
   }
   // Stockham / Bluestein in LDS: one buffer of L points per slot; P slots per workgroup, limited by the LDS and by
@@ -440,6 +448,12 @@ int launch(const SpectreMixArgs* a, const Plan* plan, const Choice& c, bool conj
       k.tpw = forced > 0 ? forced : std::max(1, (k.n_tiles + slots - 1) / slots);
       k.n_wg = gang * ((k.n_tiles + gang * k.tpw - 1) / (gang * k.tpw));
       e = sfft::launch_regtile64p(k, ib, ob, stream);
+    } else if (c.mixedp) {   // one workgroup per CU, pairs of workgroups on adjacent tiles (kernel_regtile_mixedp.h)
+      const int ncu = cu_count(a->device);
+      const int slots = std::max(2, ncu / 2 * 2);
+      k.tpw = std::max(1, (k.n_tiles + slots - 1) / slots);
+      k.n_wg = 2 * ((k.n_tiles + 2 * k.tpw - 1) / (2 * k.tpw));
+      e = sfft::launch_regtile_mixedp<60, 50>(k, stream);
     } else {
       e = c.tile->launch(k, ib, ob, c.mode, stream);
     }
@@ -533,7 +547,7 @@ int spectre_mix_describe(const SpectreMixArgs* a, char* buf, size_t cap) {
   const char* in = a->in_dtype == SPECTRE_BF16 ? "bf16" : "f32";
   const char* out = a->out_dtype == SPECTRE_BF16 ? "bf16" : "f32";
   if (c.regtile) {
-    snprintf(buf, cap, "regtile%s %dx%d in=%s out=%s mode=%d tiles=%lld", c.pipelined ? "-pipelined" : c.tile->tile_ch == 4 ? "-quad" : c.tile->tile_ch == 8 ? "-long" : c.tile->mixed ? "-mixed" : "", c.RF, c.RS,
+    snprintf(buf, cap, "regtile%s %dx%d in=%s out=%s mode=%d tiles=%lld", c.pipelined ? "-pipelined" : c.mixedp ? "-mixed-pipelined" : c.tile->tile_ch == 4 ? "-quad" : c.tile->tile_ch == 8 ? "-long" : c.tile->mixed ? "-mixed" : "", c.RF, c.RS,
              in, out, c.mode, (long long)(a->B * ((a->D + c.tile->tile_ch - 1) / c.tile->tile_ch)));
   } else {
     std::string r;

@@ -208,3 +208,45 @@ def test_bf16_in_bf16_out_is_the_rounded_f32_result(B, Nin, D, G):
     assert torch.equal(yb, yf.bfloat16())
     ref = spectral_mix_numpy(V.float().cpu().numpy(), gate.cpu().numpy(), None, N)
     assert_close(yb.float().cpu().numpy(), ref, rtol=1e-2, atol_rms=1e-2, what=f"bf16 out ({B},{Nin},{D})")
+
+
+# ---- n_fft = 3000 (BASELINE.json configs[4]): persistent kernel with deferred row blocks (kernel_regtile_mixedp.h) ---------------------
+@pytest.mark.parametrize("B,Nin,D,G", [(1, 3000, 16, 1), (3, 3000, 64, 4), (5, 3000, 80, 5), (37, 3000, 112, 7), (2, 2900, 48, 3),
+                                       (2, 700, 32, 2), (1, 1, 16, 1), (2, 3500, 32, 2)])
+def test_n3000_persistent_matches_oracle(B, Nin, D, G):
+    """tiles = B*D/16: 1, 12, 25 (odd: a workgroup pair with one tile missing), 259 (two tiles per workgroup, odd), padded and truncated."""
+    from fft_amd import describe, spectral_mix
+    n = 3000
+    torch.manual_seed(B * 7 + D + Nin)
+    V = torch.randn(B, Nin, D, device=DEV)
+    gate = torch.randn(B, G, n // 2 + 1, dtype=torch.complex64, device=DEV) * 0.3
+    gate = gate * (torch.rand(B, G, n // 2 + 1, device=DEV) >= 0.15)
+    assert describe(V, gate, None, n).startswith("regtile-mixed-pipelined 60x50")
+    y = spectral_mix(V, gate, None, n)
+    torch.cuda.synchronize()
+    assert y.shape == (B, min(Nin, n), D)
+    assert_close(y.cpu().numpy(), spectral_mix_numpy(V.cpu().numpy(), gate.cpu().numpy(), None, n), what=f"n3000 ({B},{Nin},{D})")
+
+
+def test_n3000_persistent_many_tiles_guard_rows_and_repeatability():
+    """Headline width with several tiles per workgroup; rows beyond N_out stay untouched; two launches are bit-identical; agreement with
+    the one-tile-per-workgroup kernel it replaces (algo="stockham" is a third implementation) on whole tensors, oracle on columns."""
+    from fft_amd import spectral_mix
+    n = 3000
+    torch.manual_seed(5)
+    B, Nin, D, G = 40, 2950, 768, 4
+    V = torch.randn(B, Nin, D, device=DEV)
+    gate = torch.randn(B, G, n // 2 + 1, dtype=torch.complex64, device=DEV) * 0.3
+    out = torch.full((B, Nin + 2, D), 7.0, device=DEV)
+    y = spectral_mix(V, gate, None, n, out=out[:, :Nin])
+    y2 = spectral_mix(V, gate, None, n)
+    y3 = spectral_mix(V, gate, None, n, algo="stockham")
+    torch.cuda.synchronize()
+    assert torch.all(out[:, Nin:] == 7.0)
+    assert torch.equal(y, y2)
+    rms = float(y3.square().mean().sqrt())
+    assert float((y - y3).abs().max()) <= 2e-4 * rms
+    d_g = D // G
+    for (b, c) in [(0, 0), (B - 1, D - 2), (B // 2, 18), (7, D // 2 + 2), (B - 2, 16 * 13 + 4)]:
+        ref = spectral_mix_numpy(V[b:b + 1, :, c:c + 2].cpu().numpy(), gate[b:b + 1, c // d_g:c // d_g + 1].cpu().numpy(), None, n)
+        assert_close(y[b:b + 1, :, c:c + 2].cpu().numpy(), ref, what=f"n3000 column ({b},{c})")
