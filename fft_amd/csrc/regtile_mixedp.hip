@@ -1,0 +1,31 @@
+// Persistent software-pipelined mixed-radix kernels with deferred row blocks (kernel_regtile_mixedp.h): n_fft = 3000 and the larger
+// smooth lengths whose tiles leave a CU to one workgroup.
+#include "kernel_regtile_mixedp.h"
+#include <atomic>
+#include <cstdlib>
+namespace sfft {
+// P = deferred row blocks.  n_fft = 3000 (60 x 50), interleaved runs on one box at (256,3000,768): one tile per workgroup
+// (kernel_regtile_mixed.h) 1.663 ms; P = 0 1.766, 16 1.661, 24 1.507, 26 1.506, 28 1.561 (253 VGPRs), 30 1.628 (spills).
+#define SFFT_DEFINE_MIXEDP_LAUNCHER(RF_, RS_, P_)                                                                       \
+  template <>                                                                                                          \
+  hipError_t launch_regtile_mixedp<RF_, RS_>(const RegtileArgs& a, hipStream_t stream) {                                \
+    auto kern = spectre_mix_regtile_mixedp<RF_, RS_, P_>;                                                               \
+    static std::atomic<bool> lds_opt_in[16];                                                                            \
+    const size_t lds = mixed_lds_total<RF_, RS_>();                                                                     \
+    int dev = 0;                                                                                                        \
+    (void)hipGetDevice(&dev);                                                                                           \
+    if (dev < 0 || dev >= 16 || !lds_opt_in[dev]) {                                                                     \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      if (e != hipSuccess) return e;                                                                                    \
+      if (dev >= 0 && dev < 16) lds_opt_in[dev] = true;                                                                 \
+    }                                                                                                                   \
+    hipLaunchKernelGGL(kern, dim3(a.n_wg), dim3(mixed_threads<RF_, RS_>()), lds, stream, a);                            \
+    return hipGetLastError();                                                                                           \
+  }
+// Same-box sweep at (256, n, 768), persistent vs one tile per workgroup (tools/mixedp_sweep.py, profiles/r02_mixedp_sweep.log):
+// 3000 1.511 vs 1.649 ms, 2560 1.268 vs 1.386, 2400 1.207 vs 1.343; no gain at 3072 (1.599 both), 3600 (1.961 vs 1.917) and 3840 (1.974 vs
+// 1.958) — those keep kernel_regtile_mixed.h.
+SFFT_DEFINE_MIXEDP_LAUNCHER(60, 50, 24)
+SFFT_DEFINE_MIXEDP_LAUNCHER(64, 40, 20)
+SFFT_DEFINE_MIXEDP_LAUNCHER(60, 40, 24)
+}  // namespace sfft

@@ -228,6 +228,19 @@ def test_n3000_persistent_matches_oracle(B, Nin, D, G):
     assert_close(y.cpu().numpy(), spectral_mix_numpy(V.cpu().numpy(), gate.cpu().numpy(), None, n), what=f"n3000 ({B},{Nin},{D})")
 
 
+@pytest.mark.parametrize("n", [2560, 2400])
+@pytest.mark.parametrize("B,dN,D,G", [(1, 0, 16, 1), (5, 0, 80, 5), (37, 0, 112, 7), (3, -100, 64, 2), (2, 333, 32, 2)])
+def test_other_persistent_mixed_lengths_match_oracle(n, B, dN, D, G):
+    from fft_amd import describe, spectral_mix
+    torch.manual_seed(n + B + D)
+    V = torch.randn(B, n + dN, D, device=DEV)
+    gate = torch.randn(B, G, n // 2 + 1, dtype=torch.complex64, device=DEV) * 0.3
+    assert describe(V, gate, None, n).startswith("regtile-mixed-pipelined")
+    y = spectral_mix(V, gate, None, n)
+    torch.cuda.synchronize()
+    assert_close(y.cpu().numpy(), spectral_mix_numpy(V.cpu().numpy(), gate.cpu().numpy(), None, n), what=f"n={n} ({B},{n + dN},{D})")
+
+
 def test_n3000_persistent_many_tiles_guard_rows_and_repeatability():
     """Headline width with several tiles per workgroup; rows beyond N_out stay untouched; two launches are bit-identical; agreement with
     the one-tile-per-workgroup kernel it replaces (algo="stockham" is a third implementation) on whole tensors, oracle on columns."""
