@@ -56,32 +56,32 @@ __global__ void __launch_bounds__(512) spectre_gate_grad_regtile_long(const Gate
     const int cl = PC * jt + pa;                     // channel inside the group
     bool cok = true;
     if constexpr (GENERAL) cok = cl < a.d_g;
-    const int c = g * a.d_g + (cok ? cl : 0);
 
     float2 z[64];
     {
-      const char* vb = reinterpret_cast<const char*>(a.v) + ((size_t)b * a.v_sb + c) * ES;
-      const char* db = reinterpret_cast<const char*>(a.dout) + ((size_t)b * a.dout_sb + c) * ES;
-      const uint32_t voff = (uint32_t)((long long)n2 * a.v_sn * ES), doff = (uint32_t)((long long)n2 * a.dout_sn * ES);
+      // buffer loads (kernel_regtile_grad.h): workgroup-uniform tile base + a 32-bit lane offset; GENERAL: rows >= N_in and the lanes of
+      // a ragged last tile are the out-of-range case (0 = rfft's zero padding) — no predicates, no 64-bit address arithmetic
+      const int c0 = g * a.d_g + PC * jt;
+      const int nrow = a.N_in < N ? a.N_in : N;
+      const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<char*>(reinterpret_cast<const char*>(a.v)) + ((size_t)b * a.v_sb + c0) * ES, 0, GENERAL ? (int)((long long)nrow * a.v_sn * ES) : 0x7fffffff, kRsrcFlags);
+      const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<char*>(reinterpret_cast<const char*>(a.dout)) + ((size_t)b * a.dout_sb + c0) * ES, 0, GENERAL ? (int)((long long)nrow * a.dout_sn * ES) : 0x7fffffff, kRsrcFlags);
+      uint32_t voff = (uint32_t)(((long long)n2 * a.v_sn + pa) * ES), doff = (uint32_t)(((long long)n2 * a.dout_sn + pa) * ES);
+      if constexpr (GENERAL) { if (!cok) { voff = 0x80000000u; doff = 0x80000000u; } }
       static_for<0, RF>([&](auto ic) {
         constexpr int q = (decltype(ic)::value / RAF) + RBF * (decltype(ic)::value % RAF);
-        const char* pv = vb + (size_t)q * RS * a.v_sn * ES + voff;
-        const char* pd = db + (size_t)q * RS * a.dout_sn * ES + doff;
-        bool ok = true;
-        if constexpr (GENERAL) {
-          ok = cok && (n2 + RS * q) < a.N_in;
-          pv = ok ? pv : vb;
-          pd = ok ? pd : db;
-        }
+        uint32_t vo = voff, dof = doff, vs = (uint32_t)((long long)q * RS * a.v_sn * ES), ds = (uint32_t)((long long)q * RS * a.dout_sn * ES);
+        if constexpr (GENERAL) { vo += vs; dof += ds; vs = 0; ds = 0; }   // the range check covers the VGPR offset only
         float x, dy;
         if constexpr (IO_BF16) {
-          x = __uint_as_float((uint32_t)(*reinterpret_cast<const uint16_t*>(pv)) << 16);
-          dy = __uint_as_float((uint32_t)(*reinterpret_cast<const uint16_t*>(pd)) << 16);
+          x = __uint_as_float((uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rv, vo, vs, 0) << 16);
+          dy = __uint_as_float((uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rd, dof, ds, 0) << 16);
         } else {
-          x = *reinterpret_cast<const float*>(pv);
-          dy = *reinterpret_cast<const float*>(pd);
+          x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rv, vo, vs, 0));
+          dy = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, dof, ds, 0));
         }
-        z[q] = ok ? make_float2(x, dy) : make_float2(0.f, 0.f);
+        z[q] = make_float2(x, dy);
       });
       fft_ct<RF, false, IdentityMap, 64>(z);
       float2 wa[RAF], wb[RBF];
