@@ -75,28 +75,34 @@ __global__ void __launch_bounds__(512) spectre_mix_regtile_long(const RegtileArg
   {
     const char* vb = reinterpret_cast<const char*>(a.v) + ((size_t)b * a.v_sb + (size_t)ct * (2 * PC)) * ES_IN;
     const uint32_t voff = (uint32_t)(((long long)n2 * a.v_sn + 2 * pa) * ES_IN);
+    // general modes: rows >= N_in and the lanes of a ragged last tile are the out-of-range case of the buffer instructions
+    // (kernel_regtile.h): loads return rfft's zero padding, stores are dropped — no predicates, no pointer selects
+    [[maybe_unused]] __amdgpu_buffer_rsrc_t rs_in;
+    [[maybe_unused]] uint32_t voff_c = voff;
+    if constexpr (GENERAL) {
+      const int nrow = a.N_in < N ? a.N_in : N;
+      rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(vb), 0, (int)((long long)nrow * a.v_sn * ES_IN), kRsrcFlags);
+      voff_c = ca_ok ? voff : 0x80000000u;
+    }
     static_for<0, RF>([&](auto ic) {
       constexpr int q = (decltype(ic)::value / RAF) + RBF * (decltype(ic)::value % RAF);
-      const char* ptr = vb + (size_t)q * RS * a.v_sn * ES_IN + voff;
-      bool ok = true;
-      if constexpr (GENERAL) {                       // uniform base + 32-bit lane offset (one address register per load, not two)
-        ok = ca_ok && (n2 + RS * q) < a.N_in;
-        ptr = vb + (ok ? (uint32_t)((uint32_t)(q * RS) * (uint32_t)a.v_sn * ES_IN + voff) : 0u);
-      }
-      float2 val;
-      if constexpr (IN_BF16) {
-        const uint32_t wv = *reinterpret_cast<const uint32_t*>(ptr);
-        val = make_float2(__uint_as_float(wv << 16), __uint_as_float(wv & 0xffff0000u));
-      } else {
-        val = *reinterpret_cast<const float2*>(ptr);
-      }
       if constexpr (GENERAL) {
-        // rows beyond N_in read as zero: AND with an all-ones / zero mask, not `ok ? val : 0` — a select whose only other
-        // operand is a load gets turned into a branch around the load (64 branches, values parked in scratch)
-        const uint32_t keep = ok ? 0xffffffffu : 0u;
-        z[q] = make_float2(__uint_as_float(__float_as_uint(val.x) & keep), __uint_as_float(__float_as_uint(val.y) & keep));
+        const uint32_t off = voff_c + (uint32_t)((long long)q * RS * a.v_sn * ES_IN);
+        if constexpr (IN_BF16) {
+          const uint32_t wv = __builtin_amdgcn_raw_buffer_load_b32(rs_in, off, 0, 0);
+          z[q] = make_float2(__uint_as_float(wv << 16), __uint_as_float(wv & 0xffff0000u));
+        } else {
+          const rt_u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs_in, off, 0, 0);
+          z[q] = make_float2(__uint_as_float(t.x), __uint_as_float(t.y));
+        }
       } else {
-        z[q] = val;
+        const char* ptr = vb + (size_t)q * RS * a.v_sn * ES_IN + voff;
+        if constexpr (IN_BF16) {
+          const uint32_t wv = *reinterpret_cast<const uint32_t*>(ptr);
+          z[q] = make_float2(__uint_as_float(wv << 16), __uint_as_float(wv & 0xffff0000u));
+        } else {
+          z[q] = *reinterpret_cast<const float2*>(ptr);
+        }
       }
     });
     fft_ct<RF, false, IdentityMap, 64>(z);             // k1 at position out_pos<RF>(k1)
@@ -202,14 +208,26 @@ __global__ void __launch_bounds__(512) spectre_mix_regtile_long(const RegtileArg
     fft_ct<RF, true, IdentityMap, 64>(z);              // n1 at position out_pos<RF>(n1)
     char* ob = reinterpret_cast<char*>(a.out) + ((size_t)b * a.out_sb + (size_t)ct * (2 * PC)) * ES_OUT;
     const uint32_t ooff = (uint32_t)(((long long)n2 * a.out_sn + 2 * pa) * ES_OUT);
-    int n_rows = a.N_in, n2s = n2;                      // opaque copies: otherwise the 64 row indices / predicates of the load phase
-    asm volatile("" : "+s"(n_rows), "+v"(n2s));        // are kept alive (in scratch) across the whole kernel to be reused here
+    [[maybe_unused]] __amdgpu_buffer_rsrc_t rs_out;
+    [[maybe_unused]] uint32_t ooff_c = ooff;
+    if constexpr (GENERAL) {
+      const int nrow = a.N_in < N ? a.N_in : N;              // spectre.py:553 keeps rows < min(N, n_fft)
+      rs_out = __builtin_amdgcn_make_buffer_rsrc(ob, 0, (int)((long long)nrow * a.out_sn * ES_OUT), kRsrcFlags);
+      ooff_c = ca_ok ? ooff : 0x80000000u;
+    }
     static_for<0, RF>([&](auto nc) {
       constexpr int n1 = decltype(nc)::value, j = out_pos<RF>(n1);
-      char* ptr = ob + (size_t)n1 * RS * a.out_sn * ES_OUT + ooff;
-      bool ok = true;
-      if constexpr (GENERAL) ok = ca_ok && (n2s + RS * n1) < n_rows;
-      if (ok) {
+      if constexpr (GENERAL) {
+        const uint32_t off = ooff_c + (uint32_t)((long long)n1 * RS * a.out_sn * ES_OUT);
+        if constexpr (OUT_BF16) {
+          __builtin_amdgcn_raw_buffer_store_b32(f32_to_bf16_rne(z[j].x) | (f32_to_bf16_rne(z[j].y) << 16), rs_out, off, 0, 0);
+        } else {
+          rt_u32x2 t;
+          t.x = __float_as_uint(z[j].x); t.y = __float_as_uint(z[j].y);
+          __builtin_amdgcn_raw_buffer_store_b64(t, rs_out, off, 0, 0);
+        }
+      } else {
+        char* ptr = ob + (size_t)n1 * RS * a.out_sn * ES_OUT + ooff;
         if constexpr (OUT_BF16) *reinterpret_cast<uint32_t*>(ptr) = f32_to_bf16_rne(z[j].x) | (f32_to_bf16_rne(z[j].y) << 16);
         else *reinterpret_cast<float2*>(ptr) = z[j];
       }

@@ -328,7 +328,7 @@ int choose(const SpectreMixArgs* a, const Plan* plan, Choice* c) {
   else if (a->v_sn * 255 * 4 + 64 >= ((int64_t)1 << 31) || a->out_sn * 255 * 4 + 64 >= ((int64_t)1 << 31)) why = "row stride too large";
   else if (ts->tile_ch == 16 && (n * a->v_sn * es_in >= ((int64_t)1 << 31) || n * a->out_sn * es_out >= ((int64_t)1 << 31)))
     why = "row stride too large for the 32-bit buffer offsets of the register-tile kernels";
-  else if (ts->tile_ch < 16 && (a->v_sn * (n - 1) * es_in + 64 >= ((int64_t)1 << 32) || a->out_sn * (n - 1) * es_out + 64 >= ((int64_t)1 << 32)))
+  else if (ts->tile_ch < 16 && (a->v_sn * n * es_in + 64 >= ((int64_t)1 << 31) || a->out_sn * n * es_out + 64 >= ((int64_t)1 << 31)))
     why = "row stride too large for the 32-bit row offsets of the lane-pair / lane-quad kernels";
   else if (a->B * ((D + 3) / 4) >= ((int64_t)1 << 31)) why = "too many tiles";
   c->why_not_regtile = why;
