@@ -46,6 +46,13 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm under /opt/rocm)")
 
 
+# Translation units whose kernels read LDS-DMA landing slots behind a hand-counted `s_waitcnt vmcnt(N)`: tools/isa_lint.py recounts N in
+# the emitted ISA after every (re)compile and the build FAILS on a mismatch (a compiler that splits, merges or reorders one of those
+# memory instructions would otherwise turn the wait into a silent race).
+LINTED = {"regtile_n4096p.hip": "regtile64p"}
+LINT = os.path.normpath(os.path.join(HERE, "..", "tools", "isa_lint.py"))
+
+
 def _newest(paths):
     return max(os.path.getmtime(p) for p in paths)
 
@@ -77,6 +84,14 @@ def build(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
         if verbose and r.stderr.strip():
             print(r.stderr, file=sys.stderr)
+        if src in LINTED:
+            lint = subprocess.run([sys.executable, LINT, os.path.join(CSRC, src), "--kernel", LINTED[src], "--flags", " ".join(CXXFLAGS)],
+                                  capture_output=True, text=True, env={**os.environ, "HIPCC": cc})
+            if verbose:
+                print(lint.stdout, end="", flush=True)
+            if lint.returncode != 0:
+                os.unlink(obj)                       # do not leave an object behind that the next build would take as up to date
+                raise RuntimeError(f"ISA lint failed for {src}:\n{lint.stdout}\n{lint.stderr}")
         return obj
 
     # heaviest translation units first (64-point kernels), so the long poles do not start last

@@ -55,11 +55,8 @@ struct RegtileArgs {
   int tpw;              // tiles per workgroup (>= 1)
   int n_wg;             // workgroups launched = 2 * ceil(n_tiles / (2 * tpw))
   int conj_gate;        // 1: filter with conj(gate) — the adjoint w.r.t. v (dV = mix(dOut, conj(gate)))
-  unsigned long long* trace;   // tools/trace_bench.hip only (ABL bit4): 8 words per workgroup, nullptr in the library
-  int stagger_ticks, stagger_classes, stagger_first;   // first-generation phase stagger (100 MHz ticks per class), see kernel
-  unsigned* sem; int sem_k;    // load-admission semaphore per XCD (ABL bit7): [x*64] tickets issued, [x*64+32] loads completed
-  int pf_dist;                 // ABL bit8: touch the 64-B row segments of tile + pf_dist (the tile a CU of this XCD loads one generation later)
-  unsigned* gang_cnt;          // kernel_regtile64p.h ABL bit5 (tools/p64_ab_bench.hip): zeroed rendezvous counters, 4 words per wave pair
+  int rows_in, rows_out;   // kernel_regtile64p.h: input rows that exist (min(N_in, n_fft); the rest is rfft's zero padding) and output rows
+                           // that are written (spectre.py:553) = the extents of its buffer resources
 };
 
 constexpr int kPC = 8;                       // pair-columns per tile: 16 channels, 64-byte fp32 row segments
@@ -208,42 +205,10 @@ __device__ __forceinline__ void exchange_planes_b128_w2(float2 (&z)[E], float* i
 // MODE 1 (general): row predicates, any even d_g (gate read from global memory).  MODE 2: general + memory_fft.
 // MODE 3: row predicates only (N_in < n_fft, the padded-sequence case) with the gate still staged in LDS.
 // MODE 4: MODE 3 + memory_fft.
-// ABL (ablation switches, tools/ablate_bench.hip only; 0 in the library): bit0 = no global loads/stores,
-// bit1 = no butterflies/twiddles/gate, bit2 = no LDS exchanges, bit3 = constant gate, bit4 = per-workgroup phase
-// timestamps (s_memrealtime, 100 MHz) into a.trace, bit5 = additionally wait for the stores' acknowledgement.
-template <int RF, int RS, bool IN_BF16, bool OUT_BF16, int MODE, int ABL = 0, int XV = SFFT_EXCHANGE_B128(RF, RS)>
+template <int RF, int RS, bool IN_BF16, bool OUT_BF16, int MODE, int XV = SFFT_EXCHANGE_B128(RF, RS)>
 __global__ void __launch_bounds__(kPC * RS, 2)   // at least two waves per SIMD (VGPR + AGPR budget 256): two 64x32 workgroups per CU
 spectre_mix_regtile(const RegtileArgs a) {
   constexpr bool GENERAL = MODE != 0, WITH_MEM = MODE == 2 || MODE == 4, GATE_LDS = MODE == 0 || MODE == 3 || MODE == 4;
-  constexpr bool NO_IO = (ABL & 1) != 0, NO_MATH = (ABL & 2) != 0, NO_LDS = (ABL & 4) != 0, NO_GATE = (ABL & 8) != 0;
-  constexpr bool TRACE = (ABL & 16) != 0, TRACE_ACK = (ABL & 32) != 0;
-  [[maybe_unused]] auto stamp = [&](int slot) {
-    if constexpr (TRACE) { if (threadIdx.x == 0) a.trace[(size_t)blockIdx.x * 8 + slot] = wall_clock64(); }
-  };
-  if constexpr (TRACE) {
-    if (threadIdx.x == 0) {
-      uint32_t hw, xcc;
-      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-      a.trace[(size_t)blockIdx.x * 8 + 7] = ((unsigned long long)xcc << 32) | hw;
-    }
-  }
-  if constexpr ((ABL & 64) != 0) {   // de-synchronise the first generation of workgroups (pairs of neighbouring tiles keep one phase)
-    if ((int)blockIdx.x < a.stagger_first) {
-      const int cls = ((blockIdx.x / 8) / 2) % a.stagger_classes;
-      const unsigned long long t0 = wall_clock64(), wait = (unsigned long long)cls * a.stagger_ticks;
-      while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(8);
-    }
-  }
-  if constexpr ((ABL & 128) != 0) {   // at most sem_k workgroups per XCD in their load phase, admitted in ticket order
-    if (threadIdx.x == 0) {              // [0] tickets issued (workgroups), [32] waves whose loads have landed
-      unsigned* sem = a.sem + (blockIdx.x % 8) * 64;
-      const unsigned ticket = __hip_atomic_fetch_add(&sem[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      while ((int)(ticket * 8u - __hip_atomic_load(&sem[32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= a.sem_k * 8) __builtin_amdgcn_s_sleep(8);
-    }
-    __syncthreads();
-  }
-  stamp(0);
   static_assert(RF == RS || RF == 2 * RS, "n_fft = RS*RS or 2*RS*RS");
   constexpr int N = RF * RS, NS = RF / RS;                  // NS sets of RS values per thread in the middle phase
   constexpr int RAF = FftCfg<RF>::RA, RBF = FftCfg<RF>::RB; // RF-point transforms (F1, I2)
@@ -323,9 +288,7 @@ spectre_mix_regtile(const RegtileArgs a) {
       // issue order = order of use: stage 1 of F1 works on {q0 + RBF*q1}, q0 = 0, 1, ..., so its first butterflies
       // start while the tail of the tile is still in flight
       constexpr int q = (decltype(ic)::value / RAF) + RBF * (decltype(ic)::value % RAF);
-      if constexpr (NO_IO) {
-        z[q] = make_float2(1.0f + q + u, 0.5f * p - q);
-      } else if constexpr (GENERAL) {
+      if constexpr (GENERAL) {
         const uint32_t off = voff_c + (uint32_t)((long long)q * RS * v_sn * ES_IN);
         if constexpr (IN_BF16) {
           const uint32_t wv = __builtin_amdgcn_raw_buffer_load_b32(rs_in, off, 0, 0);
@@ -346,9 +309,8 @@ spectre_mix_regtile(const RegtileArgs a) {
     });
   }
 
-  if constexpr (TRACE) { stamp(1); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(2); }
   // ---- F1: RF-point forward transform over n1, then W_N^(u*k1) ---------------------------------------
-  if constexpr (!NO_MATH) {
+  {
     fftA_stage1<RAF, RBF, false>(z);
     float2 wa[RAF], wb[RBF];
     __builtin_amdgcn_sched_barrier(0);           // keep the base loads (and their registers) out of stage 1
@@ -363,7 +325,7 @@ spectre_mix_regtile(const RegtileArgs a) {
   }
 
   // ---- E1: position j (k1 = ka + RAF*kb) -> image row k1, column (u, p); thread s reads rows s + RS*t ----
-  if constexpr (!NO_LDS) {
+  {
     if constexpr (XV) {
       constexpr int PS = RS + 4, RW = kPC * PS;      // column stride, row stride (floats)
       exchange_planes_b128_w2<RF, RAS, RBS, true, RF, 1, 0, RW>(z, img, p * PS + u,
@@ -379,11 +341,10 @@ spectre_mix_regtile(const RegtileArgs a) {
     }
   }
 
-  stamp(3);
   // ---- middle: per set t (k1 = u + RS*t):  F2 stage 1, then per register group  F2 stage 2 -> gate -> I1 stage 1,
   //      then I1 stage 2.  Bin of register (ka, kb) of set t: k = k1 + RF*k2, k2 = ka + RAS*kb.  k2 >= RS/2 means
   //      k > N/2 (or k == N/2 when k1 == 0): the Hermitian extension reads conj(g[N - k]).
-  if constexpr (!NO_MATH) {
+  {
     const int cg = cvalid ? c : 0;               // lanes beyond D compute on zeros; keep their addresses in range
     const int grp = cg / a.d_g;
     const float2* gp = a.gate + ((size_t)b * a.G + grp) * a.F;
@@ -394,7 +355,6 @@ spectre_mix_regtile(const RegtileArgs a) {
       fftA_stage1<RAS, RBS, false, OFF, RF>(z);
       auto gate_index = [&](int k2) { return (k2 >= RS / 2) ? RF * (RS - k2) - k1 : k1 + RF * k2; };
       auto fetch_gate = [&](int k2, bool upper, bool edge) -> float2 {
-        if (NO_GATE) return make_float2(0.5f, 0.25f * u);
         float2 g;
         if constexpr (GATE_LDS) {
           g = glds[gate_index(k2)];                          // already scaled, edges fixed
@@ -462,7 +422,7 @@ spectre_mix_regtile(const RegtileArgs a) {
   }
 
   // ---- E2: position t*RS + n2 -> image row n2, column (k1 = u + RS*t, p); thread u reads its row, slot k1 ----
-  if constexpr (!NO_LDS) {
+  {
     if constexpr (XV) {
       constexpr int PS = RF + 4, RW = kPC * PS;
       exchange_planes_b128_w2<RF, RAF, RBF, false, RS, RF / RS, RS, RW>(z, img, p * PS + u,
@@ -476,9 +436,8 @@ spectre_mix_regtile(const RegtileArgs a) {
     }
   }
 
-  stamp(4);
   // ---- conj twiddle, I2 and store (spectre.py:553 keeps rows < min(N, n_fft)) -----------------------------
-  if constexpr (!NO_MATH) {
+  {
     float2 wa[RAF], wb[RBF];
     load_twiddle_bases(wa, wb);
     static_for<1, RF>([&](auto jc) {
@@ -502,11 +461,9 @@ spectre_mix_regtile(const RegtileArgs a) {
     static_for<0, RF>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
       // the last butterfly stage runs group by group; each group's rows are stored as soon as they exist
-      if constexpr (!NO_MATH && (j % RBF) == 0) fftA_stage2_group<RAF, RBF, true, j / RBF>(z);
+      if constexpr ((j % RBF) == 0) fftA_stage2_group<RAF, RBF, true, j / RBF>(z);
       constexpr int n1 = (j / RBF) + RAF * (j % RBF);
-      if constexpr (NO_IO) {
-        if (z[j].x == 1.2345e-30f) *reinterpret_cast<float2*>(ob + (size_t)n1 * RS * out_sn * ES_OUT + ooff) = z[j];   // keeps the math alive, never true
-      } else if constexpr (GENERAL) {
+      if constexpr (GENERAL) {
         const uint32_t off = ooff_c + (uint32_t)((long long)n1 * RS * out_sn * ES_OUT);
         if constexpr (OUT_BF16) {
           __builtin_amdgcn_raw_buffer_store_b32(f32_to_bf16_rne(z[j].x) | (f32_to_bf16_rne(z[j].y) << 16), rs_out, off, 0, 0);
@@ -525,8 +482,6 @@ spectre_mix_regtile(const RegtileArgs a) {
       }
     });
   }
-  stamp(5);
-  if constexpr (TRACE_ACK) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(6); }
   }  // tile loop
 }
 

@@ -438,6 +438,7 @@ int launch(const SpectreMixArgs* a, const Plan* plan, const Choice& c, bool conj
     k.tiles_per_row = (int)((a->D + tch - 1) / tch); k.n_tiles = (int)(a->B * ((a->D + tch - 1) / tch));
     k.v_sb = a->v_sb; k.v_sn = a->v_sn; k.out_sb = a->out_sb; k.out_sn = a->out_sn;
     k.conj_gate = conj_gate ? 1 : 0;
+    k.rows_in = k.rows_out = (int)std::min<int64_t>(a->N_in, a->n_fft);   // spectre.py:506 pads / truncates to n_fft, :553 keeps min(N, n_fft) rows
     k.tpw = tiles_per_workgroup(k.n_tiles);
     k.n_wg = 2 * ((k.n_tiles + 2 * k.tpw - 1) / (2 * k.tpw));
     const bool ib = a->in_dtype == SPECTRE_BF16, ob = a->out_dtype == SPECTRE_BF16;

@@ -1,0 +1,225 @@
+"""Build-time ISA lint for the hand-counted waits of the pipelined 4096 kernel (fft_amd/csrc/kernel_regtile64p.h).
+
+The kernel reads its LDS-DMA landing slots behind `s_waitcnt vmcnt(N)` with N = the number of VMEM instructions the wave issues
+between the last `buffer_load ... lds` of a burst and that wait (completion is in order, so "at most N outstanding" means the DMA has
+landed).  N is a constant in the source (p64_younger / p64_younger_first); this script recounts it in what hipcc actually emitted:
+
+  * compiles the translation unit to gfx950 assembly (hipcc -S --offload-device-only),
+  * builds the control-flow graph of every kernel whose name matches --kernel,
+  * finds the guards = `s_waitcnt vmcnt(N)` that come from inline asm (bracketed by ;;#ASMSTART / ;;#ASMEND),
+  * walks BACKWARDS from each guard over every path until it meets an LDS-DMA instruction, counting VMEM instructions on the way,
+  * fails (exit 1) if on any path fewer than N VMEM instructions separate the guard from the DMA (the wait would be too loose: a wave
+    could read a slot that has not landed), and reports paths with MORE than N (the wait is stricter than necessary: performance only).
+
+A guard taken in the steady state is checked against the DMA instructions inside the tile loop, the guard of the first iteration
+against the prologue's.  The source says which is which with a comment inside the asm statement (`s_waitcnt vmcnt(N) ; lint: steady` /
+`; lint: first` — the comment survives into the -S listing); an untagged pair is told apart by N (the smaller count is the prologue's).
+
+    python tools/isa_lint.py fft_amd/csrc/regtile_n4096p.hip [--kernel regtile64p] [--asm out.s] [--flags "..."]
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+DEFAULT_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize"]
+
+VMEM = re.compile(r"^(buffer_|global_|flat_|scratch_)(load|store|atomic)")
+LABEL = re.compile(r"^(\.LBB\d+_\d+):")
+KERNEL = re.compile(r"^(_Z\w+):\s*;\s*@")
+BRANCH = re.compile(r"^s_(c?branch\w*)\s+(\.LBB\d+_\d+)")
+WAIT_VM = re.compile(r"^s_waitcnt\b.*vmcnt\((\d+)\)")
+
+
+class Ins:
+    __slots__ = ("op", "text", "inline", "is_vmem", "is_dma", "guard", "tag")
+
+    def __init__(self, text, inline, comment=""):
+        self.text = text
+        mt = re.search(r"lint:\s*(first|steady)", comment)
+        self.tag = mt.group(1) if mt else None
+        self.op = text.split()[0]
+        self.inline = inline
+        self.is_vmem = bool(VMEM.match(self.op))
+        self.is_dma = self.is_vmem and text.rstrip().endswith(" lds")
+        m = WAIT_VM.match(text)
+        self.guard = int(m.group(1)) if (m and inline) else None
+
+
+def compile_asm(src, flags):
+    fd, out = tempfile.mkstemp(suffix=".s")
+    os.close(fd)
+    cmd = [HIPCC, *flags, "--offload-device-only", "-S", src, "-o", out]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc -S failed:\n{r.stderr}")
+    return out
+
+
+def parse_kernels(path):
+    """-> {kernel name: [blocks]}, block = dict(label, ins, succ (labels / 'FALL'))"""
+    kernels, cur, blocks, blk, inline = {}, None, None, None, False
+    for raw in open(path):
+        line = raw.strip()
+        mk = KERNEL.match(line)
+        if mk:
+            cur = mk.group(1)
+            blocks = kernels[cur] = []
+            blk = {"label": "ENTRY", "ins": [], "order": 0}
+            blocks.append(blk)
+            continue
+        if cur is None:
+            continue
+        if line.startswith(".Lfunc_end"):
+            cur = None
+            continue
+        if line.startswith(";;#ASMSTART"):
+            inline = True
+            continue
+        if line.startswith(";;#ASMEND"):
+            inline = False
+            continue
+        ml = LABEL.match(line)
+        if ml:
+            blk = {"label": ml.group(1), "ins": [], "order": len(blocks)}
+            blocks.append(blk)
+            continue
+        if not line or line.startswith(";") or line.startswith(".") or line.startswith("//"):
+            continue
+        code, _, comment = line.partition(";")
+        code = code.strip()
+        if not code:
+            continue
+        ins = Ins(code, inline, comment)
+        blk["ins"].append(ins)
+        if ins.op.startswith("s_cbranch") or ins.op in ("s_branch", "s_endpgm"):
+            # a branch ends the basic block; the fall-through part gets an anonymous block
+            blk = {"label": f"{blk['label']}+{len(blocks)}", "ins": [], "order": len(blocks)}
+            blocks.append(blk)
+    return kernels
+
+
+def build_cfg(blocks):
+    by_label = {b["label"]: i for i, b in enumerate(blocks)}
+    preds = [[] for _ in blocks]
+    for i, b in enumerate(blocks):
+        last = b["ins"][-1] if b["ins"] else None
+        targets = []
+        if last is not None and last.op == "s_endpgm":
+            pass
+        elif last is not None and last.op == "s_branch":
+            targets.append(by_label[BRANCH.match(last.text).group(2)])
+        else:
+            if last is not None and last.op.startswith("s_cbranch"):
+                targets.append(by_label[BRANCH.match(last.text).group(2)])
+            if i + 1 < len(blocks):
+                targets.append(i + 1)
+        for t in targets:
+            preds[t].append(i)
+    return preds
+
+
+def walk_back(blocks, preds, bi, ii):
+    """All (count, dma block order) over paths that end right before instruction ii of block bi and start behind an LDS-DMA instruction."""
+    results = []
+    best = {}          # (block, entry index) -> smallest count seen (a larger count through the same point cannot lower the minimum)
+    worst = {}
+    stack = [(bi, ii, 0)]
+    while stack:
+        b, i, cnt = stack.pop()
+        ins = blocks[b]["ins"]
+        j = i - 1
+        hit = False
+        while j >= 0:
+            x = ins[j]
+            if x.is_dma:
+                results.append((cnt, blocks[b]["order"]))
+                hit = True
+                break
+            if x.is_vmem:
+                cnt += 1
+            j -= 1
+        if hit:
+            continue
+        for pb in preds[b]:
+            key = (pb, len(blocks[pb]["ins"]))
+            lo, hi = best.get(key), worst.get(key)
+            if lo is not None and lo <= cnt and hi >= cnt:
+                continue                     # both extremes through this point are already covered
+            best[key] = cnt if lo is None else min(lo, cnt)
+            worst[key] = cnt if hi is None else max(hi, cnt)
+            if cnt > 4096:
+                raise RuntimeError("runaway path (a loop without LDS-DMA between the guard and itself)")
+            stack.append((pb, len(blocks[pb]["ins"]), cnt))
+    return results
+
+
+def lint_kernel(name, blocks, verbose=True):
+    preds = build_cfg(blocks)
+    guards = [(bi, ii, x.guard, x.tag) for bi, b in enumerate(blocks) for ii, x in enumerate(b["ins"]) if x.guard is not None]
+    dma_orders = sorted({b["order"] for b in blocks if any(x.is_dma for x in b["ins"])})
+    if not guards:
+        return [f"{name}: no inline-asm s_waitcnt vmcnt(N) found (the guard is gone?)"], []
+    if len(dma_orders) < 2:
+        return [f"{name}: expected LDS-DMA in the prologue and in the tile loop, found blocks {dma_orders}"], []
+    first_dma = dma_orders[0]            # prologue (text order)
+    errors, notes = [], []
+    values = sorted({g[2] for g in guards})
+    if len(values) == 1 and len(guards) > 1 and not all(g[3] for g in guards):
+        errors.append(f"{name}: {len(guards)} untagged guards with the same count vmcnt({values[0]}): tag them `; lint: first` / `; lint: steady`")
+    for bi, ii, n, tag in guards:
+        paths = walk_back(blocks, preds, bi, ii)
+        # steady-state guard <-> DMA of the tile loop; first-tile guard <-> DMA of the prologue
+        steady = (tag == "steady") if tag else ((n == values[-1]) if len(values) > 1 else True)
+        rel = [c for c, o in paths if (o != first_dma) == steady]
+        if not rel:
+            errors.append(f"{name}: guard vmcnt({n}) is not reachable from {'the loop' if steady else 'the prologue'} LDS-DMA")
+            continue
+        lo, hi = min(rel), max(rel)
+        kind = "steady state" if steady else "first tile"
+        if lo < n:
+            errors.append(f"{name}: guard vmcnt({n}) [{kind}] TOO LOOSE: a path has only {lo} VMEM instructions behind the last LDS-DMA")
+        notes.append(f"{name}: guard vmcnt({n}) [{kind}]: VMEM instructions behind the last LDS-DMA on any path: min {lo}, max {hi}"
+                     + ("" if hi == n else f"  (paths with more than {n}: stricter than needed, not wrong)"))
+    return errors, notes
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("source", help=".hip translation unit (or a .s file produced by hipcc -S)")
+    ap.add_argument("--kernel", default="regtile64p", help="substring of the (mangled) kernel names to check")
+    ap.add_argument("--flags", default=None, help="compiler flags (default: the library's)")
+    ap.add_argument("--quiet", action="store_true")
+    args = ap.parse_args(argv)
+    asm, tmp = args.source, None
+    if not args.source.endswith(".s"):
+        asm = tmp = compile_asm(args.source, args.flags.split() if args.flags else DEFAULT_FLAGS)
+    try:
+        kernels = {k: v for k, v in parse_kernels(asm).items() if args.kernel in k}
+    finally:
+        if tmp:
+            os.unlink(tmp)
+    if not kernels:
+        print(f"isa_lint: no kernel matching '{args.kernel}'", file=sys.stderr)
+        return 1
+    bad = 0
+    for name, blocks in kernels.items():
+        errors, notes = lint_kernel(name, blocks)
+        if not args.quiet:
+            for n in notes:
+                print("isa_lint:", n)
+        for e in errors:
+            print("isa_lint: ERROR", e, file=sys.stderr)
+        bad += len(errors)
+    if bad == 0 and not args.quiet:
+        print(f"isa_lint: {len(kernels)} kernel(s) ok")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

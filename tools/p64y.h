@@ -39,10 +39,9 @@
 //
 // The s_waitcnt vmcnt(N) that guards the LDS-DMA landing slots is counted by hand (p64_younger below); tools/isa_lint.py recounts
 // it in the ISA of every shipped instantiation at build time (fft_amd/build.py) and fails the build on a mismatch.
-#pragma once
-#include "kernel_regtile.h"
+#include "../fft_amd/csrc/kernel_regtile.h"
 
-namespace sfft {
+namespace sfft { namespace P64Y_NS {
 
 constexpr int kP64ImageBytes = regtile_image_bytes<64, 64, 1>();
 // LDS: exchange image | half-spectrum gate | the two twiddle vectors of every team index u (W^(u j), W^(8 u j), j = 1..7): 64 x 14 x 8 B.
@@ -124,8 +123,8 @@ __device__ __forceinline__ void p64_write_col(float2 (&z)[64], float* img, int p
 //   barrier | read re | barrier | write im | barrier | read im [| barrier].
 // The chunk order of the reads (slots 0-3, 8-11, ..., then 4-7, 12-15, ...) is the order in which the next stage's first butterflies
 // consume them.  LAST_BARRIER = false leaves the image busy: the caller puts the barrier in front of its next write.
-template <bool LAST_BARRIER>
-__device__ __forceinline__ void p64_exchange_rest(float2 (&z)[64], float* img, int p, int u) {
+template <bool LAST_BARRIER, class STAMP>
+__device__ __forceinline__ void p64_exchange_rest(float2 (&z)[64], float* img, int p, int u, STAMP stamp) {
   constexpr int RW = 8 * 68, PS = 68;
   const float* rd = img + u * RW + p * PS;
   auto read_plane = [&](auto is_im) {
@@ -137,10 +136,29 @@ __device__ __forceinline__ void p64_exchange_rest(float2 (&z)[64], float* img, i
     });
   };
   p64_barrier();
+  stamp(0);
   read_plane(std::false_type{});
   p64_barrier();
+  stamp(1);
+#if P64Y_FLAGS & 2
+  {
+    typedef __attribute__((address_space(3))) float lds_float;
+    lds_float* w0 = (lds_float*)(img + p * PS + u);
+    lds_float *w1 = w0 + RW, *w2 = w0 + 32 * RW, *w3 = w0 + 33 * RW;
+    asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3));
+    static_for<0, 16>([&](auto ic) {
+      constexpr int j = 4 * decltype(ic)::value, jw = j % 32;
+      lds_float* we = j < 32 ? w0 : w2;
+      lds_float* wo = j < 32 ? w1 : w3;
+      we[jw * RW] = z[j].y; we[(jw + 2) * RW] = z[j + 2].y;
+      wo[jw * RW] = z[j + 1].y; wo[(jw + 2) * RW] = z[j + 3].y;
+    });
+  }
+#else
   static_for<0, 8>([&](auto cc) { p64_write_col<decltype(cc)::value, true>(z, img, p, u); });
+#endif
   p64_barrier();
+  stamp(2);
   read_plane(std::true_type{});
   if constexpr (LAST_BARRIER) p64_barrier();       // image free again
 }
@@ -161,7 +179,7 @@ template <int SPLIT> constexpr int p64_younger_first() { return 4 * (8 - SPLIT) 
 //         (row, dword), and every lane reads its 8 bytes back out of its wave's slot).
 // OUT_BF16 = bf16 rows out (round to nearest even, like every other kernel here): a lane stores its 4 channels as 8 bytes.
 template <int SPLIT, int PF, bool WITH_MEM = false, bool IN_BF16 = false, bool OUT_BF16 = false>
-__global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileArgs a) {
+__global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const YRegtileArgs a) {
   constexpr int ESI = IN_BF16 ? 2 : 4, ESO = OUT_BF16 ? 2 : 4;   // bytes per input / output element
   constexpr float inv_n = 1.0f / 4096.0f;
   static_assert(SPLIT >= 1 && SPLIT <= 4 && SPLIT * 4 * 1024 * 8 <= kP64ImageBytes, "staging lives in the exchange image");
@@ -208,6 +226,12 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
   const int pair_base = (wg_lin / GANG) * a.tpw * GANG + (wg_lin % GANG);
   if (pair_base >= a.n_tiles) return;
 
+#if P64Y_FLAGS & 16
+  unsigned* wst = reinterpret_cast<unsigned*>(smem + kP64LdsTotal) + (tid0 >> 6) * 16;
+  auto wstamp = [&](int slot) { if ((tid0 & 63) == 0) wst[slot] = (unsigned)__builtin_amdgcn_s_memtime(); };
+#else
+  auto wstamp = [&](int) {};
+#endif
   float2 z[64];
   float4 dfr[4 * PF];                              // deferred results of the previous tile / prefetched rows of the next one
   static_for<0, 4 * PF>([&](auto ic) { dfr[decltype(ic)::value] = make_float4(0.f, 0.f, 0.f, 0.f); });   // (stored into an empty range before the first tile)
@@ -235,11 +259,19 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
   // GUARANTEED to be younger than the one waited for, so a request inside `if (more)` does not count, N comes out too small, and a wait
   // for a prefetched register early in I2 turned into a wait for the LDS-DMA issued just before it (a full HBM round trip per tile).
   auto rsrc_in = [&](const char* vb, long long sn, bool live = true) {
+#if P64Y_FLAGS & 1
+    const int rows = !live ? 0 : a.N_in < 4096 ? a.N_in : 4096;
+#else
     const int rows = live ? a.rows_in : 0;
+#endif
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(vb), 0, (int)((long long)rows * sn * ESI), kP64RsrcFlags);
   };
   auto rsrc_out = [&](char* ob, long long sn, bool live = true) {
+#if P64Y_FLAGS & 1
+    const int rows = !live ? 0 : a.N_in < 4096 ? a.N_in : 4096;
+#else
     const int rows = live ? a.rows_out : 0;
+#endif
     return __builtin_amdgcn_make_buffer_rsrc(ob, 0, (int)((long long)rows * sn * ESO), kP64RsrcFlags);
   };
   auto unpack_lo = [](uint32_t d) { return make_float2(__uint_as_float(d << 16), __uint_as_float(d & 0xffff0000u)); };   // two bf16 -> (re, im)
@@ -350,16 +382,29 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
   }
 
   for (int it = 0; it < a.tpw; ++it) {
+#if P64Y_FLAGS & 4
+    const int tile_step = a.conj_gate ? a.n_wg : GANG;
+    const int tile = pair_base + tile_step * it;
+#else
     const int tile = pair_base + GANG * it;
+#endif
     if (tile >= a.n_tiles) break;                  // workgroup-uniform
+#if P64Y_FLAGS & 4
+    const bool more = (it + 1 < a.tpw) && (tile + tile_step < a.n_tiles);
+#else
     const bool more = (it + 1 < a.tpw) && (tile + GANG < a.n_tiles);
+#endif
     coords();
     long long v_sn = a.v_sn, out_sn = a.out_sn;
     asm volatile("" : "+s"(v_sn), "+s"(out_sn));
     const char* vb; char* ob; const float2* gp;
     tile_ptrs(tile, vb, ob, gp);
     const char* vbn = vb; char* obn = ob; const float2* gpn = gp;
+#if P64Y_FLAGS & 4
+    if (more) tile_ptrs(tile + tile_step, vbn, obn, gpn);
+#else
     if (more) tile_ptrs(tile + GANG, vbn, obn, gpn);
+#endif
     const __amdgpu_buffer_rsrc_t rs_next = rsrc_in(vbn, v_sn, more), rs_out = rsrc_out(ob, out_sn);
 
     const uint32_t pf_ooff = (uint32_t)(((long long)(u + 512 * h) * out_sn + 4 * pp) * ESO);
@@ -379,6 +424,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
       }
     };
 
+    wstamp(0);
     // ---- F1: 64-point forward transform over n1 (register position 8g + e holds row g + 8e), then W_N^(u*k1) ------------
     //      Stage 1 works group by group, in the order the groups arrive: the deferred groups (prefetched a tile ago) first, then the
     //      LDS-staged ones — only now does the wave wait for the LDS-DMA of the burst it has just left — and the groups reloaded
@@ -389,8 +435,8 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
       if constexpr (i == PF) {
         // the tile arrives: completion is in order, so once everything but the requests younger than the last LDS-DMA has retired the
         // staged groups are in the slots (p64_younger; checked against the ISA by tools/isa_lint.py)
-        if (it == 0) asm volatile("s_waitcnt vmcnt(%0) ; lint: first" :: "n"(p64_younger_first<SPLIT>()) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0) ; lint: steady" :: "n"(p64_younger<SPLIT, PF>()) : "memory");
+        if (it == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(p64_younger_first<SPLIT>()) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(p64_younger<SPLIT, PF>()) : "memory");
         static_for<0, SPLIT>([&](auto gc) { read_group(gc); });
       }
       swap_group(std::integral_constant<int, g>{});
@@ -399,6 +445,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
       pin8<8 * g, 1>(z);
       __builtin_amdgcn_sched_barrier(0);
     });
+    wstamp(1);
     {
       float2 wa[8], wb[8];
       __builtin_amdgcn_sched_barrier(0);           // keep the base loads (and their registers) out of stage 1
@@ -434,7 +481,9 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
     __builtin_amdgcn_sched_barrier(0);
     // ---- E1: position k1 -> image row k1, column (p, u); thread (p, s = u) reads row u, slot n2.  No barrier behind the last read:
     //      the image stays busy until the barrier in front of the middle phase's last stage.
-    p64_exchange_rest<false>(z, img, p, u);
+    wstamp(2);
+    p64_exchange_rest<false>(z, img, p, u, [&](int k) { wstamp(3 + k); });
+    wstamp(6);
 
     // ---- middle: F2 -> gate -> I1 (kernel_regtile.h; bin of register (ka, kb): k = k1 + 64 k2, k2 = ka + 8 kb) -------------
     {
@@ -491,6 +540,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
       });
       // type B stage 2: radix-8 over ka (positions 8 ka + n_lo) -> natural order, position n2 = n_lo + 8 n_hi.  Every wave has long
       // finished E1's reads; behind this barrier the image is written again, column by column like in F1.
+      wstamp(7);
       p64_barrier();
       static_for<0, 8>([&](auto nc) {
         constexpr int nlo = decltype(nc)::value;
@@ -504,7 +554,9 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
 
     // ---- E2: position n2 -> image row n2, column (p, k1 = u); thread (p, u) reads row u, slot k1.  The barrier behind the last read
     //      frees the image for the LDS-DMA below.
-    p64_exchange_rest<true>(z, img, p, u);
+    wstamp(8);
+    p64_exchange_rest<true>(z, img, p, u, [&](int k) { wstamp(9 + k); });
+    wstamp(12);
 
     // ---- the image is idle until the next F1: let the first row groups of the next tile land in it, and fetch its gate -----
     const uint32_t voff = (uint32_t)(((long long)(u + 512 * h) * v_sn + 4 * pp) * ESI);
@@ -515,6 +567,10 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     static_for<0, SPLIT>([&](auto gc) { dma_group(rs_next, dma_voff(voff, v_sn), v_sn, gc); });
     asm volatile("" ::: "memory");                 // the vmcnt() at the top of the loop counts on these being older than every store below
+#if P64Y_FLAGS & 8
+    asm volatile("" ::: "memory");
+    { float2 (&wa2)[8] = wa; (void)wa2; }
+#endif
 
     // ---- conj twiddle, I2, stores (spectre.py:553) interleaved with the loads that refill the released registers -----------
     static_for<1, 64>([&](auto jc) {
@@ -525,6 +581,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
     });
     __builtin_amdgcn_sched_barrier(0);
     p64_stageA1<true>(z);
+    wstamp(13);
     {
       const uint32_t ooff = (uint32_t)(((long long)(u + 512 * h) * out_sn + 4 * pp) * ESO);
       static_for<0, 8>([&](auto ic) {
@@ -559,9 +616,11 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
     }
     obp = ob;
     gate_fetch(gpn);     // committed to LDS at the end of the next tile's F1 (after the last tile: a harmless re-read of this tile's bins)
+    wstamp(14);
+#if P64Y_FLAGS & 16
+    a.trace32[(((size_t)blockIdx.x * a.tpw + it) * 8 + (tid0 >> 6)) * 16 + (tid0 & 15)] = wst[tid0 & 15];
+#endif
   }  // tile loop
 }
 
-hipError_t launch_regtile64p(const RegtileArgs& a, bool in_bf16, bool out_bf16, hipStream_t stream);
-
-}  // namespace sfft
+} }  // namespace sfft::P64Y_NS

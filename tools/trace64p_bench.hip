@@ -7,26 +7,26 @@
 #include <cmath>
 #include <algorithm>
 #include <cstdint>
-#include "../fft_amd/csrc/kernel_regtile64p.h"
+#include "p64x.h"   // the round-2 kernel with its experiment switches (frozen copy; the library header no longer has them)
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 using namespace sfft;
 static double pct(std::vector<double> v, double p) { if (v.empty()) return 0; std::sort(v.begin(), v.end()); return v[(size_t)(p * (v.size() - 1))]; }
 
 template <int SPLIT, int PF = 0, bool FEN = (PF > 0), int ABLX = 0>
-void run(const char* name, RegtileArgs a, int tpw) {
-  auto kern = spectre_mix_regtile64p<SPLIT, PF, 16 | ABLX, FEN>;
+void run(const char* name, XRegtileArgs a, int tpw) {
+  auto kern = spectre_mix_p64x<SPLIT, PF, 16 | ABLX, FEN>;
   a.tiles_per_row = a.D / 16; a.n_tiles = a.B * a.tiles_per_row;
   a.tpw = tpw; a.n_wg = 2 * ((a.n_tiles + 2 * tpw - 1) / (2 * tpw));
   unsigned long long* tr;
   const size_t nrec = (size_t)a.n_wg * tpw;
   CK(hipMalloc(&tr, nrec * 64)); CK(hipMemset(tr, 0, nrec * 64));
   a.trace = tr;
-  CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kP64LdsTotal));
+  CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, xkP64LdsTotal));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, dim3(a.n_wg), dim3(512), kP64LdsTotal, 0, a);
+  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, dim3(a.n_wg), dim3(512), xkP64LdsTotal, 0, a);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
-  hipLaunchKernelGGL(kern, dim3(a.n_wg), dim3(512), kP64LdsTotal, 0, a);
+  hipLaunchKernelGGL(kern, dim3(a.n_wg), dim3(512), xkP64LdsTotal, 0, a);
   CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   std::vector<unsigned long long> h(nrec * 8);
@@ -73,7 +73,7 @@ int main() {
   std::vector<float2> h(N);
   for (int m = 0; m < N; ++m) h[m] = make_float2((float)cos(2 * M_PI * m / N), (float)-sin(2 * M_PI * m / N));
   CK(hipMemcpy(tw, h.data(), N * 8, hipMemcpyHostToDevice));
-  RegtileArgs a{};
+  XRegtileArgs a{};
   a.v = v; a.gate = gate; a.mem = nullptr; a.out = out; a.tw = tw;
   a.B = B; a.N_in = N; a.D = D; a.G = G; a.d_g = D / G; a.F = F;
   a.v_sb = (long long)N * D; a.v_sn = D; a.out_sb = (long long)N * D; a.out_sn = D;
