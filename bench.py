@@ -83,6 +83,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--prewarm", type=int, default=60,
+                    help="untimed launches BEFORE the --warmup steps: the chip needs ~25 back-to-back launches (40 ms) to leave its idle "
+                         "power state (tools/ramp_time.py, profiles/r03_ramp_time.log); reported as `prewarm_steps`")
     ap.add_argument("--io", choices=["f32", "bf16"], default="f32",
                     help="storage dtype of V and out (arithmetic is always fp32; the reference is fp32-only)")
     ap.add_argument("--shape", default="256,4096,768", help="per-GPU B,N,D")
@@ -149,6 +152,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    for _ in range(max(0, a.prewarm)):                        # power-state ramp (untimed; the contract's warmup steps follow)
+        step()
     for _ in range(a.warmup):
         step()
     barrier()
@@ -169,8 +174,30 @@ def main():
     # other storage dtypes of the same workload, same run (informational; `value` above is the --io default).
     # BASELINE.json configs[2] words the headline shape as "bf16 in / fp32 compute": both readings are reported.
     variants = {}
+    ceilings = {}
     if world == 1:
-        from fft_amd import time_kernel
+        from fft_amd import copy_probe, time_kernel
+        # what a PURE COPY of the same bytes reaches on this device, in this process (C ABI spectre_probe_copy, fft_amd/csrc/copy_probe.hip):
+        #   dense_copy   = 256-KiB contiguous chunks, 16 bytes per lane
+        #   pattern_copy = 128-byte row segments of 4096 consecutive rows at the tensor's row stride: what the product kernel presents to
+        #                  the memory system once the two workgroups of a pair have merged their 64-byte halves in the L2 (PMC: all reads
+        #                  leave the L2 as 128-byte requests, 1.06 write-backs per line) — the ceiling of its access pattern
+        #   half_line_copy = the same with free-running 64-byte (fp32) / 32-byte (bf16) segments per workgroup, neighbours on the other pieces
+        #                  of the lines: what the pattern costs when NOTHING keeps the neighbours together (the product beats it)
+        if V.is_contiguous() and (B * N * D * V.element_size()) % (256 * 1024) == 0 and N % 4096 == 0:
+            seg = 16 * V.element_size()
+            byt = 2.0 * B * N * D * V.element_size()
+            for name, sg, md in (("dense_copy", 0, "copy"), ("pattern_copy", 128, "copy"), ("half_line_copy", seg, "copy"),
+                                 ("pattern_load_only", 128, "load"), ("pattern_store_only", 128, "store"), ("dense_load_only", 0, "load")):
+                best = None
+                for per_cu in (1, 2, 4):                                  # persistent workgroups per CU: report the best of three
+                    ms = copy_probe(V, out, sg, mode=md, wgs_per_cu=per_cu, warmup=3, iters=max(5, a.steps // 2))
+                    best = ms if best is None or ms < best else best
+                nb = byt if md == "copy" else byt / 2
+                ceilings[name + "_GBps"] = nb / best / 1e6
+                ceilings[name + "_ms"] = best
+            for _ in range(10):
+                step()                                                    # (the probes overwrote `out`; leave a valid result behind)
         for name, tin, tout in (("bf16_in_bf16_out", torch.bfloat16, torch.bfloat16), ("bf16_in_f32_out", torch.bfloat16, torch.float32),
                                 ("f32_in_f32_out", torch.float32, torch.float32)):
             if (tin == dt and tout == dt):
@@ -244,7 +271,16 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": alg, "kernel_ms": kern_ms},
+            "prewarm_steps": max(0, a.prewarm),
         }
+        if ceilings:
+            res["roofline"].update(ceilings)
+            res["roofline"]["frac_of_pattern_copy"] = achieved / ceilings["pattern_copy_GBps"]
+            res["roofline"]["frac_of_dense_copy"] = achieved / ceilings["dense_copy_GBps"]
+            res["roofline"]["ceilings_note"] = ("pure copies of this launch's V -> out bytes measured in this process through the C ABI "
+                                                "(spectre_probe_copy): dense = contiguous 16 B per lane; pattern = 128-byte row segments of 4096 rows "
+                                                "at the row stride (the product's 64-byte halves merged per pair of workgroups); half_line = free-running "
+                                                "64-byte (fp32) segments; best of 1 / 2 / 4 persistent workgroups per CU")
         if variants:
             res["variants"] = variants
         if world == 1 and not a.no_cpu_baseline:

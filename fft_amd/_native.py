@@ -14,7 +14,7 @@ import torch  # noqa: F401  — must be imported first: the library binds to the
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPECTRE_HIP_LIB") or os.path.join(_HERE, "lib", "libspectre_hip.so")   # env: A/B builds
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 F32, BF16 = 0, 1
 ALGO = {"auto": 0, "stockham": 1, "regtile": 2}
 
@@ -22,7 +22,7 @@ ALGO = {"auto": 0, "stockham": 1, "regtile": 2}
 EXPORTS = ("spectre_version", "spectre_last_error", "spectre_mix_fwd", "spectre_mix_describe",
            "spectre_plan_create", "spectre_plan_destroy", "spectre_mix_time", "spectre_mix_bwd",
            "spectre_mix_bwd_workspace_bytes", "spectre_gate_fwd", "spectre_gate_bwd", "spectre_rfft_fwd", "spectre_decode_workspace_bytes",
-           "spectre_decode_step", "spectre_decode_head_workspace_bytes", "spectre_decode_head_step")
+           "spectre_decode_step", "spectre_decode_head_workspace_bytes", "spectre_decode_head_step", "spectre_probe_copy")
 
 
 class SpectreMixArgs(ctypes.Structure):
@@ -95,6 +95,14 @@ class SpectreMixBwdArgs(ctypes.Structure):
     ]
 
 
+class SpectreProbeArgs(ctypes.Structure):
+    _fields_ = [
+        ("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("rows", ctypes.c_int64), ("row_bytes", ctypes.c_int64),
+        ("seg_bytes", ctypes.c_int32), ("tile_rows", ctypes.c_int32), ("mode", ctypes.c_int32), ("wgs_per_cu", ctypes.c_int32),
+        ("device", ctypes.c_int32), ("stream", ctypes.c_void_p),
+    ]
+
+
 _lib = None
 _lock = threading.Lock()
 
@@ -150,6 +158,8 @@ def load():
         lib.spectre_decode_head_workspace_bytes.restype = ctypes.c_int64
         lib.spectre_decode_head_step.argtypes = [ctypes.POINTER(SpectreDecodeHeadArgs)]
         lib.spectre_decode_head_step.restype = ctypes.c_int
+        lib.spectre_probe_copy.argtypes = [ctypes.POINTER(SpectreProbeArgs), ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
+        lib.spectre_probe_copy.restype = ctypes.c_int
         ver = lib.spectre_version()
         if ver != ABI_VERSION:
             raise NativeLibraryError(f"ABI mismatch: library {ver}, binding {ABI_VERSION}")

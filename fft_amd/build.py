@@ -19,7 +19,7 @@ LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libspectre_hip.so")
 
-SOURCES = ["spectre_hip.hip", "regtile_n4096.hip", "regtile_n4096p.hip", "regtile_n2048.hip", "regtile_n1024.hip", "regtile_n512.hip",
+SOURCES = ["spectre_hip.hip", "copy_probe.hip", "regtile_n4096.hip", "regtile_n4096p.hip", "regtile_n2048.hip", "regtile_n1024.hip", "regtile_n512.hip",
            "regtile_n256.hip", "regtile_n3000.hip", "regtile_mixedp.hip", "regtile_n768.hip", "regtile_n1536.hip",
            "regtile_n3072.hip", "regtile_n1000.hip", "regtile_n2000.hip", "regtile_n1280.hip", "regtile_n2560.hip", "regtile_n3840.hip",
            "regtile_mixed_small.hip", "regtile_mixed_mid.hip", "regtile_mixed_mid2.hip", "regtile_n2400.hip", "regtile_n3600.hip", "regtile_n8192.hip", "regtile_n6144.hip", "regtile_n16384.hip", "regtile_n12288.hip"]

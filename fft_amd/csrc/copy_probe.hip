@@ -1,0 +1,112 @@
+// copy_probe.hip — pure-copy probes behind the C ABI (spectre_probe_copy): what does the memory system of THIS box deliver to a kernel
+// that moves the spectral mix's bytes and does nothing else?  bench.py runs them next to the product kernel so that the ceiling the
+// product is compared with is measured in the same process, on the same device, by the driver (roofline.dense_copy_GBps /
+// roofline.pattern_copy_GBps).  No arithmetic; measurement only — nothing in the product path calls these kernels.
+//
+//   seg_bytes = 0   dense: persistent workgroups stream 256-KiB chunks of the flat buffer (16 bytes per lane, coalesced)
+//   seg_bytes = S   the product's access pattern: the buffer is a (rows x row_bytes) matrix (row_bytes = D * element size); a tile is
+//                   S bytes of `tile_rows` consecutive rows (S = 64: the 16 fp32 channels x 4096 rows one workgroup of the 4096 kernel
+//                   owns; 32 = its bf16 rows; 128 = a whole L2 line per row).  Tiles that share 128-byte lines are neighbours in the
+//                   XCD-contiguous order and are walked in step by 128 / S neighbouring workgroups, exactly like the product kernels.
+//   mode 0 copy, 1 load only (the values are consumed by a never-true store), 2 store only
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "kernel_regtile.h"
+#include "../../include/spectre_hip.h"
+
+namespace sfft {
+
+typedef float probe_f32x4 __attribute__((ext_vector_type(4)));
+
+struct ProbeArgs {
+  const char* src; char* dst;
+  long long rows, row_bytes;
+  int seg, tile_rows, mode;
+  int n_tiles, tpw, gang;       // tiles in total, tiles per workgroup, workgroups per 128-byte line
+  int cols;                     // tiles per row block (row_bytes / seg)
+};
+
+constexpr int kProbeThreads = 512, kProbeInFlight = 16;   // 16 x 16 bytes per lane in flight = 128 KiB per workgroup
+
+__global__ void __launch_bounds__(kProbeThreads) spectre_probe_copy_kernel(const ProbeArgs a) {
+  const int tid = threadIdx.x;
+  const int wg = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int base_tile = (wg / a.gang) * a.tpw * a.gang + (wg % a.gang);
+  probe_f32x4 v[kProbeInFlight];
+#pragma unroll
+  for (int q = 0; q < kProbeInFlight; ++q) v[q] = probe_f32x4{1.f, 2.f, 3.f, 4.f};
+  // lane -> (row inside an instruction's row block, 16-byte piece of the segment)
+  const int lps = a.seg > 0 ? a.seg / 16 : 0;                         // lanes per segment
+  const long long lane_off = a.seg > 0 ? (long long)(tid / lps) * a.row_bytes + (tid % lps) * 16 : (long long)tid * 16;
+  const long long step = a.seg > 0 ? (long long)(kProbeThreads / lps) * a.row_bytes : (long long)kProbeThreads * 16;   // bytes between instructions
+  const long long tile_bytes = a.seg > 0 ? (long long)a.seg * a.tile_rows : 256 * 1024;
+  const int chunks = (int)(tile_bytes / (kProbeThreads * 16 * kProbeInFlight));                                         // 128-KiB chunks per tile
+  for (int it = 0; it < a.tpw; ++it) {
+    const int t = base_tile + a.gang * it;
+    if (t >= a.n_tiles) break;
+    const long long base = a.seg > 0 ? (long long)(t / a.cols) * a.tile_rows * a.row_bytes + (long long)(t % a.cols) * a.seg : (long long)t * tile_bytes;
+    for (int c = 0; c < chunks; ++c) {
+      const long long off = base + lane_off + (long long)c * kProbeInFlight * step;
+      if (a.mode != 2) {
+#pragma unroll
+        for (int q = 0; q < kProbeInFlight; ++q) v[q] = *reinterpret_cast<const probe_f32x4*>(a.src + off + q * step);
+      }
+      if (a.mode != 1) {
+#pragma unroll
+        for (int q = 0; q < kProbeInFlight; ++q) *reinterpret_cast<probe_f32x4*>(a.dst + off + q * step) = v[q];
+      } else {
+#pragma unroll
+        for (int q = 0; q < kProbeInFlight; ++q)
+          if (v[q].x == 1.2345e-30f) *reinterpret_cast<probe_f32x4*>(a.dst + off + q * step) = v[q];   // keeps the loads alive, never true
+      }
+    }
+  }
+}
+
+// returns a SPECTRE_E_* code; *why = a static message on failure (the extern "C" wrapper in spectre_hip.hip stores it for spectre_last_error)
+int probe_copy(const SpectreProbeArgs* p, int warmup, int iters, float* ms_per_launch, const char** why) {
+  *why = "";
+  if (!p || !ms_per_launch || iters < 1 || warmup < 0 || !p->src || !p->dst || p->rows < 1 || p->row_bytes < 16) { *why = "NULL pointer or bad size"; return SPECTRE_E_INVALID; }
+  const int seg = p->seg_bytes;
+  if (seg != 0 && (seg < 16 || (seg & (seg - 1)) || seg > 1024 || p->row_bytes % seg || p->tile_rows < 1 || p->rows % p->tile_rows)) {
+    *why = "seg_bytes must be 0 or a power of two in 16..1024 that divides row_bytes; tile_rows must divide rows"; return SPECTRE_E_INVALID; }
+  if (seg != 0 && ((long long)seg * p->tile_rows) % (kProbeThreads * 16 * kProbeInFlight)) { *why = "a tile must be whole 128-KiB chunks"; return SPECTRE_E_INVALID; }
+  if (seg == 0 && (p->rows * p->row_bytes) % (256 * 1024)) { *why = "dense copy: the buffer must be whole 256-KiB chunks"; return SPECTRE_E_INVALID; }
+  if (p->mode < 0 || p->mode > 2) { *why = "mode must be 0 (copy), 1 (load) or 2 (store)"; return SPECTRE_E_INVALID; }
+  *why = "HIP runtime call failed";
+  int prev = 0;
+  if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(p->device) != hipSuccess) return SPECTRE_E_HIP;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, p->device) != hipSuccess) { (void)hipSetDevice(prev); return SPECTRE_E_HIP; }
+  ProbeArgs a{};
+  a.src = static_cast<const char*>(p->src); a.dst = static_cast<char*>(p->dst);
+  a.rows = p->rows; a.row_bytes = p->row_bytes; a.seg = seg; a.tile_rows = p->tile_rows; a.mode = p->mode;
+  a.gang = seg > 0 && seg < 128 ? 128 / seg : 1;
+  a.cols = seg > 0 ? (int)(p->row_bytes / seg) : 1;
+  const long long tile_bytes = seg > 0 ? (long long)seg * p->tile_rows : 256 * 1024;
+  a.n_tiles = (int)(p->rows * p->row_bytes / tile_bytes);
+  const int per_cu = p->wgs_per_cu > 0 ? p->wgs_per_cu : 2;
+  int slots = prop.multiProcessorCount * per_cu / a.gang * a.gang;
+  if (slots < a.gang) slots = a.gang;
+  a.tpw = (a.n_tiles + slots - 1) / slots;
+  const int n_wg = a.gang * ((a.n_tiles + a.gang * a.tpw - 1) / (a.gang * a.tpw));
+  hipStream_t stream = reinterpret_cast<hipStream_t>(p->stream);
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipSetDevice(prev); return SPECTRE_E_HIP; }
+  for (int i = 0; i < warmup; ++i) hipLaunchKernelGGL(spectre_probe_copy_kernel, dim3(n_wg), dim3(kProbeThreads), 0, stream, a);
+  hipError_t e = hipEventRecord(e0, stream);
+  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(spectre_probe_copy_kernel, dim3(n_wg), dim3(kProbeThreads), 0, stream, a);
+  if (e == hipSuccess) e = hipEventRecord(e1, stream);
+  if (e == hipSuccess) e = hipEventSynchronize(e1);
+  float ms = 0.f;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+  if (e == hipSuccess) e = hipGetLastError();
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  (void)hipSetDevice(prev);
+  if (e != hipSuccess) return SPECTRE_E_HIP;
+  *ms_per_launch = ms / (float)iters;
+  *why = "";
+  return SPECTRE_OK;
+}
+
+}  // namespace sfft

@@ -169,6 +169,27 @@ def time_kernel(V, gate, memory_fft=None, n_fft=None, *, out_dtype=None, out=Non
     return float(ms.value)
 
 
+def copy_probe(src: torch.Tensor, dst: torch.Tensor, seg_bytes: int = 0, *, tile_rows: int = 4096, mode: str = "copy",
+               wgs_per_cu: int = 0, warmup: int = 2, iters: int = 5) -> float:
+    """Milliseconds per launch of a PURE COPY of `src` into `dst` with the product kernels' access pattern (C ABI `spectre_probe_copy`;
+    measurement only, used by bench.py for the driver-visible memory ceilings).  src / dst: contiguous (B, N, D) tensors of one dtype.
+    seg_bytes 0 = dense copy; S = every workgroup moves S bytes of `tile_rows` consecutive rows (64 = the fp32 tile of the 4096 kernel)."""
+    lib = _native.load()
+    if not (src.is_cuda and dst.is_cuda and src.is_contiguous() and dst.is_contiguous() and src.shape == dst.shape and src.dtype == dst.dtype
+            and src.dim() == 3):
+        raise ValueError("copy_probe wants two contiguous (B, N, D) device tensors of the same shape and dtype")
+    B, N, D = src.shape
+    a = _native.SpectreProbeArgs()
+    a.src, a.dst = src.data_ptr(), dst.data_ptr()
+    a.rows, a.row_bytes = B * N, D * src.element_size()
+    a.seg_bytes, a.tile_rows, a.mode, a.wgs_per_cu = int(seg_bytes), int(tile_rows), {"copy": 0, "load": 1, "store": 2}[mode], int(wgs_per_cu)
+    a.device = src.device.index if src.device.index is not None else torch.cuda.current_device()
+    a.stream = torch.cuda.current_stream(src.device).cuda_stream
+    ms = ctypes.c_float(0.0)
+    _native.check(lib.spectre_probe_copy(ctypes.byref(a), warmup, iters, ctypes.byref(ms)), "spectre_probe_copy")
+    return float(ms.value)
+
+
 def spectral_gate_fused(anchors: torch.Tensor, bias: torch.Tensor, eps: float, size: int,
                         pos_phase: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Cubic resample of (B, G, K) complex anchors to `size` bins -> complex modReLU -> optional positional phase,

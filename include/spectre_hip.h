@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SPECTRE_ABI_VERSION 6
+#define SPECTRE_ABI_VERSION 7
 
 enum {
   SPECTRE_OK = 0,
@@ -242,6 +242,25 @@ typedef struct SpectreDecodeHeadArgs {
 
 int64_t spectre_decode_head_workspace_bytes(int64_t n_fft, int64_t d, int64_t G, int64_t K);
 int spectre_decode_head_step(const SpectreDecodeHeadArgs* args);
+
+/* Measurement only (bench.py's roofline block; nothing on the product path calls it): a PURE COPY of the spectral mix's bytes with a
+ * chosen access pattern, timed with HIP events on `stream` — the ceiling the memory system of this device gives a kernel that does
+ * no arithmetic.  The buffers are (rows x row_bytes) matrices (for (B, N, D) fp32: rows = B*N, row_bytes = 4*D).
+ *   seg_bytes = 0  dense: 256-KiB chunks of the flat buffer, 16 bytes per lane
+ *   seg_bytes = S  the product kernels' pattern: a workgroup moves S bytes of `tile_rows` consecutive rows (S = 64: the 16 fp32 channels
+ *                  x 4096 rows one workgroup of the 4096 kernel owns; 32: its bf16 rows; 128: a whole L2 line per row), tiles that share
+ *                  a 128-byte line walked in step by neighbouring workgroups, like the product kernels do
+ *   mode 0 copy src -> dst, 1 load only, 2 store only.  wgs_per_cu: persistent workgroups per CU (0 = 2).
+ * Replaces nothing in the reference (no counterpart in spectre.py). */
+typedef struct SpectreProbeArgs {
+  const void* src;
+  void* dst;
+  int64_t rows, row_bytes;
+  int32_t seg_bytes, tile_rows, mode, wgs_per_cu;
+  int32_t device;
+  void* stream;
+} SpectreProbeArgs;
+int spectre_probe_copy(const SpectreProbeArgs* args, int warmup, int iters, float* ms_per_launch);
 
 #ifdef __cplusplus
 }

@@ -41,10 +41,11 @@ def test_binding_matches_header(built_library):
 
 
 def test_every_abi_struct_has_the_layout_the_c_compiler_gives_the_header(tmp_path):
-    """sizeof and every field offset of the seven argument structs: ctypes mirror (fft_amd/_native.py) vs gcc on include/spectre_hip.h."""
+    """sizeof and every field offset of the eight argument structs: ctypes mirror (fft_amd/_native.py) vs gcc on include/spectre_hip.h."""
     import subprocess
     from fft_amd import _native
-    structs = ["SpectreMixArgs", "SpectreMixBwdArgs", "SpectreGateArgs", "SpectreGateBwdArgs", "SpectreRfftArgs", "SpectreDecodeArgs", "SpectreDecodeHeadArgs"]
+    structs = ["SpectreMixArgs", "SpectreMixBwdArgs", "SpectreGateArgs", "SpectreGateBwdArgs", "SpectreRfftArgs", "SpectreDecodeArgs", "SpectreDecodeHeadArgs",
+               "SpectreProbeArgs"]
     lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "spectre_hip.h"', "int main(void) {"]
     for sname in structs:
         ct = getattr(_native, sname)
