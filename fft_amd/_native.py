@@ -90,7 +90,7 @@ class SpectreMixBwdArgs(ctypes.Structure):
         ("B", ctypes.c_int64), ("N_in", ctypes.c_int64), ("n_fft", ctypes.c_int64), ("D", ctypes.c_int64),
         ("G_tot", ctypes.c_int64),
         ("v_sb", ctypes.c_int64), ("v_sn", ctypes.c_int64), ("dout_sb", ctypes.c_int64), ("dout_sn", ctypes.c_int64),
-        ("dv_sb", ctypes.c_int64), ("dv_sn", ctypes.c_int64),
+        ("dv_sb", ctypes.c_int64), ("dv_sn", ctypes.c_int64), ("workspace_bytes", ctypes.c_int64),
         ("io_dtype", ctypes.c_int32), ("device", ctypes.c_int32), ("stream", ctypes.c_void_p),
     ]
 
@@ -142,7 +142,7 @@ def load():
         lib.spectre_mix_time.restype = ctypes.c_int
         lib.spectre_mix_bwd.argtypes = [ctypes.POINTER(SpectreMixBwdArgs)]
         lib.spectre_mix_bwd.restype = ctypes.c_int
-        lib.spectre_mix_bwd_workspace_bytes.argtypes = [ctypes.c_int64] * 3
+        lib.spectre_mix_bwd_workspace_bytes.argtypes = [ctypes.c_int64] * 4
         lib.spectre_mix_bwd_workspace_bytes.restype = ctypes.c_int64
         lib.spectre_gate_fwd.argtypes = [ctypes.POINTER(SpectreGateArgs)]
         lib.spectre_gate_fwd.restype = ctypes.c_int

@@ -599,10 +599,29 @@ int spectre_mix_time(const SpectreMixArgs* a, int warmup, int iters, float* ms_p
   return SPECTRE_OK;
 }
 
-int64_t spectre_mix_bwd_workspace_bytes(int64_t B, int64_t n_fft, int64_t G_tot) {
-  if (B < 0 || n_fft < 1 || G_tot < 1) return 0;
-  // Stockham path: (B, G, n_fft) spectrum sums; register-tile path: up to 8 partial half spectra per (batch, group)
+// partial sums of the gate gradient: Stockham path (B, G, n_fft) spectrum sums; register-tile path up to 8 partial half spectra per (batch, group)
+static int64_t dgate_partials_bytes(int64_t B, int64_t n_fft, int64_t G_tot) {
   return B * G_tot * std::max<int64_t>(n_fft, 8 * (n_fft / 2 + 1)) * (int64_t)sizeof(float2);
+}
+// Transform length the LDS Stockham gate gradient would work on (n_fft, or the Bluestein convolution length), and whether two slots of it
+// still fit the LDS next to each other; if not, the two-pass form needs 2 x (batch chunk) x (F, D) complex spectra of scratch.
+static bool dgate_may_need_two_pass(int64_t n_fft) {
+  std::vector<int> rad;
+  int64_t L = n_fft;
+  if (!factorize(n_fft, rad)) { L = 1; while (L < 2 * n_fft - 1) L <<= 1; }
+  return 2 * L * 8 > (int64_t)kLdsBytes && !(find_tile_size(n_fft) && find_tile_size(n_fft)->grad);
+}
+constexpr int64_t kTwoPassTarget = (int64_t)256 << 20;   // bytes of spectra per pass and tensor the query asks for (more is used if given)
+
+int64_t spectre_mix_bwd_workspace_bytes(int64_t B, int64_t n_fft, int64_t D, int64_t G_tot) {
+  if (B < 0 || n_fft < 1 || G_tot < 1 || D < 1) return 0;
+  int64_t bytes = dgate_partials_bytes(B, n_fft, G_tot);
+  if (dgate_may_need_two_pass(n_fft)) {
+    const int64_t per_b = (n_fft / 2 + 1) * D * (int64_t)sizeof(float2);
+    const int64_t Bc = std::max<int64_t>(1, std::min<int64_t>(B, kTwoPassTarget / per_b));
+    bytes = std::max<int64_t>(bytes, 2 * Bc * per_b);
+  }
+  return bytes;
 }
 
 int spectre_mix_bwd(const SpectreMixBwdArgs* a) {
@@ -613,6 +632,9 @@ int spectre_mix_bwd(const SpectreMixBwdArgs* a) {
   if (a->B == 0) return SPECTRE_OK;
   if (!a->v || !a->gate || !a->dout) return fail(SPECTRE_E_INVALID, "v, gate and dout must be non-NULL device pointers");
   if (a->dgate && !a->workspace) return fail(SPECTRE_E_INVALID, "dgate requested without a workspace");
+  if (a->dgate && a->workspace_bytes < spectre_mix_bwd_workspace_bytes(a->B, a->n_fft, a->D, a->G_tot))
+    return fail(SPECTRE_E_INVALID, "workspace of %lld bytes, spectre_mix_bwd_workspace_bytes() asks for %lld", (long long)a->workspace_bytes,
+                (long long)spectre_mix_bwd_workspace_bytes(a->B, a->n_fft, a->D, a->G_tot));
   DeviceGuard g(a->device);
   if (!g.ok) return fail(SPECTRE_E_HIP, "cannot select device %d", a->device);
   hipStream_t stream = reinterpret_cast<hipStream_t>(a->stream);
@@ -684,15 +706,16 @@ int spectre_mix_bwd(const SpectreMixBwdArgs* a) {
     }
     if (P < 1) {
       // two LDS slots do not fit (n_fft = 12288, 16384, long Bluestein lengths): two-pass fallback — spectra of V and dOut with
-      // the half-spectrum kernel into a stream-ordered scratch buffer, then a reduction over each group's channels
-      // (kernel_gate_grad_twopass.h).  Never refuse a length the forward accepts.
+      // the half-spectrum kernel into the CALLER'S workspace (as many batch elements per pass as it holds), then a reduction over
+      // each group's channels (kernel_gate_grad_twopass.h).  Never refuse a length the forward accepts; never allocate.
       const int64_t F = n / 2 + 1, per_b = F * D * (int64_t)sizeof(float2);
-      const int64_t Bc = std::max<int64_t>(1, std::min<int64_t>(a->B, ((int64_t)256 << 20) / per_b));
-      if (F >= ((int64_t)1 << 31) || a->G_tot >= 65536 || Bc >= 65536) return fail(SPECTRE_E_UNSUPPORTED, "gate gradient: grid too large");
-      float2 *X = nullptr, *R = nullptr;
-      hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&X), (size_t)(Bc * per_b), stream);
-      if (e == hipSuccess) e = hipMallocAsync(reinterpret_cast<void**>(&R), (size_t)(Bc * per_b), stream);
-      if (e != hipSuccess) { if (X) (void)hipFreeAsync(X, stream); return fail(SPECTRE_E_HIP, "gate gradient scratch (%lld bytes): %s", (long long)(2 * Bc * per_b), hipGetErrorString(e)); }
+      const int64_t Bc = std::min<int64_t>(std::min<int64_t>(a->B, 65535), a->workspace_bytes / (2 * per_b));
+      if (Bc < 1) return fail(SPECTRE_E_INVALID, "gate gradient (two-pass): the workspace holds %lld bytes, one batch element needs %lld",
+                              (long long)a->workspace_bytes, (long long)(2 * per_b));
+      if (F >= ((int64_t)1 << 31) || a->G_tot >= 65536) return fail(SPECTRE_E_UNSUPPORTED, "gate gradient: grid too large");
+      float2* X = reinterpret_cast<float2*>(a->workspace);
+      float2* R = X + Bc * F * D;
+      hipError_t e = hipSuccess;
       int rc2 = SPECTRE_OK;
       for (int64_t b0 = 0; b0 < a->B && rc2 == SPECTRE_OK; b0 += Bc) {
         const int64_t bc = std::min<int64_t>(Bc, a->B - b0);
@@ -710,8 +733,6 @@ int spectre_mix_bwd(const SpectreMixBwdArgs* a) {
           if ((e = hipGetLastError()) != hipSuccess) rc2 = fail(SPECTRE_E_HIP, "gate-gradient reduce launch failed: %s", hipGetErrorString(e));
         }
       }
-      (void)hipFreeAsync(X, stream);
-      (void)hipFreeAsync(R, stream);
       return rc2;
     }
     sfft::StockhamArgs k{};
@@ -726,7 +747,7 @@ int spectre_mix_bwd(const SpectreMixBwdArgs* a) {
     k.tw = plan->bluestein ? plan->tw_m : plan->tw_n;
     k.bluestein = plan->bluestein ? 1 : 0; k.chirp = plan->chirp; k.bhat = plan->bhat;
     k.dout = a->dout; k.dout_sb = a->dout_sb; k.dout_sn = a->dout_sn; k.ws = reinterpret_cast<float2*>(a->workspace);
-    hipError_t e = hipMemsetAsync(a->workspace, 0, (size_t)spectre_mix_bwd_workspace_bytes(a->B, n, a->G_tot), stream);
+    hipError_t e = hipMemsetAsync(a->workspace, 0, (size_t)dgate_partials_bytes(a->B, n, a->G_tot), stream);
     if (e != hipSuccess) return fail(SPECTRE_E_HIP, "hipMemsetAsync: %s", hipGetErrorString(e));
     const size_t lds = (size_t)2 * k.L * k.P * sizeof(float2);
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(sfft::spectre_gate_grad_stockham),

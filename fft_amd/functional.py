@@ -123,12 +123,15 @@ def spectral_mix_backward(V: torch.Tensor, gate: torch.Tensor, grad_out: torch.T
     dgate = torch.empty((B, G, F), dtype=torch.complex64, device=V.device) if need_dgate else None
     ws = None
     if need_dgate:
-        ws = torch.empty(lib.spectre_mix_bwd_workspace_bytes(B, n_fft, G), dtype=torch.uint8, device=V.device)
+        # ALL scratch of the backward comes from torch's caching allocator (the library allocates nothing): the partial sums of the
+        # gate gradient and, for n_fft = 12288 / 16384 / long Bluestein lengths, the spectra of the two-pass form
+        ws = torch.empty(lib.spectre_mix_bwd_workspace_bytes(B, n_fft, D, G), dtype=torch.uint8, device=V.device)
     a = _native.SpectreMixBwdArgs()
     a.v, a.gate, a.dout = V.data_ptr(), gate.data_ptr(), grad_out.data_ptr()
     a.dv = dv.data_ptr() if dv is not None else None
     a.dgate = dgate.data_ptr() if dgate is not None else None
     a.workspace = ws.data_ptr() if ws is not None else None
+    a.workspace_bytes = ws.numel() if ws is not None else 0
     a.B, a.N_in, a.n_fft, a.D, a.G_tot = B, N, n_fft, D, G
     a.v_sb, a.v_sn = V.stride(0), V.stride(1)
     a.dout_sb, a.dout_sn = grad_out.stride(0), grad_out.stride(1)

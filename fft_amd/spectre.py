@@ -132,6 +132,7 @@ class _SpectralMixFn(torch.autograd.Function):
         return spectral_mix(V, gate, memory_fft, n_fft)
 
     @staticmethod
+    @torch.autograd.function.once_differentiable      # the gradients come from C-ABI launches: no graph behind them, so double backward must raise
     def backward(ctx, grad_out):
         V, gate = ctx.saved_tensors
         dv, dgate = spectral_mix_backward(V, gate, grad_out.contiguous(), ctx.n_fft,
@@ -150,6 +151,7 @@ class _SpectralGateFn(torch.autograd.Function):
         return spectral_gate_fused(anchors, bias, eps, size, pos_phase)
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, grad_gate):
         anchors, bias, pos_phase = ctx.saved_tensors
         da, db, dp = spectral_gate_backward(anchors, bias, ctx.eps, ctx.size, pos_phase, grad_gate.to(torch.complex64),
@@ -207,6 +209,8 @@ class SpectreHead(nn.Module):
         Bsz, N, d = x.shape
         assert d == self.d
         if v_out is not None:
+            if torch.is_grad_enabled() and (x.requires_grad or self.W_v.weight.requires_grad):
+                raise RuntimeError("spectral_gate(v_out=...) writes the value projection in place and records no graph: inference only")
             V = torch.matmul(x, self.W_v.weight.t(), out=v_out)          # W_v has no bias (spectre.py:428)
         else:
             V = self.W_v(x)
@@ -281,14 +285,22 @@ class SpectreMultiHead(nn.Module):
 
     def __init__(self, embed_dim: int, num_heads: int, n_fft: int, d_gate: int = 256, use_toeplitz: bool = False,
                  dropout_p: float = 0.0, pooling_type: str = "dct", num_groups: int = 4,
-                 num_buckets: Optional[int] = None, wavelet_on_rate: float = 0.0):
+                 num_buckets: Optional[int] = None, wavelet_on_rate: Optional[float] = None):
         super().__init__()
         assert embed_dim % num_heads == 0
         # Deviation from the reference's default (0.1): the refinement is out of scope, so the default
         # constructor builds the layer WITHOUT it instead of failing; asking for it explicitly still raises.
+        if wavelet_on_rate is None:
+            # the reference's constructor default is 0.1 (spectre.py:673): a caller who never mentions the rate gets a layer WITHOUT the
+            # stochastic refinement here — say so once instead of silently building a different function
+            warnings.warn("fft_amd.SpectreMultiHead: the stochastic WaveletRefinement (spectre.py:819-878; reference default "
+                          "wavelet_on_rate=0.1, active even in eval()) is not implemented — this layer is built without it. "
+                          "Pass wavelet_on_rate=0.0 to acknowledge (and to compare with a reference module constructed the same way).",
+                          stacklevel=2)
+            wavelet_on_rate = 0.0
         if wavelet_on_rate != 0.0:
             raise NotImplementedError("fft_amd.SpectreMultiHead: the stochastic WaveletRefinement (spectre.py:819-878) is not "
-                                      "implemented; construct with wavelet_on_rate=0.0 (the default here; the reference's is 0.1)")
+                                      "implemented; construct with wavelet_on_rate=0.0 (the reference's default is 0.1)")
         self.num_heads = num_heads
         self.head_dim = embed_dim // num_heads
         self.heads = nn.ModuleList([
@@ -301,7 +313,9 @@ class SpectreMultiHead(nn.Module):
     def forward(self, x: torch.Tensor, pos_phase: Optional[torch.Tensor] = None, memory_fft: Optional[torch.Tensor] = None):
         chunks = torch.chunk(x, self.num_heads, dim=-1)
         mems = torch.chunk(memory_fft, self.num_heads, dim=-1) if memory_fft is not None else [None] * self.num_heads
-        needs_graph = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        needs_graph = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())
+                                                   or (pos_phase is not None and pos_phase.requires_grad)
+                                                   or (memory_fft is not None and memory_fft.requires_grad))
         if needs_graph or any(not isinstance(h.dropout, nn.Identity) for h in self.heads):
             mixed = torch.cat([h(c, pos_phase, memory_fft=m) for h, c, m in zip(self.heads, chunks, mems)], dim=-1)
             return self.out_proj(mixed)

@@ -99,9 +99,12 @@ int spectre_plan_destroy(int device, int64_t n_fft);
  *   dv    (B, N_in, D)   = mix(dout, conj(gate))  zero-padded back to N_in rows   — same kernels as the forward
  *   dgate (B, G_tot, F)  = (w_k / n_fft) * sum_{c in group} conj(rfft(v)[k, c]) * rfft(dout)[k, c],  w_k = 2 (1 at DC/Nyquist)
  * `dout` is (B, min(N_in, n_fft), D) with the dtype of `v`; `dv` has the dtype of `v`; `dgate` is complex64.
- * Either output may be NULL.  `workspace` must hold spectre_mix_bwd_workspace_bytes() bytes when dgate != NULL
- * (the library zeroes it on the stream).  memory_fft gets no gradient: it is a frozen buffer in the reference
- * (spectre.py:951-959). */
+ * Either output may be NULL.  When dgate != NULL, `workspace` must hold spectre_mix_bwd_workspace_bytes(B, n_fft, D, G_tot) bytes
+ * (the library zeroes what it uses on the stream) and `workspace_bytes` says how large the buffer is.  ALL scratch of the backward
+ * lives there — the library allocates nothing (round 2 took the spectra scratch of the two-pass gate gradient, n_fft = 12288 / 16384
+ * and long Bluestein lengths, from hipMallocAsync behind the caller's caching allocator); a larger buffer lets the two-pass path take
+ * more batch elements per pass, a smaller one than the query's answer is refused.  memory_fft gets no gradient: it is a frozen buffer
+ * in the reference (spectre.py:951-959). */
 typedef struct SpectreMixBwdArgs {
   const void* v;
   const void* gate;
@@ -111,12 +114,13 @@ typedef struct SpectreMixBwdArgs {
   void* workspace;
   int64_t B, N_in, n_fft, D, G_tot;
   int64_t v_sb, v_sn, dout_sb, dout_sn, dv_sb, dv_sn; /* element strides */
+  int64_t workspace_bytes; /* size of the buffer at `workspace` */
   int32_t io_dtype;   /* SPECTRE_F32 | SPECTRE_BF16 for v, dout and dv */
   int32_t device;
   void* stream;
 } SpectreMixBwdArgs;
 
-int64_t spectre_mix_bwd_workspace_bytes(int64_t B, int64_t n_fft, int64_t G_tot);
+int64_t spectre_mix_bwd_workspace_bytes(int64_t B, int64_t n_fft, int64_t D, int64_t G_tot);
 int spectre_mix_bwd(const SpectreMixBwdArgs* args);
 
 /* Measurement helper used by bench.py: runs `warmup` untimed + `iters` timed launches of the same

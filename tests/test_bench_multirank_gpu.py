@@ -1,0 +1,47 @@
+"""bench.py --gpus 2 executed for real: two ranks (one process each, `python -m torch.distributed.run` started by bench.py itself) on the
+ONE GPU of the test box (SPECTRE_BENCH_OVERSUBSCRIBE=1), RCCL ("nccl") process group first, gloo as the fallback if RCCL refuses two
+ranks on one device.  Checks the contract of the N > 1 line: n_gpus, whole-job value = 2 x per-rank rate, MAX-over-ranks timing, and
+that two ranks sharing a device each get about half of it."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra_env, args, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(extra_env)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    return out, (json.loads(lines[-1]) if lines else None)
+
+
+def test_two_ranks_on_one_gpu():
+    shape = "64,4096,768"                                  # per rank; two ranks share the device
+    args = ["--steps", "10", "--warmup", "3", "--prewarm", "30", "--shape", shape, "--no-cpu-baseline"]
+    out1, one = _run({}, ["--gpus", "1", *args])
+    assert out1.returncode == 0 and one is not None, out1.stderr[-2000:]
+    backend = "nccl"
+    out2, two = _run({"SPECTRE_BENCH_OVERSUBSCRIBE": "1"}, ["--gpus", "2", *args])
+    if out2.returncode != 0 or two is None:                # RCCL may refuse two ranks on one device: the data path has no collective, gloo will do
+        backend = "gloo"
+        out2, two = _run({"SPECTRE_BENCH_OVERSUBSCRIBE": "1", "SPECTRE_BENCH_BACKEND": "gloo"}, ["--gpus", "2", *args])
+    assert out2.returncode == 0 and two is not None, (backend, out2.stderr[-3000:])
+    print(f"backend {backend}: 1 rank {one['value']:.4g} tok/s, 2 ranks on one GPU {two['value']:.4g} tok/s whole job")
+    assert two["n_gpus"] == 2 and two["scaling"] == "weak" and two["steps"] == 10
+    assert two["config"]["global_batch"] == 128 and "batch-shard x2" in two["config"]["parallelism"]
+    assert abs(two["value"] - 2 * two["tokens_per_s_per_gpu"]) <= 1e-6 * two["value"]
+    assert "cpu_baseline" not in two and "variants" not in two          # rank-0-at-N=1 extras stay out of the N > 1 line
+    # two ranks time-share one device: the whole job moves about what one rank alone moves (each rank gets about half)
+    ratio = two["value"] / one["value"]
+    assert 0.6 <= ratio <= 1.25, ratio
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "bench_w2_oversubscribed.json"), "w") as f:
+        json.dump({"backend": backend, "one_rank": one, "two_ranks_one_gpu": two}, f)

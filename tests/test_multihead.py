@@ -28,7 +28,12 @@ def test_surface_and_reference_state_dict():
     assert names == ["self", "embed_dim", "num_heads", "n_fft", "d_gate", "use_toeplitz", "dropout_p", "pooling_type",
                      "num_groups", "num_buckets", "wavelet_on_rate"]                    # spectre.py:664-676
     assert list(inspect.signature(SpectreMultiHead.forward).parameters) == ["self", "x", "pos_phase", "memory_fft"]
-    assert SpectreMultiHead(32, 2, 64).wavelet_refinement.on_rate == 0.0             # default constructor works (documented deviation: 0.0, reference 0.1)
+    with pytest.warns(UserWarning, match="WaveletRefinement"):                          # the default constructor works but says what it leaves out
+        assert SpectreMultiHead(32, 2, 64).wavelet_refinement.on_rate == 0.0             # (reference default 0.1)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        SpectreMultiHead(32, 2, 64, wavelet_on_rate=0.0)                                 # acknowledged: silent
     with pytest.raises(NotImplementedError, match="wavelet_on_rate"):
         SpectreMultiHead(32, 2, 64, wavelet_on_rate=0.1)                                # asking for the refinement is refused loudly
     assert len(MH) >= 2
@@ -76,3 +81,28 @@ def test_inference_is_one_mix_launch_over_all_heads(monkeypatch):
     assert len(calls) == 1
     (vs, gs), = calls
     assert vs[2] == mh.num_heads * mh.head_dim and gs[1] == mh.num_heads * mh.heads[0].G
+
+
+def test_learnable_pos_phase_forces_the_autograd_path():
+    """with frozen parameters and pos_phase.requires_grad the one-launch path would drop the gradient to pos_phase."""
+    from fft_amd import SpectreMultiHead
+    mh = SpectreMultiHead(16, 2, 32, pooling_type="mean", num_groups=2, wavelet_on_rate=0.0)
+    for p in mh.parameters():
+        p.requires_grad_(False)
+    pp = torch.randn(17, dtype=torch.complex64, requires_grad=True)
+    calls = []
+    for h in mh.heads:
+        h.forward = (lambda *a, _h=h, **k: (calls.append(1), torch.zeros(a[0].shape))[1])   # stand-in: only the routing is under test
+    mh.out_proj = torch.nn.Identity()
+    mh(torch.randn(1, 32, 16), pos_phase=pp)
+    assert len(calls) == 2                                                                  # per-head modules (graph path), not the fused launch
+
+
+def test_v_out_is_refused_under_autograd():
+    from fft_amd import SpectreHead
+    h = SpectreHead(8, 16, num_groups=2, pooling_type="mean")
+    x = torch.randn(1, 16, 8)
+    with pytest.raises(RuntimeError, match="inference only"):
+        h.spectral_gate(x, v_out=torch.empty(1, 16, 8))
+    with torch.no_grad():
+        h.spectral_gate(x, v_out=torch.empty(1, 16, 8))
