@@ -75,11 +75,10 @@ __device__ __forceinline__ void pin8(float2 (&z)[64]) {
 }
 
 template <bool INV>
-__device__ __forceinline__ void p64_stageA1(float2 (&z)[64]) {      // type A stage 1: radix-8 over q1 (positions 8 q1 + q0), * W_64^(q0 ka)
+__device__ __forceinline__ void p64_stageA1(float2 (&z)[64]) {      // type A stage 1: radix-8 over q1 (positions 8 q1 + q0); W_64^(q0 ka) is stage 2's
   static_for<0, 8>([&](auto q0c) {
     constexpr int q0 = decltype(q0c)::value;
-    bfly<8, INV, q0, 8, 64>(z);
-    static_for<1, 8>([&](auto kac) { constexpr int ka = decltype(kac)::value; z[8 * ka + q0] = twid64<q0 * ka, INV>(z[8 * ka + q0]); });
+    bfly_plain<8, INV, q0, 8, 64>(z);
     pin8<q0, 8>(z);
     __builtin_amdgcn_sched_barrier(0);
   });
@@ -157,15 +156,19 @@ template <int SPLIT> constexpr int p64_younger_first() { return 4 * (8 - SPLIT) 
 //         memory traffic in flight (3 in the library: 245 VGPRs; 4 spills).
 // IN_BF16 = bf16 rows in (spectre.py's activations under autocast), fp32 arithmetic: a lane still moves the 4 channels of a row —
 //         8 bytes, two packed dwords = its two sequences — so the lane map, the swap and everything after it are the fp32 kernel's;
-//         only the staging differs (8-byte LDS-DMA does not exist: a DMA instruction fetches 8 whole 32-byte row segments, lane =
-//         (row, dword), and every lane reads its 8 bytes back out of its wave's slot).
+//         only the staging differs: a DMA instruction fetches 32 whole 32-byte row segments (16 bytes per lane, lane = (row, half)), and
+//         every lane reads its 8 bytes back out of its wave's slot (a permutation of 512 contiguous bytes: conflict-free).  A bf16 row
+//         group is 16 KiB, so ALL EIGHT groups of the next tile fit the image (SPLIT = 8, PF = 0): every load of a tile is requested
+//         right behind E2 of the previous one, none behind its stores (round 3: the fp32 kernel's late groups cost a memory latency
+//         per tile — same-box ablation: loads only 1.11 ms, stores only 0.90, neither 0.84).
 // OUT_BF16 = bf16 rows out (round to nearest even, like every other kernel here): a lane stores its 4 channels as 8 bytes.
 template <int SPLIT, int PF, bool WITH_MEM = false, bool IN_BF16 = false, bool OUT_BF16 = false>
 __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileArgs a) {
   constexpr int ESI = IN_BF16 ? 2 : 4, ESO = OUT_BF16 ? 2 : 4;   // bytes per input / output element
   constexpr float inv_n = 1.0f / 4096.0f;
-  static_assert(SPLIT >= 1 && SPLIT <= 4 && SPLIT * 4 * 1024 * 8 <= kP64ImageBytes, "staging lives in the exchange image");
-  static_assert(PF >= 1 && SPLIT + PF <= 8, "row groups: SPLIT through LDS, PF deferred / prefetched in registers, the rest behind their stores");
+  constexpr int GROUP_SLOT = IN_BF16 ? 2 * 1024 : 4 * 1024;     // bytes of one row group in a wave's landing slots
+  static_assert(SPLIT >= 1 && SPLIT <= 8 && SPLIT * GROUP_SLOT * 8 <= kP64ImageBytes, "staging lives in the exchange image");
+  static_assert(PF >= 0 && SPLIT + PF <= 8, "row groups: SPLIT through LDS, PF deferred / prefetched in registers, the rest behind their stores");
   constexpr int GP = 8 - PF;                       // first deferred / prefetched group
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* img = reinterpret_cast<float*>(smem);
@@ -197,7 +200,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
     pp = lane & 3; h = (lane >> 4) & 1;
     p = 2 * pp + h;
     u = ((lane >> 2) & 3) + 4 * (lane >> 5) + 8 * (t >> 6);
-    slot = smem + __builtin_amdgcn_readfirstlane(t >> 6) * (SPLIT * 4 * 1024);   // this wave's landing slots
+    slot = smem + __builtin_amdgcn_readfirstlane(t >> 6) * (SPLIT * GROUP_SLOT);   // this wave's landing slots
   };
   coords();
 
@@ -209,14 +212,15 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
   if (pair_base >= a.n_tiles) return;
 
   float2 z[64];
-  float4 dfr[4 * PF];                              // deferred results of the previous tile / prefetched rows of the next one
+  float4 dfr[PF > 0 ? 4 * PF : 1];                 // deferred results of the previous tile / prefetched rows of the next one
   static_for<0, 4 * PF>([&](auto ic) { dfr[decltype(ic)::value] = make_float4(0.f, 0.f, 0.f, 0.f); });   // (stored into an empty range before the first tile)
   char* obp = nullptr;                             // output tile of the deferred results
   float2 gstage[5];      // the next tile's gate bins on their way to LDS (4097 bins / 512 threads, rounded up; + 1 for the last)
 
-  // lane offset of an LDS-DMA request: fp32 = the lane's own 16 bytes (the register-load offset); bf16 = (row l >> 3, dword l & 7)
+  // lane offset of an LDS-DMA request: fp32 = the lane's own 16 bytes (the register-load offset); bf16 = lane l fetches the 16-byte half
+  // l & 1 of the 32-byte segment of row  (l >> 1 & 7) + 8 wave + 512 (l >> 4 & 1) + 1024 (l >> 5)   [+ 64 g + 2048 (m >> 1) per instruction]
   auto dma_voff = [&](uint32_t voff, long long sn) -> uint32_t {
-    if constexpr (IN_BF16) return (uint32_t)(((long long)((lane >> 3) + 8 * (u >> 3)) * sn) * ESI + (lane & 7) * 4);
+    if constexpr (IN_BF16) return (uint32_t)(((long long)(((lane >> 1) & 7) + 8 * (u >> 3) + 512 * ((lane >> 4) & 1) + 1024 * (lane >> 5)) * sn) * ESI + (lane & 1) * 16);
     else return voff;
   };
   auto tile_ptrs = [&](int tile, const char*& vb, char*& ob, const float2*& gp) {
@@ -258,23 +262,23 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
       }
     });
   };
-  // fp32: 1 KiB per instruction, lane l's 16 bytes at slot + 16 l.  bf16: 256 B per instruction = the 8 rows (rcl + 4 rch) of one h,
-  // lane l = (row l >> 3, dword l & 7); dvoff = that lane's offset inside row block 0 (computed per tile by the caller).
+  // 1 KiB per instruction, lane l's 16 bytes at slot + 16 l.  fp32: four instructions per group (m = 0..3); bf16: two (m >> 1 = 0, 1),
+  // each with the rows of both h and of m & 1 (dma_voff).
   auto dma_group = [&](__amdgpu_buffer_rsrc_t rs, uint32_t voff, long long sn, auto gc) {        // into this wave's LDS slots
     constexpr int g = decltype(gc)::value;
-    static_for<0, 4>([&](auto mc) {
-      constexpr int m = decltype(mc)::value;
-      if constexpr (IN_BF16) {
-        static_for<0, 2>([&](auto hc) {
-          constexpr int hh = decltype(hc)::value;
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(slot + ((4 * g + m) * 2 + hh) * 256), 4,
-                                                   voff + (uint32_t)((64 * g + 1024 * m + 512 * hh) * sn * ESI), 0, 0, 0);
-        });
-      } else {
+    if constexpr (IN_BF16) {
+      static_for<0, 2>([&](auto mc) {
+        constexpr int mh = decltype(mc)::value;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(slot + (2 * g + mh) * 1024), 16,
+                                                 voff + (uint32_t)((64 * g + 2048 * mh) * sn * ESI), 0, 0, 0);
+      });
+    } else {
+      static_for<0, 4>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(slot + (4 * g + m) * 1024), 16,
                                                  voff + (uint32_t)((64 * g + 1024 * m) * sn * 4), 0, 0, 0);
-      }
-    });
+      });
+    }
   };
   auto store16 = [&](__amdgpu_buffer_rsrc_t rs, uint32_t off, const float4 v) {   // this lane's 4 channels of one row
     if constexpr (OUT_BF16) {
@@ -292,7 +296,8 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
     static_for<0, 4>([&](auto mc) {
       constexpr int m = decltype(mc)::value;
       if constexpr (IN_BF16) {
-        const rt_u32x2 t = *reinterpret_cast<const rt_u32x2*>(slot + ((4 * g + m) * 2 + h) * 256 + (((lane >> 2) & 3) + 4 * (lane >> 5)) * 32 + pp * 8);
+        // DMA lane 2 (rcl + 4 rch + 8 h + 16 (m & 1)) + (pp >> 1) of instruction (g, m >> 1), half pp & 1 of its 16 bytes
+        const rt_u32x2 t = *reinterpret_cast<const rt_u32x2*>(slot + (2 * g + (m >> 1)) * 1024 + ((((lane >> 2) & 3) + 4 * (lane >> 5)) + 8 * h + 16 * (m & 1)) * 32 + pp * 8);
         z[8 * g + 2 * m] = unpack_lo(t.x);
         z[8 * g + 2 * m + 1] = unpack_lo(t.y);
       } else {
@@ -362,13 +367,13 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
     if (more) tile_ptrs(tile + GANG, vbn, obn, gpn);
     const __amdgpu_buffer_rsrc_t rs_next = rsrc_in(vbn, v_sn, more), rs_out = rsrc_out(ob, out_sn);
 
-    const uint32_t pf_ooff = (uint32_t)(((long long)(u + 512 * h) * out_sn + 4 * pp) * ESO);
-    const uint32_t pf_voff = (uint32_t)(((long long)(u + 512 * h) * v_sn + 4 * pp) * ESI);
-    auto pf_store = [&](auto ic) {
+    [[maybe_unused]] const uint32_t pf_ooff = (uint32_t)(((long long)(u + 512 * h) * out_sn + 4 * pp) * ESO);
+    [[maybe_unused]] const uint32_t pf_voff = (uint32_t)(((long long)(u + 512 * h) * v_sn + 4 * pp) * ESI);
+    [[maybe_unused]] auto pf_store = [&](auto ic) {
       constexpr int g = GP + decltype(ic)::value / 4, m = decltype(ic)::value % 4;
       store16(rsrc_out(obp, out_sn, it > 0), pf_ooff + (uint32_t)((64 * g + 1024 * m) * out_sn * ESO), dfr[decltype(ic)::value]);
     };
-    auto pf_load = [&](auto ic) {
+    [[maybe_unused]] auto pf_load = [&](auto ic) {
       constexpr int g = GP + decltype(ic)::value / 4, m = decltype(ic)::value % 4;
       if constexpr (IN_BF16) {                       // stays packed (two dwords) until it trades places with the results in I2
         const rt_u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs_next, pf_voff + (uint32_t)((64 * g + 1024 * m) * v_sn * ESI), 0, 0);
@@ -394,8 +399,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
         static_for<0, SPLIT>([&](auto gc) { read_group(gc); });
       }
       swap_group(std::integral_constant<int, g>{});
-      bfly<8, false, 8 * g, 1, 64>(z);             // over e -> ka at position 8g + ka
-      static_for<1, 8>([&](auto kac) { constexpr int ka = decltype(kac)::value; z[8 * g + ka] = twid64<g * ka, false>(z[8 * g + ka]); });
+      bfly_plain<8, false, 8 * g, 1, 64>(z);       // over e -> ka at position 8g + ka (W_64^(g ka) is applied by the column butterflies below)
       pin8<8 * g, 1>(z);
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -407,7 +411,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
       // real parts straight into the image while the next column is computed
       static_for<0, 8>([&](auto kac) {
         constexpr int ka = decltype(kac)::value;
-        bfly<8, false, ka, 8, 64>(z);
+        bfly_tw<8, false, ka, 8, 1, ka, 64>(z);    // input g still needs W_64^(g ka): scaled form (fft_regs.h)
         static_for<0, 8>([&](auto kbc) {
           constexpr int kb = decltype(kbc)::value, j = 8 * kb + ka;
           if constexpr (ka > 0) z[j] = cmul(z[j], wa[ka]);
@@ -494,7 +498,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
       p64_barrier();
       static_for<0, 8>([&](auto nc) {
         constexpr int nlo = decltype(nc)::value;
-        bfly<8, true, nlo, 8, 64>(z);
+        fftB_stage2_group<8, 8, true, nlo>(z);
         pin8<nlo, 8>(z);
         __builtin_amdgcn_sched_barrier(0);
         p64_write_col<nlo, false>(z, img, p, u);

@@ -18,6 +18,10 @@ namespace sfft {
 
 __device__ __forceinline__ void rt_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// (Round 3 tried the 4096 kernel's early exchange writes here — E1's real plane written position by position behind the twiddle
+//  multiplication, the image-freeing barrier moved in front of it or to the top of the tile: 1.87 / 1.89 ms against 1.59, and 1.24 against
+//  1.15 ms without memory traffic; profiles/r03_mixedp_ab.log.  The scattered ds_write_b32 between the multiplications cost more than the
+//  write phase they replace, and the earlier barrier exposes the slowest wave's loads.  Not kept.)
 template <int RF, int RS, int P, bool FIRST = false>
 __global__ void __launch_bounds__(kPC * (RF > RS ? RF : RS), 1) spectre_mix_regtile_mixedp(const RegtileArgs a) {
   constexpr int D0 = FIRST ? 0 : RF - P;           // the deferred row blocks are [D0, D0 + P) of the order F1 uses them (the last ones: measured
@@ -64,8 +68,7 @@ __global__ void __launch_bounds__(kPC * (RF > RS ? RF : RS), 1) spectre_mix_regt
   // Buffer resources: base = the tile's first row, num_records = the bytes of its rows below N_in (0 = nothing: no such tile).  The
   // range check covers the VGPR offset, so the row-block offset goes there too; threads that own no row class (RF > RS) get an offset
   // beyond every range, so every wave issues the same requests.
-  auto rsrc = [&](const void* base, long long sn, bool live) {
-    const int nrow = !live ? 0 : a.N_in < N ? a.N_in : N;
+  auto rsrc = [&](const void* base, long long sn, int nrow) {   // nrow = a.rows_in / a.rows_out, or 0: no such tile
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)((long long)nrow * sn * 4), kRsrcFlags);
   };
   // row blocks in the order F1 uses them
@@ -105,7 +108,7 @@ __global__ void __launch_bounds__(kPC * (RF > RS ? RF : RS), 1) spectre_mix_regt
   {
     const char* vb; char* ob; const float2* gp;
     tile_ptrs(pair_base, vb, ob, gp);
-    const __amdgpu_buffer_rsrc_t rs = rsrc(vb, a.v_sn, true);
+    const __amdgpu_buffer_rsrc_t rs = rsrc(vb, a.v_sn, a.rows_in);
     const uint32_t voff = rows ? (uint32_t)(((long long)u * a.v_sn + 2 * p) * 4) : 0x80000000u;
     static_for<0, RF>([&](auto ic) { constexpr int q = decltype(row_q(ic))::value; z[q] = load_row(rs, voff, a.v_sn, std::integral_constant<int, q>{}); });
     gate_fetch(gp);
@@ -122,7 +125,8 @@ __global__ void __launch_bounds__(kPC * (RF > RS ? RF : RS), 1) spectre_mix_regt
     tile_ptrs(tile, vb, ob, gp);
     const char* vbn = vb; char* obn = ob; const float2* gpn = gp;
     if (more) tile_ptrs(tile + 2, vbn, obn, gpn);
-    const __amdgpu_buffer_rsrc_t rs_next = rsrc(vbn, v_sn, more), rs_out = rsrc(ob, out_sn, true), rs_prev = rsrc(obp, out_sn, it > 0);
+    const __amdgpu_buffer_rsrc_t rs_next = rsrc(vbn, v_sn, more ? a.rows_in : 0), rs_out = rsrc(ob, out_sn, a.rows_out),
+                                 rs_prev = rsrc(obp, out_sn, it > 0 ? a.rows_out : 0);
     const uint32_t voff = rows ? (uint32_t)(((long long)u * v_sn + 2 * p) * 4) : 0x80000000u;
     const uint32_t ooff = rows ? (uint32_t)(((long long)u * out_sn + 2 * p) * 4) : 0x80000000u;
 

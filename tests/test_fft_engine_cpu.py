@@ -20,6 +20,8 @@ def engine(tmp_path_factory):
     lib = ctypes.CDLL(str(out))
     lib.fft_engine_run.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     lib.fft_engine_run.restype = ctypes.c_int
+    lib.fft_regs_run.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    lib.fft_regs_run.restype = ctypes.c_int
     return lib
 
 
@@ -37,3 +39,26 @@ def test_forward_inverse_roundtrip(engine, R):
     assert np.abs(_run(engine, R, 0, x) - np.fft.fft(x)).max() <= tol
     assert np.abs(_run(engine, R, 1, x) - np.fft.ifft(x) * R).max() <= tol
     assert np.abs(_run(engine, R, 2, x) - x * R).max() <= 4e-6 * R * np.abs(x).max()
+
+
+@pytest.mark.parametrize("X", [16, 32, 64])
+def test_two_factor_power_of_two_transforms_in_scaled_twiddle_form(engine, X):
+    """fft_regs.h: fftA / fftB with the inter-stage twiddles applied to the second stage's inputs as unscaled rotations (2 FMAs) whose
+    cos factors are folded into the butterfly's additions.  Against numpy, fp32 accuracy (a few 1e-7 of the spectrum's magnitude)."""
+    rng = np.random.default_rng(100 + X)
+
+    def run(mode, x):
+        buf = np.ascontiguousarray(x.astype(np.complex64)).view(np.float32).copy()
+        assert engine.fft_regs_run(X, mode, buf.ctypes.data) == 0
+        return buf.view(np.complex64)
+
+    for trial in range(8):
+        x = rng.standard_normal(X) + 1j * rng.standard_normal(X)
+        if trial == 0:
+            x = np.zeros(X, complex); x[1] = 1.0                 # a pure twiddle pattern: every output is a root of unity
+        F = np.fft.fft(x)
+        tol = 1e-6 * max(np.abs(F).max(), 1.0)
+        assert np.abs(run(0, x) - F).max() <= tol, "forward, type A"
+        assert np.abs(run(1, x) - np.fft.ifft(x) * X).max() <= tol, "inverse, type A"
+        assert np.abs(run(2, x) - x * X).max() <= 2e-6 * X * max(np.abs(x).max(), 1.0), "A forward -> B inverse"
+        assert np.abs(run(3, x) - np.fft.ifft(x) * X).max() <= tol, "inverse, type B"

@@ -41,6 +41,18 @@
 
 namespace sfft {
 
+// the round-2 forms of the two-factor transforms (twiddle as a complex multiplication on stage 1's outputs): fft_regs.h has since moved
+// the twiddles into stage 2's butterflies in scaled form, this frozen kernel keeps the arithmetic it was measured with
+template <int RA, int RB, bool INV, int KA, int OFF = 0, int NTOT = RA * RB>
+__device__ __forceinline__ void xfftA_stage2_group(float2 (&z)[NTOT]) { bfly<RB, INV, OFF + RB * KA, 1, NTOT>(z); }
+template <int RA, int RB, bool INV, int KA, int OFF = 0, int NTOT = RA * RB>
+__device__ __forceinline__ void xfftB_stage1_group(float2 (&z)[NTOT]) {
+  constexpr int R = RA * RB, U = 64 / R;
+  bfly<RB, INV, OFF + RB * KA, 1, NTOT>(z);
+  if constexpr (KA > 0)
+    static_for<1, RB>([&](auto nc) { constexpr int nlo = decltype(nc)::value; z[OFF + RB * KA + nlo] = twid64<U * KA * nlo, INV>(z[OFF + RB * KA + nlo]); });
+}
+
 // the argument block of the round-2 kernel (the library's RegtileArgs has since lost the experiment fields)
 struct XRegtileArgs {
   const void* v; const float2* gate; const float* mem; void* out; const float2* tw;
@@ -608,7 +620,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64x(const XRegtileArgs a)
         constexpr int ka = decltype(kac)::value;
         if constexpr (ka + 1 < 8 && !FEN)
           static_for<0, 8>([&](auto kbc) { constexpr int k2n = ka + 1 + 8 * decltype(kbc)::value; gnxt[decltype(kbc)::value] = fetch_gate(k2n, k2n >= 32); });
-        if constexpr (VALU) fftA_stage2_group<8, 8, false, ka>(z);
+        if constexpr (VALU) xfftA_stage2_group<8, 8, false, ka>(z);
         static_for<0, 8>([&](auto kbc) {
           constexpr int kb = decltype(kbc)::value, j = 8 * ka + kb, k2 = ka + 8 * kb;
           if constexpr (VALU) z[j] = cmul(z[j], gcur[kb]);                                   // spectre.py:545
@@ -629,7 +641,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64x(const XRegtileArgs a)
             gcur[decltype(kbc)::value] = fetch_gate(k2n, k2n >= 32);
             if constexpr (WITH_MEM) mcur[decltype(kbc)::value] = fetch_mem(k2n, k2n >= 32);
           });
-        if constexpr (VALU) fftB_stage1_group<8, 8, true, ka>(z);
+        if constexpr (VALU) xfftB_stage1_group<8, 8, true, ka>(z);
         if constexpr (FEN) xpin8<8 * ka, 1>(z);
         if constexpr (ka + 1 < 8 && !FEN) static_for<0, 8>([&](auto kbc) { gcur[decltype(kbc)::value] = gnxt[decltype(kbc)::value]; });
         __builtin_amdgcn_sched_barrier(0);         // keep the gate prefetch one group deep (register budget)
@@ -688,7 +700,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64x(const XRegtileArgs a)
         constexpr int g = (decltype(ic)::value + SPLIT) % 8;             // register-loaded groups first: their reloads start earliest
         constexpr bool stores_now = g < GP && (ABL & 262144) == 0 && ((ABL & 64) == 0 || decltype(ic)::value % 2 == 0) && ((ABL & 128) == 0 || decltype(ic)::value % 4 == 0);                               // (deferred groups are stored before the next E1)
         if constexpr (stores_now) gang_arrive();
-        if constexpr (VALU) fftA_stage2_group<8, 8, true, g>(z);                              // rows g + 8e at positions 8g + e
+        if constexpr (VALU) xfftA_stage2_group<8, 8, true, g>(z);                              // rows g + 8e at positions 8g + e
         if constexpr (FEN) xpin8<8 * g, 1>(z);
         swap_group(std::integral_constant<int, g>{});
         if constexpr (stores_now) gang_await(members);

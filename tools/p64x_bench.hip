@@ -14,42 +14,6 @@
 #include <cstdint>
 #include "../fft_amd/csrc/kernel_regtile64p.h"
 #include "p64x.h"
-namespace sfft { struct YRegtileArgs : RegtileArgs { unsigned* trace32; }; }
-#define P64Y_NS y0
-#define P64Y_FLAGS 0
-#include "p64y.h"
-#undef P64Y_NS
-#undef P64Y_FLAGS
-#define P64Y_NS y1
-#define P64Y_FLAGS 1
-#include "p64y.h"
-#undef P64Y_NS
-#undef P64Y_FLAGS
-#define P64Y_NS y2
-#define P64Y_FLAGS 2
-#include "p64y.h"
-#undef P64Y_NS
-#undef P64Y_FLAGS
-#define P64Y_NS y4
-#define P64Y_FLAGS 4
-#include "p64y.h"
-#undef P64Y_NS
-#undef P64Y_FLAGS
-#define P64Y_NS y8
-#define P64Y_FLAGS 8
-#include "p64y.h"
-#undef P64Y_NS
-#undef P64Y_FLAGS
-#define P64Y_NS y15
-#define P64Y_FLAGS 15
-#include "p64y.h"
-#undef P64Y_NS
-#undef P64Y_FLAGS
-#define P64Y_NS ys
-#define P64Y_FLAGS 16
-#include "p64y.h"
-#undef P64Y_NS
-#undef P64Y_FLAGS
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 using namespace sfft;
 
@@ -172,6 +136,19 @@ int main(int argc, char** argv) {
                                     make(spectre_mix_p64x<3, 3, 0, true, false, false, false, 1>, t, 48)(); CK(hipDeviceSynchronize()); CK(hipFree(tr)); });
   }
 
+  // bf16 rows in (and out): the same values rounded to bf16, in the first half of a second buffer
+  uint16_t* vb16; CK(hipMalloc(&vb16, (size_t)B * N * D * 2));
+  {
+    std::vector<float> hf(1 << 22); std::vector<uint16_t> hb(1 << 22);
+    for (size_t off = 0; off < (size_t)B * N * D; off += hf.size()) {
+      const size_t cnt = std::min(hf.size(), (size_t)B * N * D - off);
+      CK(hipMemcpy(hf.data(), v + off, cnt * 4, hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < cnt; ++i) { uint32_t x; memcpy(&x, &hf[i], 4); hb[i] = (uint16_t)((x + 0x7fffu + ((x >> 16) & 1u)) >> 16); }
+      CK(hipMemcpy(vb16 + off, hb.data(), cnt * 2, hipMemcpyHostToDevice));
+    }
+  }
+  RegtileArgs lb = la; lb.v = vb16;                      // bf16 in, fp32 out (gangs of 4 workgroups: n_wg stays 256)
+  RegtileArgs lbb = lb; lbb.out = out_ref;               // bf16 in, bf16 out
   std::vector<Variant> vs;
   auto add = [&](const char* name, std::function<void()> f) { vs.push_back({name, f, {}, false}); };
   add("baseline (3,3)", make(spectre_mix_p64x<3, 3, 0, true>, a, 48));
@@ -183,26 +160,42 @@ int main(int argc, char** argv) {
   add("early Wre KB0=0 + late E1 barrier + Wim by columns", make(spectre_mix_p64x<3, 3, 0, true, false, false, false, 56, 0>, a, 48));
   add("LIBRARY kernel_regtile64p.h <3,3> (3rd slot)", lib(la));
   add("LIBRARY launched with 512 more bytes of LDS", lib_biglds(la));
-  {
-    YRegtileArgs ya{}; static_cast<RegtileArgs&>(ya) = la; ya.trace32 = nullptr;
-    CK(hipFuncSetAttribute((const void*)y0::spectre_mix_regtile64p<3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
-    add("LIBRARY copy p64y.h flags 0", [=] { hipLaunchKernelGGL((y0::spectre_mix_regtile64p<3, 3>), dim3(ya.n_wg), dim3(512), y0::kP64LdsTotal, 0, ya); });
-    CK(hipFuncSetAttribute((const void*)y1::spectre_mix_regtile64p<3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
-    add("LIBRARY copy p64y.h flags 1", [=] { hipLaunchKernelGGL((y1::spectre_mix_regtile64p<3, 3>), dim3(ya.n_wg), dim3(512), y0::kP64LdsTotal, 0, ya); });
-    add("early Wre KB0=0 + late E1 barrier (after flags 1)", make(spectre_mix_p64x<3, 3, 0, true, false, false, false, 24, 0>, a, 48));
-    CK(hipFuncSetAttribute((const void*)y2::spectre_mix_regtile64p<3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
-    add("LIBRARY copy p64y.h flags 2", [=] { hipLaunchKernelGGL((y2::spectre_mix_regtile64p<3, 3>), dim3(ya.n_wg), dim3(512), y0::kP64LdsTotal, 0, ya); });
-    add("early Wre KB0=0 + late E1 barrier (after flags 2)", make(spectre_mix_p64x<3, 3, 0, true, false, false, false, 24, 0>, a, 48));
-    CK(hipFuncSetAttribute((const void*)y4::spectre_mix_regtile64p<3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
-    add("LIBRARY copy p64y.h flags 4", [=] { hipLaunchKernelGGL((y4::spectre_mix_regtile64p<3, 3>), dim3(ya.n_wg), dim3(512), y0::kP64LdsTotal, 0, ya); });
-    add("early Wre KB0=0 + late E1 barrier (after flags 4)", make(spectre_mix_p64x<3, 3, 0, true, false, false, false, 24, 0>, a, 48));
-    CK(hipFuncSetAttribute((const void*)y8::spectre_mix_regtile64p<3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
-    add("LIBRARY copy p64y.h flags 8", [=] { hipLaunchKernelGGL((y8::spectre_mix_regtile64p<3, 3>), dim3(ya.n_wg), dim3(512), y0::kP64LdsTotal, 0, ya); });
-    add("early Wre KB0=0 + late E1 barrier (after flags 8)", make(spectre_mix_p64x<3, 3, 0, true, false, false, false, 24, 0>, a, 48));
-    CK(hipFuncSetAttribute((const void*)y15::spectre_mix_regtile64p<3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
-    add("LIBRARY copy p64y.h flags 15", [=] { hipLaunchKernelGGL((y15::spectre_mix_regtile64p<3, 3>), dim3(ya.n_wg), dim3(512), y0::kP64LdsTotal, 0, ya); });
-    add("early Wre KB0=0 + late E1 barrier (after flags 15)", make(spectre_mix_p64x<3, 3, 0, true, false, false, false, 24, 0>, a, 48));
-  }
+  CK(hipFuncSetAttribute((const void*)spectre_mix_regtile64p<4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+  add("LIBRARY <4,3>", [=] { hipLaunchKernelGGL((spectre_mix_regtile64p<4, 3>), dim3(la.n_wg), dim3(512), kP64LdsTotal, 0, la); });
+  CK(hipFuncSetAttribute((const void*)spectre_mix_regtile64p<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+  add("LIBRARY <3,2>", [=] { hipLaunchKernelGGL((spectre_mix_regtile64p<3, 2>), dim3(la.n_wg), dim3(512), kP64LdsTotal, 0, la); });
+  CK(hipFuncSetAttribute((const void*)spectre_mix_regtile64p<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+  add("LIBRARY <4,2>", [=] { hipLaunchKernelGGL((spectre_mix_regtile64p<4, 2>), dim3(la.n_wg), dim3(512), kP64LdsTotal, 0, la); });
+  CK(hipFuncSetAttribute((const void*)spectre_mix_regtile64p<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+  add("LIBRARY <4,1>", [=] { hipLaunchKernelGGL((spectre_mix_regtile64p<4, 1>), dim3(la.n_wg), dim3(512), kP64LdsTotal, 0, la); });
+  CK(hipFuncSetAttribute((const void*)spectre_mix_regtile64p<8, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+  add("LIBRARY bf16 -> f32 <8,0>", [=] { hipLaunchKernelGGL((spectre_mix_regtile64p<8, 0, false, true>), dim3(lb.n_wg), dim3(512), kP64LdsTotal, 0, lb); });
+  CK(hipFuncSetAttribute((const void*)spectre_mix_regtile64p<8, 0, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+  add("LIBRARY bf16 -> bf16 <8,0>", [=] { hipLaunchKernelGGL((spectre_mix_regtile64p<8, 0, false, true, true>), dim3(lbb.n_wg), dim3(512), kP64LdsTotal, 0, lbb); });
+  CK(hipFuncSetAttribute((const void*)spectre_mix_regtile64p<6, 2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+  add("LIBRARY bf16 -> f32 <6,2>", [=] { hipLaunchKernelGGL((spectre_mix_regtile64p<6, 2, false, true>), dim3(lb.n_wg), dim3(512), kP64LdsTotal, 0, lb); });
+  CK(hipFuncSetAttribute((const void*)spectre_mix_regtile64p<6, 2, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+  add("LIBRARY bf16 -> bf16 <6,2>", [=] { hipLaunchKernelGGL((spectre_mix_regtile64p<6, 2, false, true, true>), dim3(lbb.n_wg), dim3(512), kP64LdsTotal, 0, lbb); });
+  CK(hipFuncSetAttribute((const void*)spectre_mix_regtile64p<6, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+  add("LIBRARY bf16 -> f32 <6,0>", [=] { hipLaunchKernelGGL((spectre_mix_regtile64p<6, 0, false, true>), dim3(lb.n_wg), dim3(512), kP64LdsTotal, 0, lb); });
+  CK(hipFuncSetAttribute((const void*)spectre_mix_regtile64p<6, 0, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+  add("LIBRARY bf16 -> bf16 <6,0>", [=] { hipLaunchKernelGGL((spectre_mix_regtile64p<6, 0, false, true, true>), dim3(lbb.n_wg), dim3(512), kP64LdsTotal, 0, lbb); });
+  CK(hipFuncSetAttribute((const void*)spectre_mix_regtile64p<4, 2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+  add("LIBRARY bf16 -> f32 <4,2>", [=] { hipLaunchKernelGGL((spectre_mix_regtile64p<4, 2, false, true>), dim3(lb.n_wg), dim3(512), kP64LdsTotal, 0, lb); });
+  CK(hipFuncSetAttribute((const void*)spectre_mix_regtile64p<4, 2, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+  add("LIBRARY bf16 -> bf16 <4,2>", [=] { hipLaunchKernelGGL((spectre_mix_regtile64p<4, 2, false, true, true>), dim3(lbb.n_wg), dim3(512), kP64LdsTotal, 0, lbb); });
+  CK(hipFuncSetAttribute((const void*)spectre_mix_regtile64p<3, 3, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+  add("LIBRARY bf16 -> f32 <3,3>", [=] { hipLaunchKernelGGL((spectre_mix_regtile64p<3, 3, false, true>), dim3(lb.n_wg), dim3(512), kP64LdsTotal, 0, lb); });
+  CK(hipFuncSetAttribute((const void*)spectre_mix_regtile64p<3, 3, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+  add("LIBRARY bf16 -> bf16 <3,3>", [=] { hipLaunchKernelGGL((spectre_mix_regtile64p<3, 3, false, true, true>), dim3(lbb.n_wg), dim3(512), kP64LdsTotal, 0, lbb); });
+  CK(hipFuncSetAttribute((const void*)spectre_mix_regtile64p<7, 1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+  add("LIBRARY bf16 -> f32 <7,1>", [=] { hipLaunchKernelGGL((spectre_mix_regtile64p<7, 1, false, true>), dim3(lb.n_wg), dim3(512), kP64LdsTotal, 0, lb); });
+  CK(hipFuncSetAttribute((const void*)spectre_mix_regtile64p<7, 1, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+  add("LIBRARY bf16 -> bf16 <7,1>", [=] { hipLaunchKernelGGL((spectre_mix_regtile64p<7, 1, false, true, true>), dim3(lbb.n_wg), dim3(512), kP64LdsTotal, 0, lbb); });
+  add("LIBRARY <3,3> again", lib(la));
+  add("early Wre KB0=0 + late E1 barrier (5th slot)", make(spectre_mix_p64x<3, 3, 0, true, false, false, false, 24, 0>, a, 48));
+  add("early+late, stores dropped", make(spectre_mix_p64x<3, 3, 256, true, false, false, false, 24, 0>, a, 48));
+  add("early+late, loads answered with 0", make(spectre_mix_p64x<3, 3, 512, true, false, false, false, 24, 0>, a, 48));
   add("early Wre KB0=0 + late E1 barrier (4th slot)", make(spectre_mix_p64x<3, 3, 0, true, false, false, false, 24, 0>, a, 48));
   { RegtileArgs x = la; x.rows_in = 0; x.rows_out = 0; add("LIBRARY, no traffic (rows_in = rows_out = 0)", lib(x)); }
   { RegtileArgs x = la; x.rows_out = 0; add("LIBRARY, stores dropped (rows_out = 0)", lib(x)); }
@@ -230,6 +223,8 @@ int main(int argc, char** argv) {
     for (int r = 0; r < 4; ++r) for (auto& x : keep) { x.launch(); CK(hipDeviceSynchronize()); }
     return 0;
   }
+  const bool tl_only = argc > 1 && !strcmp(argv[1], "tl");
+  if (tl_only) vs.clear();
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (auto& x : vs) { x.launch(); x.launch(); }
   CK(hipDeviceSynchronize());
@@ -248,16 +243,12 @@ int main(int argc, char** argv) {
   }
   fflush(stdout);
 
-  {
-    YRegtileArgs ya{}; static_cast<RegtileArgs&>(ya) = la;
-    CK(hipFuncSetAttribute((const void*)ys::spectre_mix_regtile64p<3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
-    timeline_run("LIBRARY copy (p64y.h, stamped)", Geo{ya.n_wg, ya.n_tiles}, 48, [=](unsigned* tr) { YRegtileArgs x = ya; x.trace32 = tr;
-                 hipLaunchKernelGGL((ys::spectre_mix_regtile64p<3, 3>), dim3(x.n_wg), dim3(512), kLds, 0, x); });
-    timeline("early Wre KB0=0 + late E1 barrier (stamped)", spectre_mix_p64x<3, 3, 0, true, false, false, false, 25, 0>, a, 48);
-    YRegtileArgs yb = ya; yb.rows_in = 0; yb.rows_out = 0;
-    timeline_run("LIBRARY copy (p64y.h, stamped), no traffic", Geo{ya.n_wg, ya.n_tiles}, 48, [=](unsigned* tr) { YRegtileArgs x = yb; x.trace32 = tr;
-                 hipLaunchKernelGGL((ys::spectre_mix_regtile64p<3, 3>), dim3(x.n_wg), dim3(512), kLds, 0, x); });
-    timeline("early Wre KB0=0 + late E1 barrier (stamped), no traffic", spectre_mix_p64x<3, 3, 768, true, false, false, false, 25, 0>, a, 48);
+  if (argc > 1 && !strcmp(argv[1], "tl")) {
+    timeline("early+late (stamped), no traffic", spectre_mix_p64x<3, 3, 768, true, false, false, false, 25, 0>, a, 48);
+    timeline("early+late (stamped), loads only (stores dropped)", spectre_mix_p64x<3, 3, 256, true, false, false, false, 25, 0>, a, 48);
+    timeline("early+late (stamped), stores only (loads answered with 0)", spectre_mix_p64x<3, 3, 512, true, false, false, false, 25, 0>, a, 48);
+    timeline("early+late (stamped), everything", spectre_mix_p64x<3, 3, 0, true, false, false, false, 25, 0>, a, 48);
+    return 0;
   }
   timeline("baseline (3,3)", spectre_mix_p64x<3, 3, 0, true, false, false, false, 1>, a, 48);
   timeline("baseline (3,3), no traffic", spectre_mix_p64x<3, 3, 768, true, false, false, false, 1>, a, 48);
