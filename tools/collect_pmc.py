@@ -4,10 +4,11 @@ half the bytes of a wide coalesced streaming read (MI355X_MICROARCH.md, section 
 import csv, glob, json, os, sys
 
 root, io, shape = sys.argv[1], sys.argv[2], [int(x) for x in sys.argv[3].split(",")]
+want = sys.argv[4] if len(sys.argv) > 4 else "spectre_mix"          # substring of the kernel name the counters are taken from
 vals, kname = {}, None
 for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        if "spectre_mix" in r["Kernel_Name"] and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+        if want in r["Kernel_Name"] and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
             vals.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
             kname = r["Kernel_Name"].split("(")[0][:80]
 fetch = sum(vals["FETCH_SIZE"]) / len(vals["FETCH_SIZE"])

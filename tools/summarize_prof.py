@@ -9,13 +9,13 @@ print(f"# rocprofv3 summary for {root}")
 for f in find("*kernel_stats.csv"):
     print(f"\n## kernel stats ({os.path.relpath(f, root)})")
     for i, row in enumerate(csv.reader(open(f))):
-        if i < 8:
-            print(", ".join(c[:70] for c in row))
+        if i < 16:
+            print(", ".join(c[:100] for c in row))
 for f in find("*kernel_trace.csv"):
     rows = list(csv.DictReader(open(f)))
     by = collections.defaultdict(list)
     for r in rows:
-        by[r["Kernel_Name"][:60]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        by[r["Kernel_Name"][:96]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     print(f"\n## kernel trace durations (us) ({os.path.relpath(f, root)})")
     for k, v in by.items():
         v2 = sorted(v)
@@ -27,7 +27,7 @@ for f in find("*counter_collection.csv"):
     rows = list(csv.DictReader(open(f)))
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in rows:
-        agg[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        agg[r["Kernel_Name"][:96]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     print(f"\n## counters ({os.path.relpath(f, root)})  [per-dispatch average]")
     for k, cs in agg.items():
         if "spectre" not in k and "tile" not in k:
