@@ -493,7 +493,7 @@ hipError_t launch_regtile(const RegtileArgs& a, bool in_bf16, bool out_bf16, int
   template <>                                                                                                \
   hipError_t launch_regtile<RF_, RS_>(const RegtileArgs& a, bool in_bf16, bool out_bf16, int mode,           \
                                       hipStream_t stream) {                                                  \
-    if (mode != 0 && in_bf16 != out_bf16) return hipErrorInvalidValue;   /* built for the fast mode only */  \
+    if (mode != 0 && !in_bf16 && out_bf16) return hipErrorInvalidValue;   /* f32 -> bf16: fast mode only */   \
     const dim3 grid(a.n_wg), block(regtile_threads<RF_, RS_>());                                             \
     const size_t lds = regtile_lds_total<RF_, RS_>();                                                        \
     const int key = (in_bf16 ? 16 : 0) | (out_bf16 ? 8 : 0) | mode;                                          \
@@ -518,6 +518,10 @@ hipError_t launch_regtile(const RegtileArgs& a, bool in_bf16, bool out_bf16, int
       case 4: return go(spectre_mix_regtile<RF_, RS_, false, false, 4>);                                     \
       case 8: return go(spectre_mix_regtile<RF_, RS_, false, true, 0>);                                      \
       case 16: return go(spectre_mix_regtile<RF_, RS_, true, false, 0>);                                     \
+      case 17: return go(spectre_mix_regtile<RF_, RS_, true, false, 1>);   /* bf16 rows in, fp32 rows out   */ \
+      case 18: return go(spectre_mix_regtile<RF_, RS_, true, false, 2>);   /* (activations under autocast): */ \
+      case 19: return go(spectre_mix_regtile<RF_, RS_, true, false, 3>);   /* every mode, not only the fast */ \
+      case 20: return go(spectre_mix_regtile<RF_, RS_, true, false, 4>);   /* one                           */ \
       case 24: return go(spectre_mix_regtile<RF_, RS_, true, true, 0>);                                      \
       case 25: return go(spectre_mix_regtile<RF_, RS_, true, true, 1>);                                      \
       case 26: return go(spectre_mix_regtile<RF_, RS_, true, true, 2>);                                      \

@@ -246,6 +246,9 @@ hipError_t launch_regtile_mixed(const RegtileArgs& a, bool in_bf16, bool out_bf1
       case 3: return go(spectre_mix_regtile_mixed<RF_, RS_, false, false, 3>);                               \
       case 4: return go(spectre_mix_regtile_mixed<RF_, RS_, false, true, 0>);                                \
       case 8: return go(spectre_mix_regtile_mixed<RF_, RS_, true, false, 0>);                                \
+      case 9: return go(spectre_mix_regtile_mixed<RF_, RS_, true, false, 1>);   /* bf16 in, fp32 out in     */ \
+      case 10: return go(spectre_mix_regtile_mixed<RF_, RS_, true, false, 2>);  /* every mode               */ \
+      case 11: return go(spectre_mix_regtile_mixed<RF_, RS_, true, false, 3>);                               \
       case 12: return go(spectre_mix_regtile_mixed<RF_, RS_, true, true, 0>);                                \
       case 13: return go(spectre_mix_regtile_mixed<RF_, RS_, true, true, 1>);                                \
       case 14: return go(spectre_mix_regtile_mixed<RF_, RS_, true, true, 2>);                                \

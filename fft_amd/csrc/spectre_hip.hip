@@ -355,7 +355,10 @@ int choose(const SpectreMixArgs* a, const Plan* plan, Choice* c) {
                    a->v_sn % 4 == 0 && a->v_sb % 4 == 0 && a->out_sn % 4 == 0 && a->out_sb % 4 == 0 &&
                    a->v_sn * 4096 * 4 + 64 < ((int64_t)1 << 32) && a->out_sn * 4096 * 4 + 64 < ((int64_t)1 << 32);
   bool can = can_regtile;
-  if (can && mode != 0 && a->in_dtype != a->out_dtype && !pipelined_ok) {   // differing storage dtypes are built for the fast mode only
+  // differing storage dtypes outside the fast mode: bf16 rows in / fp32 rows out (activations under autocast, padded or ragged shapes) is
+  // built for the five power-of-two lengths and for 3000; f32 -> bf16 and the secondary lengths take the general path
+  const bool mixed_io_modes = in_bf && !out_bf && ts && !ts->same_dtype && ts->tile_ch == 16;
+  if (can && mode != 0 && a->in_dtype != a->out_dtype && !pipelined_ok && !mixed_io_modes) {
     c->why_not_regtile = "storage dtypes differ (built for the fast mode only)";
     can = false;
     if (a->algo == SPECTRE_ALGO_REGTILE) return fail(SPECTRE_E_UNSUPPORTED, "register-tile kernel not applicable: %s", c->why_not_regtile);

@@ -279,17 +279,34 @@ def test_in_place_is_allowed(n_fft):
     assert torch.equal(Vd, want)
 
 
-def test_differing_storage_dtypes_outside_the_fast_mode_take_the_general_path():
-    """bf16 -> f32 (or f32 -> bf16) is built into the register-tile kernels for the fast mode only; a padded sequence
-    with differing dtypes must still work (LDS Stockham path) and say so."""
-    V, gate, _ = _problem(31, 2, 1000, 32, 2, 1024, dtype=torch.bfloat16)
-    d = _describe(V.to(DEV), gate.to(DEV), None, 1024, out_dtype=torch.float32)
-    assert d.startswith("stockham") and "storage dtypes differ" in d
-    y = _mix(V.to(DEV), gate.to(DEV), None, 1024, out_dtype=torch.float32)
+@pytest.mark.parametrize("B,N,D,G,n_fft,mem", [(2, 1000, 32, 2, 1024, False), (3, 200, 48, 3, 256, False), (2, 500, 32, 2, 512, True), (2, 2000, 64, 4, 2048, False),
+                                               (2, 4000, 40, 5, 4096, False), (2, 4096, 24, 3, 4096, True), (2, 2900, 32, 2, 3000, False), (2, 3000, 40, 5, 3000, False)])
+def test_bf16_in_f32_out_outside_the_fast_mode_runs_on_the_register_tile_kernels(B, N, D, G, n_fft, mem):
+    """Activations under autocast (bf16 rows in, fp32 rows out) with a padded sequence, a ragged group width or memory_fft: round 2 built
+    the differing storage dtypes for the fast mode only and dropped to the 4x slower LDS Stockham path otherwise."""
+    V, gate, memory = _problem(31 + n_fft, B, N, D, G, n_fft, dtype=torch.bfloat16, mem=mem)
+    md = None if memory is None else memory.to(DEV)
+    d = _describe(V.to(DEV), gate.to(DEV), md, n_fft, out_dtype=torch.float32)
+    assert d.startswith("regtile") and "in=bf16 out=f32" in d, d
+    y = _mix(V.to(DEV), gate.to(DEV), md, n_fft, out_dtype=torch.float32)
     assert y.dtype == torch.float32
-    assert_close(y.cpu().numpy(), _oracle(V, gate, None, 1024), what="bf16 -> f32, padded")
+    assert_close(y.cpu().numpy(), _oracle(V, gate, memory, n_fft), what=f"bf16 -> f32, {d}")
+    # the same arithmetic on the general path
+    ys = _mix(V.to(DEV), gate.to(DEV), md, n_fft, out_dtype=torch.float32, algo="stockham")
+    assert_close(y.cpu().numpy(), ys.cpu().numpy(), what="register tile vs stockham")
+
+
+def test_f32_in_bf16_out_outside_the_fast_mode_still_takes_the_general_path():
+    """The opposite pairing (fp32 rows in, bf16 rows out) is built for the fast mode only; a padded sequence must still work and say so."""
+    V, gate, _ = _problem(33, 2, 1000, 32, 2, 1024)
+    d = _describe(V.to(DEV), gate.to(DEV), None, 1024, out_dtype=torch.bfloat16)
+    assert d.startswith("stockham") and "storage dtypes differ" in d
+    y = _mix(V.to(DEV), gate.to(DEV), None, 1024, out_dtype=torch.bfloat16)
+    assert y.dtype == torch.bfloat16
+    ref = torch.from_numpy(_oracle(V, gate, None, 1024)).bfloat16().float().numpy()
+    assert_close(y.float().cpu().numpy(), ref, rtol=1e-2, atol_rms=1e-2, what="f32 -> bf16, padded")
     with pytest.raises(NotImplementedError, match="storage dtypes differ"):
-        _mix(V.to(DEV), gate.to(DEV), None, 1024, out_dtype=torch.float32, algo="regtile")
+        _mix(V.to(DEV), gate.to(DEV), None, 1024, out_dtype=torch.bfloat16, algo="regtile")
 
 
 def test_concurrent_streams():
