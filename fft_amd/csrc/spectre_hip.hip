@@ -181,6 +181,11 @@ struct Plan {
 
 std::mutex g_mu;
 std::map<std::pair<int, int64_t>, std::unique_ptr<Plan>> g_plans;
+// Plans taken out of service by spectre_plan_destroy.  They are NOT freed: a launch path uses its plan (host object and device tables)
+// after the registry lock is released, and a kernel reads the tables until it retires, so freeing here would be a use-after-free the
+// library cannot see coming (round 2 documented it as a contract; round 3 removes it).  A retired plan costs a few tens of KiB, is put
+// back into service by the next spectre_plan_create / launch for the same (device, n_fft), and is released at process exit.
+std::map<std::pair<int, int64_t>, std::unique_ptr<Plan>> g_retired;
 
 bool factorize(int64_t n, std::vector<int>& out) {
   out.clear();
@@ -267,14 +272,21 @@ int build_plan(int device, int64_t n, Plan** out) {
   return SPECTRE_OK;
 }
 
-// Plans live until spectre_plan_destroy, which must not run concurrently with a launch that uses the same (device, n_fft):
-// the launch paths keep the raw pointer after the mutex is released (documented in include/spectre_hip.h).
+// The launch paths keep the raw pointer after the mutex is released: plans are therefore never freed while the process lives —
+// spectre_plan_destroy retires them (g_retired above).
 // Building a plan allocates and copies synchronously, which would invalidate a stream capture: refuse instead of corrupting
 // the capture (the caller creates the plan first with spectre_plan_create or one eager call).
 int get_plan(int device, int64_t n, Plan** out, hipStream_t stream = nullptr) {
   std::lock_guard<std::mutex> lk(g_mu);
   auto it = g_plans.find({device, n});
   if (it != g_plans.end()) { *out = it->second.get(); return SPECTRE_OK; }
+  auto rt = g_retired.find({device, n});
+  if (rt != g_retired.end()) {                     // destroyed earlier: the tables are still there
+    *out = rt->second.get();
+    g_plans[{device, n}] = std::move(rt->second);
+    g_retired.erase(rt);
+    return SPECTRE_OK;
+  }
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (stream && hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
     return fail(SPECTRE_E_INVALID, "no plan for n_fft=%lld on device %d yet and the stream is capturing: call spectre_plan_create "
@@ -536,6 +548,7 @@ int spectre_plan_destroy(int device, int64_t n_fft) {
   std::lock_guard<std::mutex> lk(g_mu);
   auto it = g_plans.find({device, n_fft});
   if (it == g_plans.end()) return fail(SPECTRE_E_INVALID, "no plan for device %d n_fft %lld", device, (long long)n_fft);
+  g_retired[{device, n_fft}] = std::move(it->second);   // out of service, not freed (see g_retired): safe against launches in flight
   g_plans.erase(it);
   return SPECTRE_OK;
 }

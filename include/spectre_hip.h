@@ -88,9 +88,9 @@ int spectre_mix_describe(const SpectreMixArgs* args, char* buf, size_t cap);
 
 /* Plans: twiddle tables (and Bluestein chirps) for one (device, n_fft).  spectre_mix_fwd creates and
  * caches them on demand; explicit creation lets a caller pay the one-time upload outside a timed or
- * graph-captured region.  Destroying a cached plan is allowed only when no launch using it is in flight AND no
- * other thread is inside a spectre_* call for the same (device, n_fft): the launch paths use the plan after the
- * registry lock is released (not thread-safe against destroy, by contract).  A call on a CAPTURING stream whose plan
+ * graph-captured region.  spectre_plan_destroy takes the plan out of service; it is safe at any time, also while launches that
+ * use the plan are in flight or other threads are inside spectre_* calls for the same (device, n_fft): the tables are retired, not
+ * freed (a few tens of KiB, reused by the next create / launch for that length, released at process exit).  A call on a CAPTURING stream whose plan
  * does not exist yet returns SPECTRE_E_INVALID instead of building it (the upload would invalidate the capture). */
 int spectre_plan_create(int device, int64_t n_fft);
 int spectre_plan_destroy(int device, int64_t n_fft);

@@ -6,6 +6,7 @@ import subprocess
 import sys
 
 import pytest
+import torch
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,3 +18,30 @@ def test_random_shapes_repeatable_and_equal_to_oracle(seed):
     assert r.returncode == 0, r.stderr[-2000:]
     assert "STRESS OK" in r.stdout, r.stdout[-3000:]
     assert r.stdout.count("\nok  ") + r.stdout.startswith("ok  ") == 60
+
+
+def test_plan_destroy_while_launches_are_in_flight_is_safe():
+    """Round 2 documented spectre_plan_destroy racing a launch as a use-after-free by contract; plans are now retired, not freed: destroy
+    right behind asynchronous launches (the kernels are still reading the twiddle table), keep launching, compare with an undisturbed run."""
+    import ctypes
+    from fft_amd import _native, spectral_mix
+    lib = _native.load()
+    dev = torch.device("cuda:0")
+    V = torch.randn(48, 4096, 64, device=dev)
+    gate = torch.randn(48, 4, 2049, dtype=torch.complex64, device=dev) * 0.3
+    want = spectral_mix(V, gate, None, 4096).clone()
+    torch.cuda.synchronize()
+    outs = []
+    for i in range(12):
+        outs.append(spectral_mix(V, gate, None, 4096))                    # asynchronous
+        rc = lib.spectre_plan_destroy(dev.index or 0, ctypes.c_int64(4096))
+        assert rc == 0, lib.spectre_last_error()
+        if i % 3 == 0:
+            assert lib.spectre_plan_create(dev.index or 0, ctypes.c_int64(4096)) == 0
+    torch.cuda.synchronize()
+    for y in outs:
+        assert torch.equal(y, want)
+    assert lib.spectre_plan_destroy(dev.index or 0, ctypes.c_int64(4096)) != 0   # the last iteration left nothing in service: reported, not fatal
+    assert lib.spectre_plan_create(dev.index or 0, ctypes.c_int64(4096)) == 0     # back in service (the retired tables, no upload)
+    assert lib.spectre_plan_destroy(dev.index or 0, ctypes.c_int64(4096)) == 0
+    assert torch.equal(spectral_mix(V, gate, None, 4096), want)                 # and the next call puts it back
