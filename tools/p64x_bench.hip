@@ -192,6 +192,10 @@ int main(int argc, char** argv) {
   add("LIBRARY bf16 -> f32 <7,1>", [=] { hipLaunchKernelGGL((spectre_mix_regtile64p<7, 1, false, true>), dim3(lb.n_wg), dim3(512), kP64LdsTotal, 0, lb); });
   CK(hipFuncSetAttribute((const void*)spectre_mix_regtile64p<7, 1, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
   add("LIBRARY bf16 -> bf16 <7,1>", [=] { hipLaunchKernelGGL((spectre_mix_regtile64p<7, 1, false, true, true>), dim3(lbb.n_wg), dim3(512), kP64LdsTotal, 0, lbb); });
+  add("exp early+late (4,2)", make(spectre_mix_p64x<4, 2, 0, true, false, false, false, 24, 0>, a, 48));
+  add("exp early+late (4,3)", make(spectre_mix_p64x<4, 3, 0, true, false, false, false, 24, 0>, a, 48));
+  add("exp early+late (4,1)", make(spectre_mix_p64x<4, 1, 0, true, false, false, false, 24, 0>, a, 48));
+  add("LIBRARY <4,2> (2nd slot)", [=] { hipLaunchKernelGGL((spectre_mix_regtile64p<4, 2>), dim3(la.n_wg), dim3(512), kP64LdsTotal, 0, la); });
   add("LIBRARY <3,3> again", lib(la));
   add("early Wre KB0=0 + late E1 barrier (5th slot)", make(spectre_mix_p64x<3, 3, 0, true, false, false, false, 24, 0>, a, 48));
   add("early+late, stores dropped", make(spectre_mix_p64x<3, 3, 256, true, false, false, false, 24, 0>, a, 48));
@@ -222,6 +226,23 @@ int main(int argc, char** argv) {
       if (x.name == "LIBRARY kernel_regtile64p.h <3,3>" || x.name == "early Wre KB0=0 + late E1 barrier (2nd slot)" || x.name == "baseline (3,3)") keep.push_back(x);
     for (int r = 0; r < 4; ++r) for (auto& x : keep) { x.launch(); CK(hipDeviceSynchronize()); }
     return 0;
+  }
+  if (argc > 3 && !strcmp(argv[1], "loop")) {   // tools/power_probe.sh: run ONE variant back to back for argv[3] seconds (power / clock sampling from outside)
+    for (auto& x : vs)
+      if (x.name == argv[2]) {
+        const double secs = atof(argv[3]);
+        hipEvent_t l0, l1; CK(hipEventCreate(&l0)); CK(hipEventCreate(&l1));
+        int launches = 0; float total = 0;
+        while (total < secs * 1e3f) {
+          CK(hipEventRecord(l0));
+          for (int i = 0; i < 50; ++i) x.launch();
+          CK(hipEventRecord(l1)); CK(hipEventSynchronize(l1));
+          float ms; CK(hipEventElapsedTime(&ms, l0, l1)); total += ms; launches += 50;
+        }
+        printf("loop \"%s\": %d launches, %.4f ms per launch\n", argv[2], launches, total / launches);
+        return 0;
+      }
+    fprintf(stderr, "no variant named \"%s\"\n", argv[2]); return 1;
   }
   const bool tl_only = argc > 1 && !strcmp(argv[1], "tl");
   if (tl_only) vs.clear();
