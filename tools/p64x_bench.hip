@@ -223,8 +223,9 @@ int main(int argc, char** argv) {
   if (argc > 1 && !strcmp(argv[1], "pair")) {   // for rocprofv3 --pmc: only the library kernel, the experimental equivalent and the round-2 baseline
     std::vector<Variant> keep;
     for (auto& x : vs)
-      if (x.name == "LIBRARY kernel_regtile64p.h <3,3>" || x.name == "early Wre KB0=0 + late E1 barrier (2nd slot)" || x.name == "baseline (3,3)") keep.push_back(x);
-    for (int r = 0; r < 4; ++r) for (auto& x : keep) { x.launch(); CK(hipDeviceSynchronize()); }
+      if (x.name == "LIBRARY <4,2>" || x.name == "LIBRARY <4,3>" || x.name == "LIBRARY <4,1>" || x.name == "exp early+late (4,3)" || x.name == "exp early+late (4,2)" ||
+          x.name == "exp early+late (4,1)" || x.name == "baseline (3,3)") keep.push_back(x);
+    for (int r = 0; r < 6; ++r) for (auto& x : keep) { for (int i = 0; i < 8; ++i) x.launch(); CK(hipDeviceSynchronize()); }
     return 0;
   }
   if (argc > 3 && !strcmp(argv[1], "loop")) {   // tools/power_probe.sh: run ONE variant back to back for argv[3] seconds (power / clock sampling from outside)
