@@ -1,4 +1,4 @@
-"""Persistent mixed-radix kernel (SPECTRE_MIXEDP_ALL=1) against the one-tile-per-workgroup kernel at (256, n, 768), plus a parity check."""
+"""Persistent mixed-radix kernels at (256, n, 768) plus a parity check; run again with SPECTRE_MIXEDP=0 for the one-tile-per-workgroup kernels."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,5 +1,5 @@
 """Development aid: persistent n_fft = 3000 kernel against the fp64 oracle (full, padded, truncated sequences, odd tile counts), then timing
-(SPECTRE_MIXEDP=0 in a second run = the one-tile-per-workgroup kernel; SPECTRE_MIXEDP_P = deferred row blocks)."""
+(SPECTRE_MIXEDP=0 in a second run = the one-tile-per-workgroup kernel)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -38,4 +38,4 @@ g = torch.randn(B, G, N // 2 + 1, device=dev, dtype=torch.complex64) * 0.3
 out = torch.empty_like(V)
 byt = B * N * D * 8 + B * G * (N // 2 + 1) * 8
 ms = min(time_kernel(V, g, None, N, out=out, warmup=3, iters=10) for _ in range(3))
-print(f"TIME (256,3000,768) f32: {ms:.3f} ms  {byt/ms/1e6:.0f} GB/s  frac={byt/ms/1e6/8000:.3f} [{describe(V, g, None, N)[:40]}] P={os.environ.get('SPECTRE_MIXEDP_P', '24')}")
+print(f"TIME (256,3000,768) f32: {ms:.3f} ms  {byt/ms/1e6:.0f} GB/s  frac={byt/ms/1e6/8000:.3f} [{describe(V, g, None, N)[:40]}]")
