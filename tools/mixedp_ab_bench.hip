@@ -13,6 +13,10 @@
 #include <algorithm>
 #include <cstdint>
 #include "../fft_amd/csrc/kernel_regtile_mixedp.h"
+#if __has_include("_old/mixedp_old.h")
+#include "_old/mixedp_old.h"      // a frozen copy of an earlier kernel, when one is being compared (not committed)
+#define HAVE_OLD 1
+#endif
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 using namespace sfft;
 struct Variant { std::string name; std::function<void()> launch; std::vector<float> ms; };
@@ -55,6 +59,23 @@ int main() {
   RegtileArgs l2l = a; l2l.v_sn = 16; l2l.v_sb = 0;                                       // loads from the L2, stores to HBM
   RegtileArgs l2s = a; l2s.out_sn = 16; l2s.out_sb = 0;                                   // loads from HBM, stores into the L2
   add("the product (loads from HBM, stores to HBM)", mk(k0, a));
+#ifdef HAVE_OLD
+  auto kold = spectre_mix_regtile_mixedp_old<RF, RS, 24>;
+  add("EARLIER kernel: the product", mk(kold, a));
+  add("EARLIER kernel: no loads, no stores", mk(kold, nn));
+  {
+    RegtileArgs ar = a; ar.out = ref;
+    mk(kold, ar)(); mk(k0, a)();
+    CK(hipDeviceSynchronize());
+    std::vector<float> ha(1 << 22), hb(1 << 22);
+    double worst = 0, rms = 0;
+    for (size_t off : {(size_t)0, n / 2, n - ha.size()}) {
+      CK(hipMemcpy(ha.data(), out + off, ha.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hb.data(), ref + off, hb.size() * 4, hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < ha.size(); ++i) { worst = std::max(worst, (double)fabsf(ha[i] - hb[i])); rms += (double)hb[i] * hb[i]; }
+    }
+    printf("new vs earlier kernel on 3 x 4M samples: max |diff| %.3e, rms %.3e\n", worst, sqrt(rms / (3.0 * ha.size())));
+  }
+#endif
   for (auto kv : {std::make_pair("ablation", k0)}) {
     std::string t = kv.first;
     add((t + ": no loads, no stores (VALU + LDS + barriers)").c_str(), mk(kv.second, nn));

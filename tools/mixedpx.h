@@ -1,45 +1,36 @@
-// kernel_regtile_mixedp.h — persistent, software-pipelined variant of kernel_regtile_mixed.h (n_fft = RF * RS, e.g. 3000 = 60 x 50) for
-// fp32 rows in and out, every 16-channel tile inside one gate group, any sequence length (rows >= N_in are the buffer instructions'
-// out-of-range case, as in kernel_regtile64p.h).  Same mathematics, same tile, same exchanges; replaces /root/reference/spectre.py:506,
-// :542-553.
-//
-// A mixed-radix tile needs 2 * max(RF, RS) data registers per thread (120 for 60 x 50) of the 256 a 400-thread workgroup may use, so —
-// unlike at n_fft = 4096, where the tile fills the register file — P row blocks can be DEFERRED the way kernel_regtile64p.h defers three
-// row groups: their results stay in 2 P registers through F1 of the next tile and are stored there (a quiet part of the tile), the same
-// registers then request those row blocks of the tile after, which trade places with the next results at the end of I2.  The other
-// RF - P row blocks are stored at the end of the tile and reloaded behind their stores.  One workgroup per CU walks through its tiles,
-// pairs of workgroups on adjacent tiles (one 128-byte line per row).  Everything learned there about hipcc's waits applies: LDS-only
-// barriers (a __syncthreads() would drain the deferred requests), every request unconditional (an empty buffer range when there is no
-// next / previous tile), the gate bins requested raw and fixed up at commit time, the twiddle bases requested BEFORE the deferred block.
+// mixedpx.h — a copy of fft_amd/csrc/kernel_regtile_mixedp.h (round 3) with its tidy-ups behind a template parameter, for
+// tools/mixedp_opt_bench.hip only (profiles/r03_mixedp_opt_matrix.log).  OPT bits: 1 = compile-time gate side, 2 = single ds_read_b32 with
+// immediate offsets, 4 = second write base beyond 64 KiB, 8 = the previous tile's output base recomputed instead of carried.  The library
+// kernel is OPT = 7.  Not part of the product.
 #pragma once
-#include "kernel_regtile_mixed.h"
+#include "../fft_amd/csrc/kernel_regtile_mixed.h"
 
 namespace sfft {
 
 // Bin k = u + RF*k2 (u < RF a lane quantity, k2 a compile-time one) against N/2: 0 = at or below for every u, 1 = above for every u
 // (the gate is conj(g[N - k]) there), 2 = depends on u (the one or two k2 that straddle N/2).
-template <int RF, int N> constexpr int mixed_gate_side(int k2) { return 2 * (RF - 1 + RF * k2) <= N ? 0 : (2 * RF * k2 > N ? 1 : 2); }
+template <int RF, int N> constexpr int xmixed_gate_side(int k2) { return 2 * (RF - 1 + RF * k2) <= N ? 0 : (2 * RF * k2 > N ? 1 : 2); }
 
-__device__ __forceinline__ void rt_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void xrt_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // One float of the exchange image, read by a single ds_read_b32 with an immediate offset.  hipcc pairs neighbouring reads into
 // ds_read2_b32, whose two results must sit in consecutive VGPRs — but x and y of one value already do (64-bit global loads and stores), so
 // every pair costs a v_mov (320 per tile at 60 x 50).  The wave's LDS queue has room for twice the instructions; the VALU does not have
-// room for the moves.  The result is not tracked by the compiler's s_waitcnt insertion: the caller reads behind rt_lds_barrier() (which
-// waits for lgkmcnt(0)) and then passes the values through mp_pin() so that no use is scheduled above that barrier.
+// room for the moves.  The result is not tracked by the compiler's s_waitcnt insertion: the caller reads behind xrt_lds_barrier() (which
+// waits for lgkmcnt(0)) and then passes the values through xmp_pin() so that no use is scheduled above that barrier.
 template <int OFF_BYTES>
-__device__ __forceinline__ float mp_lds_read(uint32_t addr) {
+__device__ __forceinline__ float xmp_lds_read(uint32_t addr) {
   static_assert(OFF_BYTES >= 0 && OFF_BYTES < 65536, "16-bit immediate");
   float v;
   asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF_BYTES));
   return v;
 }
-__device__ __forceinline__ void mp_pin1(float& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void xmp_pin1(float& x) { asm volatile("" : "+v"(x)); }
 template <int LO, int HI, bool IM, int NZ>
-__device__ __forceinline__ void mp_pin(float2 (&z)[NZ]) {
+__device__ __forceinline__ void xmp_pin(float2 (&z)[NZ]) {
   static_for<LO, HI>([&](auto ic) {
     constexpr int i = decltype(ic)::value;
-    if constexpr (IM) mp_pin1(z[i].y); else mp_pin1(z[i].x);
+    if constexpr (IM) xmp_pin1(z[i].y); else xmp_pin1(z[i].x);
   });
 }
 
@@ -47,8 +38,8 @@ __device__ __forceinline__ void mp_pin(float2 (&z)[NZ]) {
 //  multiplication, the image-freeing barrier moved in front of it or to the top of the tile: 1.87 / 1.89 ms against 1.59, and 1.24 against
 //  1.15 ms without memory traffic; profiles/r03_mixedp_ab.log.  The scattered ds_write_b32 between the multiplications cost more than the
 //  write phase they replace, and the earlier barrier exposes the slowest wave's loads.  Not kept.)
-template <int RF, int RS, int P, bool FIRST = false>
-__global__ void __launch_bounds__(kPC * (RF > RS ? RF : RS), 1) spectre_mix_regtile_mixedp(const RegtileArgs a) {
+template <int RF, int RS, int P, int OPT = 7, bool FIRST = false>
+__global__ void __launch_bounds__(kPC * (RF > RS ? RF : RS), 1) spectre_mix_regtile_mixedpx(const RegtileArgs a) {
   constexpr int D0 = FIRST ? 0 : RF - P;           // the deferred row blocks are [D0, D0 + P) of the order F1 uses them (the last ones: measured
                                                    // 1 % better than the first ones, 1.586 vs 1.605 ms)
   constexpr int N = RF * RS, NZ = mixed_team<RF, RS>(), NT = mixed_threads<RF, RS>();
@@ -153,9 +144,11 @@ __global__ void __launch_bounds__(kPC * (RF > RS ? RF : RS), 1) spectre_mix_regt
     tile_ptrs(tile, vb, ob, gp);
     const char* vbn = vb; char* obn = ob; const float2* gpn = gp;
     if (more) tile_ptrs(tile + 2, vbn, obn, gpn);
-    // (obp is carried across the back edge in VGPRs, so hipcc wraps each of the P deferred stores in a waterfall loop — v_readfirstlane,
-    //  v_cmp, s_and_saveexec.  Recomputing the pointer from tile - 2 removes the loops and is SLOWER, 1.6 % at 60 x 50 and 7 % at 64 x 40
-    //  (profiles/r03_mixedp_opt_matrix.log, OPT=8 against OPT=0): the loops pace the stores of the quiet part.  Left as hipcc emits it.)
+    if constexpr (OPT & 8) {                         // previous tile's output base recomputed instead of carried (no waterfall loops)
+      const char* vbp = vb; const float2* gpp = gp;
+      obp = ob;
+      if (it > 0) tile_ptrs(tile - 2, vbp, obp, gpp);
+    }
     const __amdgpu_buffer_rsrc_t rs_next = rsrc(vbn, v_sn, more ? a.rows_in : 0), rs_out = rsrc(ob, out_sn, a.rows_out),
                                  rs_prev = rsrc(obp, out_sn, it > 0 ? a.rows_out : 0);
     const uint32_t voff = rows ? (uint32_t)(((long long)u * v_sn + 2 * p) * 4) : 0x80000000u;
@@ -182,25 +175,26 @@ __global__ void __launch_bounds__(kPC * (RF > RS ? RF : RS), 1) spectre_mix_regt
 
     // ---- E1 (kernel_regtile_mixed.h); the first barrier also separates it from the previous tile's E2 reads ---------------
     // Writes: image rows beyond 64 KiB are addressed from a second lane constant (one v_add_u32 per write otherwise).  Reads: single
-    // ds_read_b32 (mp_lds_read), pinned behind the barrier that waits for them.
+    // ds_read_b32 (xmp_lds_read), pinned behind the barrier that waits for them.
     lds_float* const w_lo = lane_base(u * kPC + p);
     lds_float* const w_hi = lane_base(u * kPC + p + HI);
     const uint32_t r1 = (uint32_t)(uintptr_t)lane_base(u * ROW1 + p), r2 = (uint32_t)(uintptr_t)lane_base(u * ROW2 + p);
     auto wr = [&](auto offc, float v) {
       constexpr int off = decltype(offc)::value;
-      if constexpr (off * 4 + 4096 < 65536) w_lo[off] = v; else w_hi[off - HI] = v;
+      if constexpr (!(OPT & 4)) img[off + u * kPC + p] = v;
+      else if constexpr (off * 4 + 4096 < 65536) w_lo[off] = v; else w_hi[off - HI] = v;
     };
-    rt_lds_barrier();
+    xrt_lds_barrier();
     if (rows) static_for<0, RF>([&](auto kc) { constexpr int k1 = decltype(kc)::value; wr(std::integral_constant<int, k1 * ROW1>{}, z[out_pos<RF>(k1)].x); });
-    rt_lds_barrier();
-    if (bins) static_for<0, RS>([&](auto nc) { constexpr int n2 = decltype(nc)::value; z[n2].x = mp_lds_read<n2 * kPC * 4>(r1); });
-    rt_lds_barrier();
-    mp_pin<0, RS, false>(z);
+    xrt_lds_barrier();
+    if (bins) static_for<0, RS>([&](auto nc) { constexpr int n2 = decltype(nc)::value; if constexpr (OPT & 2) z[n2].x = xmp_lds_read<n2 * kPC * 4>(r1); else z[n2].x = img[u * ROW1 + n2 * kPC + p]; });
+    xrt_lds_barrier();
+    if constexpr (OPT & 2) xmp_pin<0, RS, false>(z);
     if (rows) static_for<0, RF>([&](auto kc) { constexpr int k1 = decltype(kc)::value; wr(std::integral_constant<int, k1 * ROW1>{}, z[out_pos<RF>(k1)].y); });
-    rt_lds_barrier();
-    if (bins) static_for<0, RS>([&](auto nc) { constexpr int n2 = decltype(nc)::value; z[n2].y = mp_lds_read<n2 * kPC * 4>(r1); });
-    rt_lds_barrier();
-    mp_pin<0, RS, true>(z);
+    xrt_lds_barrier();
+    if (bins) static_for<0, RS>([&](auto nc) { constexpr int n2 = decltype(nc)::value; if constexpr (OPT & 2) z[n2].y = xmp_lds_read<n2 * kPC * 4>(r1); else z[n2].y = img[u * ROW1 + n2 * kPC + p]; });
+    xrt_lds_barrier();
+    if constexpr (OPT & 2) xmp_pin<0, RS, true>(z);
 
     // ---- bins k = u + RF*k2: F2 over n2, gate, I1 over k2 ------------------------------------------------------------------
     using BinMap = OutPosMap<RS>;
@@ -213,7 +207,7 @@ __global__ void __launch_bounds__(kPC * (RF > RS ? RF : RS), 1) spectre_mix_regt
         // Hermitian extension above N/2: conj(g[N - k]).  Which side bin k = u + RF*k2 is on is known at compile time for all k2 but
         // the one or two that straddle N/2, so the reads are immediate offsets from two lane constants and can all be in flight at once
         // (a per-bin select serialised them behind s_waitcnt lgkmcnt(0): 24 exposed LDS latencies per tile)
-        constexpr int side = mixed_gate_side<RF, N>(k2);
+        constexpr int side = (OPT & 1) ? xmixed_gate_side<RF, N>(k2) : 2;
         if constexpr (side == 0) z[pos] = cmul(z[pos], g_lo[RF * k2]);                  // spectre.py:545
         else if constexpr (side == 1) z[pos] = cmulc(z[pos], g_hi[N - RF * k2]);
         else {
@@ -228,15 +222,15 @@ __global__ void __launch_bounds__(kPC * (RF > RS ? RF : RS), 1) spectre_mix_regt
 
     // ---- E2 ---------------------------------------------------------------------------------------------------------------
     if (bins) static_for<0, RS>([&](auto nc) { constexpr int n2 = decltype(nc)::value; wr(std::integral_constant<int, n2 * ROW2>{}, z[BinMap::at(out_pos<RS>(n2))].x); });
-    rt_lds_barrier();
-    if (rows) static_for<0, RF>([&](auto kc) { constexpr int k1 = decltype(kc)::value; z[k1].x = mp_lds_read<k1 * kPC * 4>(r2); });
-    rt_lds_barrier();
-    mp_pin<0, RF, false>(z);
+    xrt_lds_barrier();
+    if (rows) static_for<0, RF>([&](auto kc) { constexpr int k1 = decltype(kc)::value; if constexpr (OPT & 2) z[k1].x = xmp_lds_read<k1 * kPC * 4>(r2); else z[k1].x = img[u * ROW2 + k1 * kPC + p]; });
+    xrt_lds_barrier();
+    if constexpr (OPT & 2) xmp_pin<0, RF, false>(z);
     if (bins) static_for<0, RS>([&](auto nc) { constexpr int n2 = decltype(nc)::value; wr(std::integral_constant<int, n2 * ROW2>{}, z[BinMap::at(out_pos<RS>(n2))].y); });
-    rt_lds_barrier();
-    if (rows) static_for<0, RF>([&](auto kc) { constexpr int k1 = decltype(kc)::value; z[k1].y = mp_lds_read<k1 * kPC * 4>(r2); });
-    rt_lds_barrier();
-    mp_pin<0, RF, true>(z);
+    xrt_lds_barrier();
+    if (rows) static_for<0, RF>([&](auto kc) { constexpr int k1 = decltype(kc)::value; if constexpr (OPT & 2) z[k1].y = xmp_lds_read<k1 * kPC * 4>(r2); else z[k1].y = img[u * ROW2 + k1 * kPC + p]; });
+    xrt_lds_barrier();
+    if constexpr (OPT & 2) xmp_pin<0, RF, true>(z);
 
     // ---- conj twiddle, I2 over k1, store rows u + RS*n1 (spectre.py:553), reload / trade places -------------------------------
     load_twiddle_bases(wa, wb);
@@ -274,12 +268,12 @@ __global__ void __launch_bounds__(kPC * (RF > RS ? RF : RS), 1) spectre_mix_regt
       constexpr int i = decltype(ic)::value, q = decltype(row_q(ic))::value;
       if constexpr (i < D0 || i >= D0 + P) z[q] = load_row(rs_next, voff, v_sn, std::integral_constant<int, q>{});
     });
-    obp = ob;
+    if constexpr (!(OPT & 8)) obp = ob;
     gate_fetch(gpn);                                 // (after the last tile: a harmless re-read of this tile's bins)
   }
 }
 
 template <int RF, int RS>
-hipError_t launch_regtile_mixedp(const RegtileArgs& a, hipStream_t stream);
+hipError_t launch_regtile_mixedpx(const RegtileArgs& a, hipStream_t stream);
 
 }  // namespace sfft
