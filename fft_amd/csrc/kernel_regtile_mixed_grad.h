@@ -80,12 +80,13 @@ spectre_gate_grad_regtile_mixed(const GateGradArgs a) {
       });
     }
 
+    const MixedM0 m0 = mixed_m0(img, tid);
     // ---- E1 (as in kernel_regtile_mixed.h) ------------------------------------------------------------------------
-    if (rows) static_for<0, RF>([&](auto kc) { constexpr int k1 = decltype(kc)::value; img[k1 * ROW1 + u * kPC + p] = z[out_pos<RF>(k1)].x; });
+    if (rows) static_for<0, RF>([&](auto kc) { constexpr int k1 = decltype(kc)::value; mixed_write_addtid<k1 * ROW1 * 4>(z[out_pos<RF>(k1)].x, m0); });
     __syncthreads();
     if (bins) static_for<0, RS>([&](auto nc) { constexpr int n2 = decltype(nc)::value; z[n2].x = img[u * ROW1 + n2 * kPC + p]; });
     __syncthreads();
-    if (rows) static_for<0, RF>([&](auto kc) { constexpr int k1 = decltype(kc)::value; img[k1 * ROW1 + u * kPC + p] = z[out_pos<RF>(k1)].y; });
+    if (rows) static_for<0, RF>([&](auto kc) { constexpr int k1 = decltype(kc)::value; mixed_write_addtid<k1 * ROW1 * 4>(z[out_pos<RF>(k1)].y, m0); });
     __syncthreads();
     if (bins) static_for<0, RS>([&](auto nc) { constexpr int n2 = decltype(nc)::value; z[n2].y = img[u * ROW1 + n2 * kPC + p]; });
     __syncthreads();

@@ -61,7 +61,6 @@ __global__ void __launch_bounds__(kPC * (RF > RS ? RF : RS), 1) spectre_mix_regt
   float* img = reinterpret_cast<float*>(smem);
   float2* glds = reinterpret_cast<float2*>(smem + mixed_image_bytes<RF, RS>());
   typedef __attribute__((address_space(3))) float lds_float;
-  constexpr int HI = 16384;                          // floats: the second write base sits 64 KiB into the image
   auto lane_base = [&](int off) { lds_float* b = (lds_float*)(img + off); asm volatile("" : "+v"(b)); return b; };
 
   // Only threadIdx.x stays live across the tile loop; the lane coordinates are re-derived from an opaque copy per tile (otherwise LICM
@@ -181,15 +180,12 @@ __global__ void __launch_bounds__(kPC * (RF > RS ? RF : RS), 1) spectre_mix_regt
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- E1 (kernel_regtile_mixed.h); the first barrier also separates it from the previous tile's E2 reads ---------------
-    // Writes: image rows beyond 64 KiB are addressed from a second lane constant (one v_add_u32 per write otherwise).  Reads: single
-    // ds_read_b32 (mp_lds_read), pinned behind the barrier that waits for them.
-    lds_float* const w_lo = lane_base(u * kPC + p);
-    lds_float* const w_hi = lane_base(u * kPC + p + HI);
+    // Writes: ds_write_addtid_b32 from one of two M0 bases.  Reads: single ds_read_b32 (mp_lds_read), pinned behind the barrier that
+    // waits for them.
     const uint32_t r1 = (uint32_t)(uintptr_t)lane_base(u * ROW1 + p), r2 = (uint32_t)(uintptr_t)lane_base(u * ROW2 + p);
-    auto wr = [&](auto offc, float v) {
-      constexpr int off = decltype(offc)::value;
-      if constexpr (off * 4 + 4096 < 65536) w_lo[off] = v; else w_hi[off - HI] = v;
-    };
+    // a write goes to img[off + tid]: consecutive lanes, consecutive dwords — ds_write_addtid_b32 (mp_write_addtid) from the wave's base
+    const MixedM0 m0 = mixed_m0(img, tid);
+    auto wr = [&](auto offc, float v) { mixed_write_addtid<decltype(offc)::value * 4>(v, m0); };
     rt_lds_barrier();
     if (rows) static_for<0, RF>([&](auto kc) { constexpr int k1 = decltype(kc)::value; wr(std::integral_constant<int, k1 * ROW1>{}, z[out_pos<RF>(k1)].x); });
     rt_lds_barrier();

@@ -55,11 +55,10 @@ void run(int short_rows) {
 #ifdef HAVE_OLD
   add("EARLIER kernel", mk(spectre_mix_regtile_mixedp_old<RF, RS, P>, a));
 #endif
-  add("OPT=8 prev ptr recomputed", mk(spectre_mix_regtile_mixedpx<RF, RS, P, 8>, a));
-  add("OPT=3", mk(spectre_mix_regtile_mixedpx<RF, RS, P, 3>, a));
-  add("OPT=7", mk(spectre_mix_regtile_mixedpx<RF, RS, P, 7>, a));
-  add("OPT=11", mk(spectre_mix_regtile_mixedpx<RF, RS, P, 11>, a));
-  add("OPT=15 (all)", mk(spectre_mix_regtile_mixedpx<RF, RS, P, 15>, a));
+  add("OPT=7 (library)", mk(spectre_mix_regtile_mixedpx<RF, RS, P, 7>, a));
+  add("OPT=23 addtid writes", mk(spectre_mix_regtile_mixedpx<RF, RS, P, 23>, a));
+  add("OPT=7 (library) again", mk(spectre_mix_regtile_mixedpx<RF, RS, P, 7>, a));
+  add("OPT=23 addtid writes again", mk(spectre_mix_regtile_mixedpx<RF, RS, P, 23>, a));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int w = 0; w < 30; ++w) vs[0].launch();                              // power-state ramp
   for (auto& x : vs) { x.launch(); x.launch(); }

@@ -1,6 +1,7 @@
 // mixedpx.h — a copy of fft_amd/csrc/kernel_regtile_mixedp.h (round 3) with its tidy-ups behind a template parameter, for
 // tools/mixedp_opt_bench.hip only (profiles/r03_mixedp_opt_matrix.log).  OPT bits: 1 = compile-time gate side, 2 = single ds_read_b32 with
-// immediate offsets, 4 = second write base beyond 64 KiB, 8 = the previous tile's output base recomputed instead of carried.  The library
+// immediate offsets, 4 = second write base beyond 64 KiB, 8 = the previous tile's output base recomputed instead of carried, 16 = exchange writes as
+// ds_write_addtid_b32 (M0 + offset + 4 * lane).  The library
 // kernel is OPT = 7.  Not part of the product.
 #pragma once
 #include "../fft_amd/csrc/kernel_regtile_mixed.h"
@@ -24,6 +25,11 @@ __device__ __forceinline__ float xmp_lds_read(uint32_t addr) {
   float v;
   asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF_BYTES));
   return v;
+}
+template <int OFF_BYTES>
+__device__ __forceinline__ void xmp_write_addtid(float v, uint32_t m0v) {
+  static_assert(OFF_BYTES >= 0 && OFF_BYTES < 65536, "16-bit immediate");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:%2" :: "v"(v), "s"(m0v), "n"(OFF_BYTES) : "memory", "m0");
 }
 __device__ __forceinline__ void xmp_pin1(float& x) { asm volatile("" : "+v"(x)); }
 template <int LO, int HI, bool IM, int NZ>
@@ -179,9 +185,14 @@ __global__ void __launch_bounds__(kPC * (RF > RS ? RF : RS), 1) spectre_mix_regt
     lds_float* const w_lo = lane_base(u * kPC + p);
     lds_float* const w_hi = lane_base(u * kPC + p + HI);
     const uint32_t r1 = (uint32_t)(uintptr_t)lane_base(u * ROW1 + p), r2 = (uint32_t)(uintptr_t)lane_base(u * ROW2 + p);
+    const uint32_t m0_lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_float*)img + (uint32_t)(tid >> 6) * 256u), m0_hi = m0_lo + 49152u;
     auto wr = [&](auto offc, float v) {
       constexpr int off = decltype(offc)::value;
-      if constexpr (!(OPT & 4)) img[off + u * kPC + p] = v;
+      if constexpr (OPT & 16) {                       // ds_write_addtid_b32: address = M0 + offset + 4 * lane, no address VGPR, 2 cycles instead of 4
+        constexpr int byte = off * 4, kHiBase = 49152;
+        if constexpr (byte < 65536 - 2048) xmp_write_addtid<byte>(v, m0_lo); else xmp_write_addtid<byte - kHiBase>(v, m0_hi);
+      }
+      else if constexpr (!(OPT & 4)) img[off + u * kPC + p] = v;
       else if constexpr (off * 4 + 4096 < 65536) w_lo[off] = v; else w_hi[off - HI] = v;
     };
     xrt_lds_barrier();
