@@ -1,5 +1,9 @@
 // Runs the compile-time in-register FFTs of fft_amd/csrc/fft_regs_mixed.h on the host (g++), one length per call.
+#ifdef SFFT_ENGINE_HEADER
+#include SFFT_ENGINE_HEADER          // tools/fft_regs_mixed_scaled.h: the round-3 scaled-twiddle experiment, same interface
+#else
 #include "fft_regs_mixed.h"
+#endif
 using namespace sfft;
 
 template <int R, bool INV>

@@ -11,10 +11,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LENGTHS = [2, 3, 4, 5, 7, 8, 6, 14, 10, 12, 15, 16, 20, 24, 25, 30, 32, 40, 48, 50, 56, 60, 64]
 
 
-@pytest.fixture(scope="module")
-def engine(tmp_path_factory):
-    out = tmp_path_factory.mktemp("fft_engine") / "libfft_engine_host.so"
-    cmd = ["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-I", os.path.join(ROOT, "tests", "host_shim"),
+def _build(tmp_path_factory, name, extra=()):
+    out = tmp_path_factory.mktemp(name) / "libfft_engine_host.so"
+    cmd = ["g++", "-O1", "-std=c++17", "-shared", "-fPIC", *extra, "-I", os.path.join(ROOT, "tests", "host_shim"),
            "-I", os.path.join(ROOT, "fft_amd", "csrc"), os.path.join(ROOT, "tests", "host_shim", "fft_engine_host.cpp"), "-o", str(out)]
     subprocess.run(cmd, check=True, capture_output=True)
     lib = ctypes.CDLL(str(out))
@@ -23,6 +22,18 @@ def engine(tmp_path_factory):
     lib.fft_regs_run.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     lib.fft_regs_run.restype = ctypes.c_int
     return lib
+
+
+@pytest.fixture(scope="module")
+def engine(tmp_path_factory):
+    return _build(tmp_path_factory, "fft_engine")
+
+
+@pytest.fixture(scope="module")
+def scaled_engine(tmp_path_factory):
+    """tools/fft_regs_mixed_scaled.h — the scaled-twiddle variant of the engine measured in round 3 (not shipped)."""
+    header = os.path.join(ROOT, "tools", "fft_regs_mixed_scaled.h")
+    return _build(tmp_path_factory, "fft_engine_scaled", [f'-DSFFT_ENGINE_HEADER="{header}"'])
 
 
 def _run(lib, R, mode, x):
@@ -39,6 +50,16 @@ def test_forward_inverse_roundtrip(engine, R):
     assert np.abs(_run(engine, R, 0, x) - np.fft.fft(x)).max() <= tol
     assert np.abs(_run(engine, R, 1, x) - np.fft.ifft(x) * R).max() <= tol
     assert np.abs(_run(engine, R, 2, x) - x * R).max() <= 4e-6 * R * np.abs(x).max()
+
+
+def test_scaled_twiddle_experiment_computes_the_same_transforms(scaled_engine):
+    for R in LENGTHS:
+        rng = np.random.default_rng(1000 + R)
+        x = rng.standard_normal(R) + 1j * rng.standard_normal(R)
+        tol = 2e-6 * np.sqrt(R) * np.abs(np.fft.fft(x)).max()
+        assert np.abs(_run(scaled_engine, R, 0, x) - np.fft.fft(x)).max() <= tol, R
+        assert np.abs(_run(scaled_engine, R, 1, x) - np.fft.ifft(x) * R).max() <= tol, R
+        assert np.abs(_run(scaled_engine, R, 2, x) - x * R).max() <= 4e-6 * R * np.abs(x).max(), R
 
 
 @pytest.mark.parametrize("X", [16, 32, 64])
