@@ -51,7 +51,9 @@ def hipcc() -> str:
 # Translation units whose kernels read LDS-DMA landing slots behind a hand-counted `s_waitcnt vmcnt(N)`: tools/isa_lint.py recounts N in
 # the emitted ISA after every (re)compile and the build FAILS on a mismatch (a compiler that splits, merges or reorders one of those
 # memory instructions would otherwise turn the wait into a silent race).
-LINTED = {"regtile_n4096p.hip": "regtile64p"}
+LINTED = {"regtile_n4096p.hip": ("regtile64p", "vmcnt"),     # hand-counted s_waitcnt vmcnt(N) in front of the LDS-DMA landing slots
+          "regtile_mixedp.hip": ("mixedp", "lds"),            # inline-asm ds_read_b32 consumed behind s_waitcnt lgkmcnt(0); M0-based writes
+          "regtile_n3000.hip": ("regtile_mixed", "addtid")}   # M0-based LDS writes of the one-tile mixed-radix kernels (one representative TU)
 LINT = os.path.normpath(os.path.join(HERE, "..", "tools", "isa_lint.py"))
 
 
@@ -87,7 +89,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if verbose and r.stderr.strip():
             print(r.stderr, file=sys.stderr)
         if src in LINTED:
-            lint = subprocess.run([sys.executable, LINT, os.path.join(CSRC, src), "--kernel", LINTED[src], "--flags", " ".join(CXXFLAGS)],
+            lint = subprocess.run([sys.executable, LINT, os.path.join(CSRC, src), "--kernel", LINTED[src][0], "--check", LINTED[src][1], "--flags", " ".join(CXXFLAGS)],
                                   capture_output=True, text=True, env={**os.environ, "HIPCC": cc})
             if verbose:
                 print(lint.stdout, end="", flush=True)

@@ -93,3 +93,109 @@ def test_untagged_guards_fall_back_to_their_counts(tmp_path):
     assert not errors and len(notes) == 2
     errors, _ = run(tmp_path, listing(4, 4, tags=False))              # same count twice and no tags: refuse to guess
     assert errors and "untagged" in errors[0]
+
+
+# ---- --check lds: inline-asm ds_read_b32 (kernel_regtile_mixedp.h) must be consumed behind an s_waitcnt lgkmcnt(0) --------------------
+def lds_listing(use_before_wait=False, wait="s_waitcnt lgkmcnt(0)", clobber_addr=False):
+    early = "\tv_add_f32_e32 v3, v11, v4\n" if use_before_wait else ""
+    dst2 = "v20" if clobber_addr else "v12"
+    return f"""
+_Z6kernelv:                             ; @_Z6kernelv
+\ts_and_saveexec_b64 s[0:1], vcc
+\ts_cbranch_execz .LBB0_2
+\t;;#ASMSTART
+\tds_read_b32 v10, v20 offset:0
+\t;;#ASMEND
+\t;;#ASMSTART
+\tds_read_b32 v11, v20 offset:32
+\t;;#ASMEND
+\t;;#ASMSTART
+\tds_read_b32 {dst2}, v20 offset:64
+\t;;#ASMEND
+.LBB0_2:
+\ts_or_b64 exec, exec, s[0:1]
+{early}\tv_mul_f32_e32 v5, v6, v7
+\t;;#ASMSTART
+\t{wait}
+\ts_barrier
+\t;;#ASMEND
+\tv_add_f32_e32 v3, v10, v11
+\tv_add_f32_e32 v3, v3, v12
+\ts_endpgm
+.Lfunc_end0:
+"""
+
+
+def run_lds(tmp_path, text):
+    p = tmp_path / "k.s"
+    p.write_text(text)
+    kernels = isa_lint.parse_kernels(str(p))
+    return isa_lint.lint_lds_reads("_Z6kernelv", kernels["_Z6kernelv"])
+
+
+def test_lds_reads_behind_the_barrier_pass(tmp_path):
+    errors, notes = run_lds(tmp_path, lds_listing())
+    assert not errors, errors
+    assert "3 untracked ds_read_b32" in notes[0]
+
+
+def test_lds_read_used_before_the_wait_fails(tmp_path):
+    errors, _ = run_lds(tmp_path, lds_listing(use_before_wait=True))
+    assert errors and "touches v11" in errors[0]
+
+
+def test_lds_read_behind_a_partial_wait_fails(tmp_path):
+    errors, _ = run_lds(tmp_path, lds_listing(wait="s_waitcnt lgkmcnt(1)"))
+    assert errors                                     # lgkmcnt(1) leaves the last read in flight: its first use is flagged
+
+
+def test_lds_read_into_its_own_address_register_fails(tmp_path):
+    errors, _ = run_lds(tmp_path, lds_listing(clobber_addr=True))
+    assert errors and "address register" in errors[0]
+
+
+def test_lds_check_without_reads_is_an_error(tmp_path):
+    errors, _ = run_lds(tmp_path, lds_listing().replace("ds_read_b32", "ds_read_b64"))
+    assert errors and "no inline-asm ds_read_b32" in errors[0]
+
+
+# ---- --check addtid: ds_write_addtid_b32 takes its base from M0, set inside the same asm statement ------------------------------------
+def addtid_listing(own_m0=True, compiler_m0=False):
+    mov = "\ts_mov_b32 m0, s4\n\ts_nop 0\n" if own_m0 else ""
+    other = "\ts_mov_b32 m0, s9\n\tbuffer_load_dword v1, s[0:3], 0 offen lds\n" if compiler_m0 else ""
+    return f"""
+_Z6kernelv:                             ; @_Z6kernelv
+{other}\t;;#ASMSTART
+{mov}\tds_write_addtid_b32 v3 offset:1024
+\t;;#ASMEND
+\t;;#ASMSTART
+\ts_mov_b32 m0, s5
+\ts_nop 0
+\tds_write_addtid_b32 v4 offset:2048
+\t;;#ASMEND
+\ts_endpgm
+.Lfunc_end0:
+"""
+
+
+def run_addtid(tmp_path, text):
+    p = tmp_path / "k.s"
+    p.write_text(text)
+    kernels = isa_lint.parse_kernels(str(p))
+    return isa_lint.lint_addtid("_Z6kernelv", kernels["_Z6kernelv"])
+
+
+def test_addtid_writes_with_their_own_m0_pass(tmp_path):
+    errors, notes = run_addtid(tmp_path, addtid_listing())
+    assert not errors, errors
+    assert "2 ds_write_addtid_b32" in notes[0]
+
+
+def test_addtid_write_without_m0_fails(tmp_path):
+    errors, _ = run_addtid(tmp_path, addtid_listing(own_m0=False))
+    assert errors and "not preceded by s_mov_b32 m0" in errors[0]
+
+
+def test_compiler_use_of_m0_next_to_addtid_fails(tmp_path):
+    errors, _ = run_addtid(tmp_path, addtid_listing(compiler_m0=True))
+    assert errors and "uses M0" in errors[0]

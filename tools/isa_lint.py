@@ -16,6 +16,15 @@ against the prologue's.  The source says which is which with a comment inside th
 `; lint: first` — the comment survives into the -S listing); an untagged pair is told apart by N (the smaller count is the prologue's).
 
     python tools/isa_lint.py fft_amd/csrc/regtile_n4096p.hip [--kernel regtile64p] [--asm out.s] [--flags "..."]
+
+A second check (--check lds) covers the untracked LDS reads of kernel_regtile_mixedp.h: its exchanges read the image with inline-asm
+`ds_read_b32` whose results hipcc's s_waitcnt insertion does not know about; they are consumed behind rt_lds_barrier() (s_waitcnt
+lgkmcnt(0) ; s_barrier) and pinned there.  The script follows every such read forward through the listing and fails if any instruction
+mentions its destination register before an `s_waitcnt` with lgkmcnt(0) has been passed.  The same kernels write the image with
+`ds_write_addtid_b32` (base in M0, set inside each asm statement): --check addtid (part of --check lds) verifies that every one follows
+its own `s_mov_b32 m0` and that no compiler-generated instruction of the kernel touches M0.
+
+    python tools/isa_lint.py fft_amd/csrc/regtile_mixedp.hip --kernel mixedp --check lds
 """
 from __future__ import annotations
 
@@ -189,11 +198,82 @@ def lint_kernel(name, blocks, verbose=True):
     return errors, notes
 
 
+VREG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+WAIT_LGKM0 = re.compile(r"^s_waitcnt\b(?!.*lgkmcnt\([1-9])(.*lgkmcnt\(0\)|\s+0\s*$)")
+
+
+def _vregs(text):
+    regs = set()
+    for m in VREG.finditer(text):
+        if m.group(1) is not None:
+            regs.add(int(m.group(1)))
+        else:
+            regs.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return regs
+
+
+def lint_lds_reads(name, blocks):
+    """Every inline-asm ds_read_b32: no instruction may mention its destination VGPR before an s_waitcnt lgkmcnt(0) (text order: the reads
+    sit in a lane-predicated block that falls through to the barrier)."""
+    flat = [x for b in blocks for x in b["ins"]]
+    errors, reads = [], 0
+    for i, x in enumerate(flat):
+        if not (x.inline and x.op == "ds_read_b32"):
+            continue
+        reads += 1
+        dst = _vregs(x.text.split(",")[0])
+        addr = _vregs(x.text.split(",")[1]) if "," in x.text else set()
+        if dst & addr:
+            errors.append(f"{name}: `{x.text}` overwrites its own address register (later reads of the burst use it)")
+        for y in flat[i + 1:]:
+            if WAIT_LGKM0.match(y.text):
+                break
+            if y.inline and y.op == "ds_read_b32":
+                if dst & _vregs(y.text.split(",")[0]):
+                    errors.append(f"{name}: two reads of one burst land in v{sorted(dst)[0]}")
+                continue
+            if dst & _vregs(y.text):
+                errors.append(f"{name}: `{y.text}` touches v{sorted(dst)[0]} before the s_waitcnt lgkmcnt(0) behind `{x.text}`")
+                break
+        else:
+            errors.append(f"{name}: no s_waitcnt lgkmcnt(0) behind `{x.text}`")
+    notes = [f"{name}: {reads} untracked ds_read_b32, each consumed behind an s_waitcnt lgkmcnt(0)"]
+    if reads == 0:
+        errors.append(f"{name}: no inline-asm ds_read_b32 found (the exchange reads are gone?)")
+    return errors, notes
+
+
+def lint_addtid(name, blocks):
+    """ds_write_addtid_b32 takes its base from M0, which the asm statement sets itself (hipcc treats M0 as reserved).  Each one must follow
+    an s_mov_b32 m0 inside the same asm statement, and no compiler-generated instruction of the kernel may read or write M0 (if hipcc
+    started to use M0 here — LDS-DMA, s_movrel — it would have to be told about these statements)."""
+    errors, n = [], 0
+    for b in blocks:
+        prev_inline_m0 = False
+        for x in b["ins"]:
+            mentions_m0 = bool(re.search(r"(?<![\w.])m0(?![\w.])", x.text))
+            if x.op == "ds_write_addtid_b32":
+                n += 1
+                if not (x.inline and prev_inline_m0):
+                    errors.append(f"{name}: `{x.text}` is not preceded by s_mov_b32 m0 inside its asm statement")
+            if mentions_m0 and not x.inline:
+                errors.append(f"{name}: compiler-generated `{x.text}` uses M0 in a kernel whose asm statements overwrite it")
+            if x.inline and x.op == "s_mov_b32" and x.text.split()[1].rstrip(",") == "m0":
+                prev_inline_m0 = True
+            elif not (x.inline and x.op in ("s_nop", "ds_write_addtid_b32")):
+                prev_inline_m0 = False
+    if n == 0:
+        errors.append(f"{name}: no ds_write_addtid_b32 found")
+    return errors, [f"{name}: {n} ds_write_addtid_b32, each behind its own s_mov_b32 m0; no other use of M0"]
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("source", help=".hip translation unit (or a .s file produced by hipcc -S)")
     ap.add_argument("--kernel", default="regtile64p", help="substring of the (mangled) kernel names to check")
     ap.add_argument("--flags", default=None, help="compiler flags (default: the library's)")
+    ap.add_argument("--check", default="vmcnt", choices=["vmcnt", "lds", "addtid"],
+                    help="vmcnt: hand-counted guards of LDS-DMA slots; lds: untracked ds_read_b32 (+ addtid); addtid: M0-based LDS writes")
     ap.add_argument("--quiet", action="store_true")
     args = ap.parse_args(argv)
     asm, tmp = args.source, None
@@ -209,7 +289,14 @@ def main(argv=None):
         return 1
     bad = 0
     for name, blocks in kernels.items():
-        errors, notes = lint_kernel(name, blocks)
+        if args.check == "vmcnt":
+            errors, notes = lint_kernel(name, blocks)
+        elif args.check == "addtid":
+            errors, notes = lint_addtid(name, blocks)
+        else:
+            errors, notes = lint_lds_reads(name, blocks)
+            e2, n2 = lint_addtid(name, blocks)
+            errors, notes = errors + e2, notes + n2
         if not args.quiet:
             for n in notes:
                 print("isa_lint:", n)
