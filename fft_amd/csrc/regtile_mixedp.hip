@@ -6,6 +6,9 @@
 namespace sfft {
 // P = deferred row blocks.  n_fft = 3000 (60 x 50), interleaved runs on one box at (256,3000,768): one tile per workgroup
 // (kernel_regtile_mixed.h) 1.663 ms; P = 0 1.766, 16 1.661, 24 1.507, 26 1.506, 28 1.561 (253 VGPRs), 30 1.628 (spills).
+// Round 3, after the exchanges were tidied (fewer live registers; profiles/r03_mixedp_p_sweep.log, one box): 60 x 50 P = 20 1.498,
+// 24 1.472, 26 1.441, 28 1.423 (252 VGPRs, no spill), 30 1.428; 64 x 40 P = 16 1.329, 20 1.292, 22 1.291, 24 1.297, 26 1.306;
+// 60 x 40 P = 20 1.446, 24 1.438, 26 1.444, 28 1.449, 30 1.507.
 #define SFFT_DEFINE_MIXEDP_LAUNCHER(RF_, RS_, P_)                                                                       \
   template <>                                                                                                          \
   hipError_t launch_regtile_mixedp<RF_, RS_>(const RegtileArgs& a, hipStream_t stream) {                                \
@@ -25,7 +28,7 @@ namespace sfft {
 // Same-box sweep at (256, n, 768), persistent vs one tile per workgroup (tools/mixedp_sweep.py, profiles/r02_mixedp_sweep.log):
 // 3000 1.511 vs 1.649 ms, 2560 1.268 vs 1.386, 2400 1.207 vs 1.343; no gain at 3072 (1.599 both), 3600 (1.961 vs 1.917) and 3840 (1.974 vs
 // 1.958) — those keep kernel_regtile_mixed.h.
-SFFT_DEFINE_MIXEDP_LAUNCHER(60, 50, 24)
+SFFT_DEFINE_MIXEDP_LAUNCHER(60, 50, 28)
 SFFT_DEFINE_MIXEDP_LAUNCHER(64, 40, 20)
 SFFT_DEFINE_MIXEDP_LAUNCHER(60, 40, 24)
 }  // namespace sfft

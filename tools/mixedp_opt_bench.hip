@@ -55,10 +55,11 @@ void run(int short_rows) {
 #ifdef HAVE_OLD
   add("EARLIER kernel", mk(spectre_mix_regtile_mixedp_old<RF, RS, P>, a));
 #endif
-  add("OPT=7 (library)", mk(spectre_mix_regtile_mixedpx<RF, RS, P, 7>, a));
-  add("OPT=23 addtid writes", mk(spectre_mix_regtile_mixedpx<RF, RS, P, 23>, a));
-  add("OPT=7 (library) again", mk(spectre_mix_regtile_mixedpx<RF, RS, P, 7>, a));
-  add("OPT=23 addtid writes again", mk(spectre_mix_regtile_mixedpx<RF, RS, P, 23>, a));
+  add("OPT=23 (library), P as shipped", mk(spectre_mix_regtile_mixedpx<RF, RS, P, 23>, a));
+  add("OPT=23, P + 2", mk(spectre_mix_regtile_mixedpx<RF, RS, P + 2, 23>, a));
+  add("OPT=23, P + 4", mk(spectre_mix_regtile_mixedpx<RF, RS, P + 4, 23>, a));
+  add("OPT=23, P + 6", mk(spectre_mix_regtile_mixedpx<RF, RS, P + 6, 23>, a));
+  add("OPT=23, P - 4", mk(spectre_mix_regtile_mixedpx<RF, RS, P - 4, 23>, a));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int w = 0; w < 30; ++w) vs[0].launch();                              // power-state ramp
   for (auto& x : vs) { x.launch(); x.launch(); }
@@ -87,8 +88,8 @@ void run(int short_rows) {
 }
 
 int main() {
-  run<60, 50, 24>(0); run<60, 50, 24>(7);
-  run<64, 40, 20>(0); run<64, 40, 20>(7);
-  run<60, 40, 24>(0); run<60, 40, 24>(7);
+  run<60, 50, 24>(0);
+  run<64, 40, 20>(0);
+  run<60, 40, 24>(0);
   return 0;
 }
