@@ -193,6 +193,23 @@ def copy_probe(src: torch.Tensor, dst: torch.Tensor, seg_bytes: int = 0, *, tile
     return float(ms.value)
 
 
+def empty_on_fast_allocation(shape, dtype=torch.float32, device="cuda", candidates: int = 4):
+    """`torch.empty(shape)` on the fastest of `candidates` fresh allocations, by a store-only pass of the copy probe over each.
+
+    On MI355X device allocations come in two classes; one takes stores ~19 % faster, and the class belongs to the allocation (DESIGN.md
+    section 5, round 3, item 7; tools/placement_classes.py).  For long-lived (B, N, D) activation buffers it is worth half a millisecond
+    per candidate, once.  The losers go back to torch's caching allocator, which may hand them out again: allocate what must be fast
+    first.  Returns (tensor, store_ms_of_every_candidate); tensors the dense probe cannot take (not 3-D, not a multiple of 256 KiB) come
+    back as the first candidate with an empty list."""
+    first = torch.empty(shape, dtype=dtype, device=device)
+    if candidates < 2 or first.dim() != 3 or (first.numel() * first.element_size()) % (256 * 1024) or not first.is_cuda:
+        return first, []
+    cands = [first] + [torch.empty(shape, dtype=dtype, device=device) for _ in range(candidates - 1)]
+    ms = [min(copy_probe(c, c, 0, mode="store", wgs_per_cu=w, warmup=3, iters=8) for w in (2, 4)) for c in cands]
+    best = min(range(len(cands)), key=lambda i: ms[i])
+    return cands[best], ms
+
+
 def spectral_gate_fused(anchors: torch.Tensor, bias: torch.Tensor, eps: float, size: int,
                         pos_phase: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Cubic resample of (B, G, K) complex anchors to `size` bins -> complex modReLU -> optional positional phase,
