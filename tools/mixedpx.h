@@ -2,7 +2,7 @@
 // tools/mixedp_opt_bench.hip only (profiles/r03_mixedp_opt_matrix.log).  OPT bits: 1 = compile-time gate side, 2 = single ds_read_b32 with
 // immediate offsets, 4 = second write base beyond 64 KiB, 8 = the previous tile's output base recomputed instead of carried, 16 = exchange writes as
 // ds_write_addtid_b32 (M0 + offset + 4 * lane).  The library
-// kernel is OPT = 7.  Not part of the product.
+// kernel is OPT = 23 (1 + 2 + 4 + 16).  Not part of the product.
 #pragma once
 #include "../fft_amd/csrc/kernel_regtile_mixed.h"
 
