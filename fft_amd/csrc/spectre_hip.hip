@@ -37,6 +37,9 @@ template <int RF, int RS> hipError_t launch_regtile_mixedp(const RegtileArgs&, h
 template <> hipError_t launch_regtile_mixedp<60, 50>(const RegtileArgs&, hipStream_t);               // regtile_mixedp.hip
 template <> hipError_t launch_regtile_mixedp<64, 40>(const RegtileArgs&, hipStream_t);
 template <> hipError_t launch_regtile_mixedp<60, 40>(const RegtileArgs&, hipStream_t);
+template <> hipError_t launch_regtile_mixedp<64, 48>(const RegtileArgs&, hipStream_t);
+template <> hipError_t launch_regtile_mixedp<60, 60>(const RegtileArgs&, hipStream_t);
+template <> hipError_t launch_regtile_mixedp<64, 60>(const RegtileArgs&, hipStream_t);
 hipError_t launch_regtile_long_8192(const RegtileArgs&, bool, bool, int, hipStream_t);   // regtile_n8192.hip, regtile_n6144.hip
 hipError_t launch_regtile_long_6144(const RegtileArgs&, bool, bool, int, hipStream_t);
 hipError_t launch_regtile_quad_16384(const RegtileArgs&, bool, bool, int, hipStream_t);   // regtile_n16384.hip, regtile_n12288.hip
@@ -299,7 +302,7 @@ struct Choice {
   const TileSize* tile = nullptr;
   int RF = 0, RS = 0;      // n_fft = RF * RS
   int mode = 0;            // 0 fast, 1 general (row predicates / gate from global), 2 general + memory_fft, 3 row predicates only
-  bool mixedp = false;     // n_fft = 3000 / 2560 / 2400, fp32 in/out, gate in LDS, 8-byte aligned rows: persistent kernel with deferred row blocks (kernel_regtile_mixedp.h)
+  bool mixedp = false;     // n_fft = 3000 / 2560 / 2400 / 3072 / 3600 / 3840, fp32 in/out, gate in LDS, 8-byte aligned rows: persistent kernel with deferred row blocks (kernel_regtile_mixedp.h)
   bool pipelined = false;  // n_fft = 4096 fast mode, fp32, 16-byte aligned rows: persistent software-pipelined kernel (kernel_regtile64p.h)
   // stockham
   int P = 0, S = 0, solo = 0;
@@ -381,7 +384,7 @@ int choose(const SpectreMixArgs* a, const Plan* plan, Choice* c) {
     c->mode = mode;
     c->pipelined = pipelined_ok;
     static const bool mixedp_off = [] { const char* e = getenv("SPECTRE_MIXEDP"); return e && atoi(e) == 0; }();
-    c->mixedp = !mixedp_off && ts->mixed && (n == 3000 || n == 2560 || n == 2400) && (mode == 0 || mode == 3) && a->in_dtype == SPECTRE_F32 && a->out_dtype == SPECTRE_F32 &&
+    c->mixedp = !mixedp_off && ts->mixed && (n == 3000 || n == 2560 || n == 2400 || n == 3072 || n == 3600 || n == 3840) && (mode == 0 || mode == 3) && a->in_dtype == SPECTRE_F32 && a->out_dtype == SPECTRE_F32 &&
                 reinterpret_cast<uintptr_t>(a->v) % 8 == 0 && reinterpret_cast<uintptr_t>(a->out) % 8 == 0 &&
                 a->v_sn % 2 == 0 && a->v_sb % 2 == 0 && a->out_sn % 2 == 0 && a->out_sb % 2 == 0 &&
                 a->v_sn * n * 4 < ((int64_t)1 << 31) && a->out_sn * n * 4 < ((int64_t)1 << 31);
@@ -474,7 +477,8 @@ int launch(const SpectreMixArgs* a, const Plan* plan, const Choice& c, bool conj
       k.n_wg = 2 * ((k.n_tiles + 2 * k.tpw - 1) / (2 * k.tpw));
       const int64_t n = a->n_fft;
       e = n == 3000 ? sfft::launch_regtile_mixedp<60, 50>(k, stream) : n == 2560 ? sfft::launch_regtile_mixedp<64, 40>(k, stream)
-                    : sfft::launch_regtile_mixedp<60, 40>(k, stream);
+        : n == 2400 ? sfft::launch_regtile_mixedp<60, 40>(k, stream) : n == 3072 ? sfft::launch_regtile_mixedp<64, 48>(k, stream)
+        : n == 3600 ? sfft::launch_regtile_mixedp<60, 60>(k, stream) : sfft::launch_regtile_mixedp<64, 60>(k, stream);
     } else {
       e = c.tile->launch(k, ib, ob, c.mode, stream);
     }

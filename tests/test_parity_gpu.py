@@ -66,12 +66,12 @@ def test_native_library_is_the_thing_that_runs():
     V3, g3, _ = _problem(0, 1, 3000, 16, 1, 3000)
     assert _describe(V3.to(DEV), g3.to(DEV)).startswith("regtile-mixed-pipelined 60x50 in=f32 out=f32 mode=0")   # fp32 rows: persistent kernel
     assert _describe(V3.to(DEV).bfloat16(), g3.to(DEV)).startswith("regtile-mixed 60x50 in=bf16 out=bf16")     # bf16 rows: one tile per workgroup
-    for n, tag in ((2560, "64x40"), (2400, "60x40")):
+    for n, tag in ((2560, "64x40"), (2400, "60x40"), (3072, "64x48"), (3600, "60x60"), (3840, "64x60")):
         Vn, gn, _ = _problem(0, 1, n, 16, 1, n)
         assert _describe(Vn.to(DEV), gn.to(DEV)).startswith("regtile-mixed-pipelined " + tag)
-    for n, tag in ((768, "32x24"), (1536, "48x32"), (3072, "64x48"), (1000, "40x25"), (2000, "50x40"),
-                   (1280, "40x32"), (3840, "64x60"), (64, "8x8"), (128, "16x8"), (196, "14x14"), (384, "24x16"),
-                   (640, "32x20"), (960, "32x30"), (1200, "40x30"), (1920, "48x40"), (3600, "60x60")):
+    for n, tag in ((768, "32x24"), (1536, "48x32"), (1000, "40x25"), (2000, "50x40"),
+                   (1280, "40x32"), (64, "8x8"), (128, "16x8"), (196, "14x14"), (384, "24x16"),
+                   (640, "32x20"), (960, "32x30"), (1200, "40x30"), (1920, "48x40")):
         Vn, gn, _ = _problem(0, 1, n, 16, 1, n)
         assert _describe(Vn.to(DEV), gn.to(DEV)).startswith("regtile-mixed " + tag)
     Vn, gn, _ = _problem(0, 1, 4096, 24, 2, 4096)    # D % 16 != 0: ragged last tile, general mode of the same kernel

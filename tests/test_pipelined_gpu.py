@@ -228,8 +228,8 @@ def test_n3000_persistent_matches_oracle(B, Nin, D, G):
     assert_close(y.cpu().numpy(), spectral_mix_numpy(V.cpu().numpy(), gate.cpu().numpy(), None, n), what=f"n3000 ({B},{Nin},{D})")
 
 
-@pytest.mark.parametrize("n", [2560, 2400])
-@pytest.mark.parametrize("B,dN,D,G", [(1, 0, 16, 1), (5, 0, 80, 5), (37, 0, 112, 7), (3, -100, 64, 2), (2, 333, 32, 2)])
+@pytest.mark.parametrize("n", [2560, 2400, 3072, 3600, 3840])
+@pytest.mark.parametrize("B,dN,D,G", [(1, 0, 16, 1), (5, 0, 80, 5), (37, 0, 112, 7), (3, -100, 64, 2), (2, 333, 32, 2), (40, 0, 768, 4)])
 def test_other_persistent_mixed_lengths_match_oracle(n, B, dN, D, G):
     from fft_amd import describe, spectral_mix
     torch.manual_seed(n + B + D)

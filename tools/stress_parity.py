@@ -10,7 +10,7 @@ rng = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 bad = 0
 for case in range(n_cases):
-    n = rng.choice([4096, 4096, 4096, 3000, 2560, 2400])
+    n = rng.choice([4096, 4096, 4096, 3000, 2560, 2400, 3072, 3600, 3840])
     G = rng.choice([1, 2, 3, 4, 6])
     d_g = 16 * rng.randint(1, 12)
     D = G * d_g
