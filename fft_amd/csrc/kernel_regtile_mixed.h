@@ -44,6 +44,11 @@ __device__ __forceinline__ void mixed_write_addtid(float v, MixedM0 m0) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:%2" :: "v"(v), "s"(HI ? m0.hi : m0.lo), "n"(OFF) : "memory", "m0");
 }
 
+// General modes: request the gate bins / memory_fft rows eight bins at a time (see the middle phase).  Measured per length at
+// (B, n, 768) + memory_fft, round 3 (profiles/r03_mixed_lengths_ab_final.log): 1536 -33 %, 1920 -34 %, 3840 -26 %, 1280 -23 %, 64 ... 384
+// -7 ... -13 %, the others +-2 % — except 40 x 25, 40 x 30 (+11 ... +13 %) and 32 x 20 (+4 %), which keep the bin-by-bin form.
+template <int RF, int RS> constexpr bool mixed_batch_bins() { return !((RF == 40 && RS <= 30) || (RF == 32 && RS == 20)); }
+
 template <int RF, int RS> constexpr int mixed_lds_total() { return mixed_image_bytes<RF, RS>() + (RF * RS / 2 + 1) * 8; }
 
 // MODE as in kernel_regtile.h: 0 fast (no predicates, gate staged in LDS), 1 general, 2 general + memory_fft,
@@ -108,6 +113,24 @@ spectre_mix_regtile_mixed(const RegtileArgs a) {
       rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(vb), 0, (int)((long long)nrow * a.v_sn * ES_IN), kRsrcFlags);
       voff_c = cvalid ? voff : 0x80000000u;
     }
+    if constexpr (IN_BF16) {
+      // bf16 rows: every request first, the unpacking afterwards.  Written as one loop hipcc may serialise it — load, s_waitcnt
+      // vmcnt(0), unpack, next load: ONE request in flight per wave — and does so for RF = 48 and 64 (2.6 ms instead of 1.35 at
+      // (300,2560,768); rocprof SQ_INST_LEVEL_VMEM halved, 44 more s_waitcnt in the listing).  The packed words sit in z[].x meanwhile.
+      static_for<0, RF>([&](auto ic) {
+        constexpr int q = (decltype(ic)::value / RAF) + RBF * (decltype(ic)::value % RAF);   // order of use in stage 1
+        uint32_t wv;
+        if constexpr (GENERAL) wv = __builtin_amdgcn_raw_buffer_load_b32(rs_in, voff_c + (uint32_t)((long long)q * RS * a.v_sn * ES_IN), 0, 0);
+        else wv = *reinterpret_cast<const uint32_t*>(vb + (size_t)q * RS * a.v_sn * ES_IN + voff);
+        z[q].x = __uint_as_float(wv);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<0, RF>([&](auto ic) {
+        constexpr int q = (decltype(ic)::value / RAF) + RBF * (decltype(ic)::value % RAF);
+        const uint32_t wv = __float_as_uint(z[q].x);
+        z[q] = make_float2(__uint_as_float(wv << 16), __uint_as_float(wv & 0xffff0000u));
+      });
+    } else
     static_for<0, RF>([&](auto ic) {
       constexpr int q = (decltype(ic)::value / RAF) + RBF * (decltype(ic)::value % RAF);   // order of use in stage 1
       if constexpr (GENERAL) {
@@ -159,6 +182,46 @@ spectre_mix_regtile_mixed(const RegtileArgs a) {
     const int cg = cvalid ? c : 0;
     const int grp = cg / a.d_g;
     const float2* gp = a.gate + ((size_t)b * a.G + grp) * a.F;
+    if constexpr ((!GATE_LDS || WITH_MEM) && mixed_batch_bins<RF, RS>()) {
+      // The gate bins (general modes: straight from global memory) and the memory_fft rows are requested EIGHT BINS AT A TIME and used
+      // behind a scheduling barrier: written bin by bin, hipcc puts an s_waitcnt vmcnt(0) behind every request (tools/serial_load_scan.py
+      // counted up to 86 such pairs in one kernel) — one L2 round trip per bin.
+      constexpr int CH = 8;
+      static_for<0, (RS + CH - 1) / CH>([&](auto cc) {
+        constexpr int k0 = decltype(cc)::value * CH, kn = RS - k0 < CH ? RS - k0 : CH;
+        float2 gq[CH];
+        [[maybe_unused]] float4 mq[CH];
+        static_for<0, kn>([&](auto ic) {
+          constexpr int i = decltype(ic)::value, k2 = k0 + i;
+          const int k = u + RF * k2;
+          const int idx = 2 * k > N ? N - k : k;
+          if constexpr (GATE_LDS) gq[i] = glds[idx]; else gq[i] = gp[idx];
+          if constexpr (WITH_MEM) mq[i] = *reinterpret_cast<const float4*>(a.mem + ((size_t)idx * a.D + cg) * 2);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, kn>([&](auto ic) {
+          constexpr int i = decltype(ic)::value, k2 = k0 + i, pos = BinMap::at(k2);
+          const int k = u + RF * k2;
+          const bool upper = 2 * k > N;                     // Hermitian extension: conj(g[N - k])
+          float2 g = gq[i];
+          if constexpr (!GATE_LDS) {
+            if (a.conj_gate) g.y = -g.y;
+            if (k == 0 || 2 * k == N) g.y = 0.f;            // irfft ignores Im(DC), Im(Nyquist)
+            g.x *= inv_n; g.y *= inv_n;
+          }
+          if (upper) g.y = -g.y;
+          z[pos] = cmul(z[pos], g);
+          if constexpr (WITH_MEM) {                         // spectre.py:548-549
+            const float4 m = mq[i];
+            float2 add;
+            if (k == 0 || 2 * k == N) add = make_float2(m.x, m.z);
+            else if (upper)           add = make_float2(m.x + m.w, m.z - m.y);
+            else                      add = make_float2(m.x - m.w, m.y + m.z);
+            z[pos].x += add.x * inv_n; z[pos].y += add.y * inv_n;
+          }
+        });
+      });
+    } else
     static_for<0, RS>([&](auto kc) {
       constexpr int k2 = decltype(kc)::value, pos = BinMap::at(k2);
       const int k = u + RF * k2;

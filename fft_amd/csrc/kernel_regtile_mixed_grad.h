@@ -60,15 +60,25 @@ spectre_gate_grad_regtile_mixed(const GateGradArgs a) {
         uint32_t vo = voff, dof = doff, vs = (uint32_t)((long long)q * RS * a.v_sn * ES), ds = (uint32_t)((long long)q * RS * a.dout_sn * ES);
         if constexpr (GENERAL) { vo += vs; dof += ds; vs = 0; ds = 0; }   // the range check covers the VGPR offset only
         float x, dy;
-        if constexpr (IO_BF16) {
-          x = __uint_as_float((uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rv, vo, vs, 0) << 16);
-          dy = __uint_as_float((uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rd, dof, ds, 0) << 16);
+        if constexpr (IO_BF16) {                    // the raw halves now, the shift behind every request (below)
+          x = __uint_as_float((uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rv, vo, vs, 0));
+          dy = __uint_as_float((uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rd, dof, ds, 0));
         } else {
           x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rv, vo, vs, 0));
           dy = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, dof, ds, 0));
         }
         z[q] = make_float2(x, dy);
       });
+      if constexpr (IO_BF16) {
+        // Unpacked in a second pass: with the shift inside the loop hipcc serialises the requests at some (RF, RS) — load, s_waitcnt
+        // vmcnt(0), shift, next load — one request in flight per wave (dgate at bf16 4.8 ms against 2.0 at fp32, (500,1536,768);
+        // tools/dtype_sweep.py).  The same happened to the forward kernel (kernel_regtile_mixed.h).
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, RF>([&](auto ic) {
+          constexpr int q = decltype(ic)::value;
+          z[q] = make_float2(__uint_as_float(__float_as_uint(z[q].x) << 16), __uint_as_float(__float_as_uint(z[q].y) << 16));
+        });
+      }
       fft_ct<RF, false, IdentityMap, NZ>(z);
       float2 wa[RAF], wb[RBF];
       static_for<1, RAF>([&](auto jc) { constexpr int j = decltype(jc)::value; wa[j] = a.tw[u * j]; });
