@@ -81,6 +81,7 @@ template <> hipError_t launch_gate_grad_regtile<32, 32>(const GateGradArgs&, boo
 template <> hipError_t launch_gate_grad_regtile<64, 32>(const GateGradArgs&, bool, bool, hipStream_t);
 template <> hipError_t launch_gate_grad_regtile<64, 64>(const GateGradArgs&, bool, bool, hipStream_t);
 template <> hipError_t launch_gate_grad_mixed<60, 50>(const GateGradArgs&, bool, bool, hipStream_t);
+template <> hipError_t launch_gate_grad_mixed<25, 40>(const GateGradArgs&, bool, bool, hipStream_t);
 template <> hipError_t launch_gate_grad_mixed<32, 24>(const GateGradArgs&, bool, bool, hipStream_t);
 template <> hipError_t launch_gate_grad_mixed<48, 32>(const GateGradArgs&, bool, bool, hipStream_t);
 template <> hipError_t launch_gate_grad_mixed<64, 48>(const GateGradArgs&, bool, bool, hipStream_t);
@@ -117,7 +118,7 @@ const TileSize kTileSizes[] = {
     {768, 32, 24, true, true, &sfft::launch_regtile_mixed<32, 24>, &sfft::launch_gate_grad_mixed<32, 24>},
     {1536, 48, 32, true, true, &sfft::launch_regtile_mixed<48, 32>, &sfft::launch_gate_grad_mixed<48, 32>},
     {3072, 64, 48, true, true, &sfft::launch_regtile_mixed<64, 48>, &sfft::launch_gate_grad_mixed<64, 48>},
-    {1000, 40, 25, true, true, &sfft::launch_regtile_mixed<40, 25>, nullptr},
+    {1000, 40, 25, true, true, &sfft::launch_regtile_mixed<40, 25>, &sfft::launch_gate_grad_mixed<25, 40>},   // (gradient: 25 x 40, even RS)
     {2000, 50, 40, true, true, &sfft::launch_regtile_mixed<50, 40>, &sfft::launch_gate_grad_mixed<50, 40>},
     {1280, 40, 32, true, true, &sfft::launch_regtile_mixed<40, 32>, &sfft::launch_gate_grad_mixed<40, 32>},
     {2560, 64, 40, true, true, &sfft::launch_regtile_mixed<64, 40>, &sfft::launch_gate_grad_mixed<64, 40>},

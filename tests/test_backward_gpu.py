@@ -36,7 +36,7 @@ SHAPES = [(2, 4096, 64, 4, 4096), (2, 2048, 32, 2, 2048), (3, 1024, 48, 3, 1024)
           (2, 3000, 32, 2, 3000), (2, 97, 12, 2, 97), (2, 1000, 32, 2, 1024), (2, 5000, 32, 2, 4096), (2, 60, 6, 2, 60), (2, 64, 10, 2, 64),
           # register-tile gate gradient: ragged channel tiles (d_g = 6, 5, 20), many tiles per group (d_g = 200), short input
           (2, 256, 12, 2, 256), (2, 512, 15, 3, 512), (3, 1024, 40, 2, 1024), (1, 2048, 200, 1, 2048), (2, 100, 24, 1, 256),
-          # mixed-radix register-tile gate gradient (RS even); 1000 = 40 x 25 stays on the Stockham path
+          # mixed-radix register-tile gate gradient (RS even; 1000 runs it as 25 x 40)
           (2, 3000, 64, 4, 3000), (2, 2500, 24, 2, 3000), (2, 768, 32, 2, 768), (2, 1536, 40, 2, 1536), (1, 3072, 32, 2, 3072),
           (2, 2000, 32, 4, 2000), (2, 1280, 32, 2, 1280), (1, 2560, 48, 2, 2560), (1, 3840, 32, 2, 3840), (2, 1000, 32, 2, 1000),
           (3, 64, 32, 2, 64), (2, 128, 24, 2, 128), (2, 196, 32, 2, 196), (2, 384, 32, 2, 384), (2, 640, 32, 2, 640), (2, 960, 20, 2, 960),
