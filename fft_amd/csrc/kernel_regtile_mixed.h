@@ -301,6 +301,15 @@ spectre_mix_regtile_mixed(const RegtileArgs a) {
   }
 }
 
+// mixed_m0() assumes the exchange image starts the workgroup's LDS (M0 bases below 4096 + kMixedM0Hi <= 65535): true as long as a kernel
+// has no static __shared__ in front of its dynamic LDS.  Checked once per kernel at its first launch.
+inline hipError_t mixed_check_lds_layout(const void* kern) {
+  hipFuncAttributes attr;
+  hipError_t e = hipFuncGetAttributes(&attr, kern);
+  if (e != hipSuccess) return e;
+  return attr.sharedSizeBytes == 0 ? hipSuccess : hipErrorInvalidConfiguration;
+}
+
 template <int RF, int RS>
 hipError_t launch_regtile_mixed(const RegtileArgs& a, bool in_bf16, bool out_bf16, int mode, hipStream_t stream);
 
@@ -319,6 +328,7 @@ hipError_t launch_regtile_mixed(const RegtileArgs& a, bool in_bf16, bool out_bf1
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                              \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
         if (e != hipSuccess) return e;                                                                       \
+        if ((e = mixed_check_lds_layout(reinterpret_cast<const void*>(kern))) != hipSuccess) return e;       \
         if (dev >= 0 && dev < 16) lds_opt_in[dev][key] = true;                                               \
       }                                                                                                      \
       hipLaunchKernelGGL(kern, grid, block, lds, stream, a);                                                 \
@@ -359,6 +369,7 @@ hipError_t launch_regtile_mixed(const RegtileArgs& a, bool in_bf16, bool out_bf1
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                              \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
         if (e != hipSuccess) return e;                                                                       \
+        if ((e = mixed_check_lds_layout(reinterpret_cast<const void*>(kern))) != hipSuccess) return e;       \
         if (dev >= 0 && dev < 16) lds_opt_in[dev][key] = true;                                               \
       }                                                                                                      \
       hipLaunchKernelGGL(kern, grid, block, lds, stream, a);                                                 \

@@ -169,6 +169,7 @@ hipError_t launch_gate_grad_mixed(const GateGradArgs& a, bool io_bf16, bool gene
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                              \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
         if (e != hipSuccess) return e;                                                                       \
+        if ((e = mixed_check_lds_layout(reinterpret_cast<const void*>(kern))) != hipSuccess) return e;       \
         if (dev >= 0 && dev < 16) lds_opt_in[dev][key] = true;                                               \
       }                                                                                                      \
       hipLaunchKernelGGL(kern, grid, block, lds, stream, a);                                                 \

@@ -20,6 +20,7 @@ namespace sfft {
     if (dev < 0 || dev >= 16 || !lds_opt_in[dev]) {                                                                     \
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
       if (e != hipSuccess) return e;                                                                                    \
+      if ((e = mixed_check_lds_layout(reinterpret_cast<const void*>(kern))) != hipSuccess) return e;                    \
       if (dev >= 0 && dev < 16) lds_opt_in[dev] = true;                                                                 \
     }                                                                                                                   \
     hipLaunchKernelGGL(kern, dim3(a.n_wg), dim3(mixed_threads<RF_, RS_>()), lds, stream, a);                            \
