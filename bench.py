@@ -255,6 +255,12 @@ def main():
             byt = 2 * B * N * D * V.element_size()     # dV: read dOut, write dV; dgate: read V and dOut
             variants[name] = {"tokens_per_s": B * N / (ms * 1e-3), "kernel_ms": ms, "achieved_GBps": byt / ms / 1e6,
                               "roofline_frac": byt / ms / 1e6 / HBM_PEAK_GBS}
+        # the gate gradient reads V and dOut in 32-byte row segments (8 fp32 channels per tile): what a LOAD-ONLY pass with that pattern
+        # reaches here (C ABI spectre_probe_copy, 32-byte segments of 4096 rows), next to the kernel
+        if V.is_contiguous() and V.dtype == torch.float32 and (B * N * D * 4) % (256 * 1024) == 0 and N % 4096 == 0:
+            ld = min(copy_probe(V, out, 32, mode="load", wgs_per_cu=w, warmup=5, iters=10) for w in (1, 2, 4))
+            g32 = B * N * D * 4 / ld / 1e6
+            variants["backward_dgate"].update({"load_only_32B_segments_GBps": g32, "frac_of_32B_load_only": variants["backward_dgate"]["achieved_GBps"] / g32})
         del dout
 
     if rank == 0:
