@@ -205,7 +205,12 @@ __global__ void __launch_bounds__(kPC * RS) spectre_gate_grad_regtile(const Gate
           const float q = z[j].x * pi + z[j].y * pr;                                   // Im(A A')
           const float e = (z[j].x * z[j].x + z[j].y * z[j].y) - (pr * pr + pi * pi);   // |A|^2 - |A'|^2
           const float sr = team_sum8(0.5f * q), si = team_sum8(-0.25f * e);
-          if (p == 0) {                               // bin k1 + RF*k2 belongs to this team alone: plain read-modify-write
+          // bin k1 + RF*k2 belongs to this team alone, and after team_sum8 its eight lanes hold the same sums: ALL of them do the
+          // read-modify-write (same address, same value).  Guarding it with `if (p == 0)` made every bin its own basic block — 32 serial
+          // chains of LDS read, DPP adds, LDS read-modify-write per tile, nothing overlapped (s_memtime: the product phase took as long
+          // as both transforms together).
+          // (short transforms keep the guard: 0.52 -> 0.56 ms at (512,512,768) without it)
+          if (N > 512 || p == 0) {
             float2 cur = acc[k1 + RF * k2];
             cur.x += sr; cur.y += si;
             acc[k1 + RF * k2] = cur;
