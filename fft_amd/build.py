@@ -48,13 +48,15 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm under /opt/rocm)")
 
 
-# Translation units whose kernels read LDS-DMA landing slots behind a hand-counted `s_waitcnt vmcnt(N)`: tools/isa_lint.py recounts N in
-# the emitted ISA after every (re)compile and the build FAILS on a mismatch (a compiler that splits, merges or reorders one of those
-# memory instructions would otherwise turn the wait into a silent race).
-LINTED = {"regtile_n4096p.hip": ("regtile64p", "vmcnt"),     # hand-counted s_waitcnt vmcnt(N) in front of the LDS-DMA landing slots
-          "regtile_mixedp.hip": ("mixedp", "lds"),            # inline-asm ds_read_b32 consumed behind s_waitcnt lgkmcnt(0); M0-based writes
-          "regtile_n3000.hip": ("regtile_mixed", "addtid")}   # M0-based LDS writes of the one-tile mixed-radix kernels (one representative TU)
-LINT = os.path.normpath(os.path.join(HERE, "..", "tools", "isa_lint.py"))
+# ISA lint (fft_amd/isa_lint.py): every translation unit is compiled with -save-temps, and the gfx950 listing that leaves behind is
+# checked BEFORE the object is accepted — the build FAILS on a finding (a compiler that splits, merges or reorders one of the instructions
+# the hand-written synchronisation counts on would otherwise turn it into a silent race):
+#   * every kernel of every unit that contains a `ds_write_addtid_b32` (all mixed-radix forward and gate-gradient kernels): each one behind
+#     its own `s_mov_b32 m0`, no compiler-generated use of M0 (-Wno-inline-asm hides clang's own warning about M0);
+#   * the units below additionally: hand-counted `s_waitcnt vmcnt(N)` in front of the LDS-DMA landing slots / inline-asm ds_read_b32
+#     consumed behind `s_waitcnt lgkmcnt(0)`.
+LINTED = {"regtile_n4096p.hip": {"vmcnt_kernel": "regtile64p"},
+          "regtile_mixedp.hip": {"lds_kernel": "mixedp"}}
 
 
 def _newest(paths):
@@ -80,22 +82,36 @@ def build(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(hdr_time, os.path.getmtime(os.path.join(CSRC, src))):
             return obj                                # up to date (every translation unit includes most of the headers)
-        cmd = [cc, *CXXFLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        # -save-temps=obj in a scratch directory of its own: the device listing (.s) is a by-product of the compile that the lint reads
+        tmp = os.path.join(OBJDIR, "tmp_" + src.replace(".hip", ""))
+        shutil.rmtree(tmp, ignore_errors=True)
+        os.makedirs(tmp)
+        tobj = os.path.join(tmp, os.path.basename(obj))
+        cmd = [cc, *CXXFLAGS, "-save-temps=obj", "-c", os.path.join(CSRC, src), "-o", tobj]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
+            shutil.rmtree(tmp, ignore_errors=True)
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
         if verbose and r.stderr.strip():
             print(r.stderr, file=sys.stderr)
-        if src in LINTED:
-            lint = subprocess.run([sys.executable, LINT, os.path.join(CSRC, src), "--kernel", LINTED[src][0], "--check", LINTED[src][1], "--flags", " ".join(CXXFLAGS)],
-                                  capture_output=True, text=True, env={**os.environ, "HIPCC": cc})
+        listing = os.path.join(tmp, src.replace(".hip", "") + "-hip-amdgcn-amd-amdhsa-gfx950.s")
+        try:
+            if not os.path.exists(listing):
+                raise RuntimeError(f"ISA lint: hipcc left no device listing for {src} ({listing})")
+            from . import isa_lint                     # part of the package: an installed / vendored copy lints its own builds
+            errors, notes = isa_lint.lint_listing(listing, **LINTED.get(src, {}))
             if verbose:
-                print(lint.stdout, end="", flush=True)
-            if lint.returncode != 0:
-                os.unlink(obj)                       # do not leave an object behind that the next build would take as up to date
-                raise RuntimeError(f"ISA lint failed for {src}:\n{lint.stdout}\n{lint.stderr}")
+                for n in notes:
+                    print(f"isa_lint[{src}]:", n, flush=True)
+            if src in LINTED and not notes:
+                errors.append(f"{src}: the lint found none of the kernels it is meant to check ({LINTED[src]})")
+            if errors:
+                raise RuntimeError(f"ISA lint failed for {src}:\n" + "\n".join(errors))
+            os.replace(tobj, obj)                      # accepted: only now does an object exist that the next build takes as up to date
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
         return obj
 
     # heaviest translation units first (64-point kernels), so the long poles do not start last

@@ -9,6 +9,13 @@
 //                   owns; 32 = its bf16 rows; 128 = a whole L2 line per row).  Tiles that share 128-byte lines are neighbours in the
 //                   XCD-contiguous order and are walked in step by 128 / S neighbouring workgroups, exactly like the product kernels.
 //   mode 0 copy, 1 load only (the values are consumed by a never-true store), 2 store only
+// Round 4 ("a ceiling that agrees with the hardware guide"): the persistent forms above top out at 5.0-5.8 TB/s
+// where MI355X_MICROARCH.md records 6.29 TB/s for "a float4 copy".  tools/copy_ceiling.hip found the form that reaches it on these
+// boxes — the plain NON-persistent copy, one 256-thread workgroup per 4 KiB, one 16-byte load and one 16-byte store per lane —
+// and bench.py now measures it beside the product (copy mode only):
+//   seg_bytes = -1  flat float4 copy (6.25-6.31 TB/s on 3 GiB -> 3 GiB)
+//   seg_bytes = -2  the same with non-temporal loads and stores (6.56-6.57 TB/s)
+//   seg_bytes = -3  hipMemcpyAsync device-to-device (4.9-5.2 TB/s)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "kernel_regtile.h"
@@ -63,11 +70,52 @@ __global__ void __launch_bounds__(kProbeThreads) spectre_probe_copy_kernel(const
   }
 }
 
+template <bool NT>
+__global__ void __launch_bounds__(256) spectre_probe_flat_kernel(const probe_f32x4* __restrict__ src, probe_f32x4* __restrict__ dst) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if constexpr (NT) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+  else dst[i] = src[i];
+}
+
 // returns a SPECTRE_E_* code; *why = a static message on failure (the extern "C" wrapper in spectre_hip.hip stores it for spectre_last_error)
 int probe_copy(const SpectreProbeArgs* p, int warmup, int iters, float* ms_per_launch, const char** why) {
   *why = "";
   if (!p || !ms_per_launch || iters < 1 || warmup < 0 || !p->src || !p->dst || p->rows < 1 || p->row_bytes < 16) { *why = "NULL pointer or bad size"; return SPECTRE_E_INVALID; }
   const int seg = p->seg_bytes;
+  if (seg < 0) {          // the flat (non-persistent) copies and the runtime's own device-to-device copy
+    const long long bytes = p->rows * p->row_bytes;
+    if (seg < -3 || p->mode != 0 || bytes % 4096 || bytes / 4096 > 0x7fffffffLL) { *why = "seg_bytes -1 / -2 / -3: copy mode only, whole 4-KiB chunks"; return SPECTRE_E_INVALID; }
+    *why = "HIP runtime call failed";
+    int prev = 0;
+    if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(p->device) != hipSuccess) return SPECTRE_E_HIP;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(p->stream);
+    const probe_f32x4* s = static_cast<const probe_f32x4*>(p->src);
+    probe_f32x4* d = static_cast<probe_f32x4*>(p->dst);
+    const dim3 grid((unsigned)(bytes / 4096));
+    auto go = [&]() -> hipError_t {
+      if (seg == -1) hipLaunchKernelGGL(spectre_probe_flat_kernel<false>, grid, dim3(256), 0, stream, s, d);
+      else if (seg == -2) hipLaunchKernelGGL(spectre_probe_flat_kernel<true>, grid, dim3(256), 0, stream, s, d);
+      else return hipMemcpyAsync(p->dst, p->src, (size_t)bytes, hipMemcpyDeviceToDevice, stream);
+      return hipSuccess;
+    };
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipSetDevice(prev); return SPECTRE_E_HIP; }
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < warmup && e == hipSuccess; ++i) e = go();
+    if (e == hipSuccess) e = hipEventRecord(e0, stream);
+    for (int i = 0; i < iters && e == hipSuccess; ++i) e = go();
+    if (e == hipSuccess) e = hipEventRecord(e1, stream);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e == hipSuccess) e = hipGetLastError();
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipSetDevice(prev);
+    if (e != hipSuccess) return SPECTRE_E_HIP;
+    *ms_per_launch = ms / (float)iters;
+    *why = "";
+    return SPECTRE_OK;
+  }
   if (seg != 0 && (seg < 16 || (seg & (seg - 1)) || seg > 1024 || p->row_bytes % seg || p->tile_rows < 1 || p->rows % p->tile_rows)) {
     *why = "seg_bytes must be 0 or a power of two in 16..1024 that divides row_bytes; tile_rows must divide rows"; return SPECTRE_E_INVALID; }
   if (seg != 0 && ((long long)seg * p->tile_rows) % (kProbeThreads * 16 * kProbeInFlight)) { *why = "a tile must be whole 128-KiB chunks"; return SPECTRE_E_INVALID; }

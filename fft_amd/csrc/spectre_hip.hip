@@ -142,6 +142,20 @@ const TileSize* find_tile_size(int64_t n) {
 
 thread_local std::string g_err;
 
+// Tuning aids (A/B switches for measurements): the SPECTRE_* environment variables below are read ONLY when the master
+// switch SPECTRE_TUNING=1 is set — the shipped library's dispatch cannot be changed from the environment by accident — and every
+// override that is in force is named by spectre_mix_describe ("[tuning: ...]").
+const char* tuning_env(const char* name) {
+  static const bool on = [] { const char* e = getenv("SPECTRE_TUNING"); return e && atoi(e) == 1; }();
+  return on ? getenv(name) : nullptr;
+}
+std::string tuning_overrides() {
+  std::string r;
+  for (const char* n : {"SPECTRE_P64", "SPECTRE_P64_BF16", "SPECTRE_MIXEDP", "SPECTRE_STOCKHAM_PMAX", "SPECTRE_TPW", "SPECTRE_P64_TPW", "SPECTRE_GATE_GRAD"})
+    if (const char* e = tuning_env(n)) r += std::string(r.empty() ? "" : " ") + n + "=" + e;
+  return r;
+}
+
 int fail(int code, const char* fmt, ...) {
   char buf[512];
   va_list ap;
@@ -187,8 +201,9 @@ std::mutex g_mu;
 std::map<std::pair<int, int64_t>, std::unique_ptr<Plan>> g_plans;
 // Plans taken out of service by spectre_plan_destroy.  They are NOT freed: a launch path uses its plan (host object and device tables)
 // after the registry lock is released, and a kernel reads the tables until it retires, so freeing here would be a use-after-free the
-// library cannot see coming (round 2 documented it as a contract; round 3 removes it).  A retired plan costs a few tens of KiB, is put
-// back into service by the next spectre_plan_create / launch for the same (device, n_fft), and is released at process exit.
+// library cannot see coming (round 2 documented it as a contract; round 3 removes it).  A retired plan keeps its device tables (32 KiB
+// at n_fft = 4096; a long Bluestein length carries four tables, about 1 MiB), is put back into service by the next spectre_plan_create /
+// launch for the same (device, n_fft), and is released by spectre_plans_release_retired (caller-synchronised) or at process exit.
 std::map<std::pair<int, int64_t>, std::unique_ptr<Plan>> g_retired;
 
 bool factorize(int64_t n, std::vector<int>& out) {
@@ -359,10 +374,10 @@ int choose(const SpectreMixArgs* a, const Plan* plan, Choice* c) {
     else if (!ts->mixed) mode = (d_g % 16 != 0) ? (a->mem ? 2 : 1) : a->mem ? 4 : (a->N_in < a->n_fft) ? 3 : 0;   // 3, 4: gate still in LDS
     else mode = a->mem ? 2 : (d_g % 16 != 0) ? 1 : (a->N_in < a->n_fft) ? 3 : 0;
   }
-  static const bool p64_off = [] { const char* e = getenv("SPECTRE_P64"); return e && atoi(e) == 0; }();   // A/B switch (tuning aid)
+  static const bool p64_off = [] { const char* e = tuning_env("SPECTRE_P64"); return e && atoi(e) == 0; }();   // A/B switch (tuning aid)
   // fast mode, padded sequences (mode 3: rows >= N_in are the buffer instructions' out-of-range case) and memory_fft (mode 4);
   // 32-bit byte offsets
-  static const bool p64_bf16_off = [] { const char* e = getenv("SPECTRE_P64_BF16"); return e && atoi(e) == 0; }();
+  static const bool p64_bf16_off = [] { const char* e = tuning_env("SPECTRE_P64_BF16"); return e && atoi(e) == 0; }();
   const bool in_bf = a->in_dtype == SPECTRE_BF16;     // a lane moves the 4 channels of a row: 16 bytes of fp32, 8 of bf16
   const bool out_bf = a->out_dtype == SPECTRE_BF16;   // built: f32 -> f32 (+ memory_fft), bf16 -> f32, bf16 -> bf16
   const bool pipelined_ok = can_regtile && ts && !ts->mixed && ts->tile_ch == 16 && !p64_off && n == 4096 && (mode == 0 || mode == 3 || mode == 4) &&
@@ -384,7 +399,7 @@ int choose(const SpectreMixArgs* a, const Plan* plan, Choice* c) {
     c->tile = ts; c->RF = ts->RF; c->RS = ts->RS;
     c->mode = mode;
     c->pipelined = pipelined_ok;
-    static const bool mixedp_off = [] { const char* e = getenv("SPECTRE_MIXEDP"); return e && atoi(e) == 0; }();
+    static const bool mixedp_off = [] { const char* e = tuning_env("SPECTRE_MIXEDP"); return e && atoi(e) == 0; }();
     c->mixedp = !mixedp_off && ts->mixed && (n == 3000 || n == 2560 || n == 2400 || n == 3072 || n == 3600 || n == 3840) && (mode == 0 || mode == 3) && a->in_dtype == SPECTRE_F32 && a->out_dtype == SPECTRE_F32 &&
                 reinterpret_cast<uintptr_t>(a->v) % 8 == 0 && reinterpret_cast<uintptr_t>(a->out) % 8 == 0 &&
                 a->v_sn % 2 == 0 && a->v_sb % 2 == 0 && a->out_sn % 2 == 0 && a->out_sb % 2 == 0 &&
@@ -399,7 +414,7 @@ int choose(const SpectreMixArgs* a, const Plan* plan, Choice* c) {
   c->S = (int)(c->solo ? D : D / 2);
   int64_t P = (int64_t)kLdsBytes / (8 * L);
   if (P > 16) P = 16;
-  { static const int pmax = [] { const char* e = getenv("SPECTRE_STOCKHAM_PMAX"); return e ? atoi(e) : 0; }(); if (pmax > 0 && P > pmax) P = pmax; }
+  { static const int pmax = [] { const char* e = tuning_env("SPECTRE_STOCKHAM_PMAX"); return e ? atoi(e) : 0; }(); if (pmax > 0 && P > pmax) P = pmax; }
   if (P > c->S) P = c->S;
   for (int r : rad) {
     const int64_t cap = (int64_t)sfft::kStockhamMaxThreads * sfft::stockham_kmax(r) * r / L;
@@ -420,7 +435,7 @@ int choose(const SpectreMixArgs* a, const Plan* plan, Choice* c) {
 // 5-10 % at n_fft <= 1024, where several workgroups per CU overlap each other and finer dispatch balances better.
 // One tile per workgroup therefore; SPECTRE_TPW overrides (tuning aid).
 int tiles_per_workgroup(int n_tiles) {
-  static const int forced = [] { const char* e = getenv("SPECTRE_TPW"); return e ? atoi(e) : 0; }();
+  static const int forced = [] { const char* e = tuning_env("SPECTRE_TPW"); return e ? atoi(e) : 0; }();
   (void)n_tiles;
   return forced > 0 ? forced : 1;
 }
@@ -465,7 +480,7 @@ int launch(const SpectreMixArgs* a, const Plan* plan, const Choice& c, bool conj
     if (c.tile->mixed) { k.tpw = 1; k.n_wg = 2 * ((k.n_tiles + 1) / 2); }
     if (c.pipelined) {   // one workgroup per CU walks through tpw tiles; pairs of workgroups stay on adjacent tiles
       const int ncu = cu_count(a->device);
-      static const int forced = [] { const char* e = getenv("SPECTRE_P64_TPW"); return e ? atoi(e) : 0; }();
+      static const int forced = [] { const char* e = tuning_env("SPECTRE_P64_TPW"); return e ? atoi(e) : 0; }();
       const int gang = (ib || ob) ? 4 : 2;                  // kP64Gang: workgroups that share a 128-byte line walk through adjacent tiles
       const int slots = std::max(gang, ncu / gang * gang);
       k.tpw = forced > 0 ? forced : std::max(1, (k.n_tiles + slots - 1) / slots);
@@ -558,6 +573,19 @@ int spectre_plan_destroy(int device, int64_t n_fft) {
   return SPECTRE_OK;
 }
 
+int spectre_plans_release_retired(int device) {
+  // Frees what spectre_plan_destroy only retired.  The caller vouches that no launch that used those plans is still in flight and no
+  // other thread is inside a spectre_* call for them (typically: right after a device synchronisation) — exactly the knowledge the
+  // library does not have, which is why spectre_plan_destroy itself never frees.
+  std::lock_guard<std::mutex> lk(g_mu);
+  int n = 0;
+  for (auto it = g_retired.begin(); it != g_retired.end();) {
+    if (device < 0 || it->first.first == device) { it = g_retired.erase(it); ++n; }
+    else ++it;
+  }
+  return n;
+}
+
 int spectre_mix_fwd(const SpectreMixArgs* a) {
   if (!a) return fail(SPECTRE_E_INVALID, "args is NULL");
   DeviceGuard g(a->device);
@@ -590,6 +618,8 @@ int spectre_mix_describe(const SpectreMixArgs* a, char* buf, size_t cap) {
              (long long)(plan->bluestein ? plan->m : a->n_fft), r.c_str(), plan->bluestein ? 1 : 0, in, out,
              c.why_not_regtile[0] ? c.why_not_regtile : "not selected");
   }
+  const std::string ov = tuning_overrides();
+  if (!ov.empty()) { const size_t l = strlen(buf); snprintf(buf + l, cap - l, " [tuning: %s]", ov.c_str()); }
   return SPECTRE_OK;
 }
 
@@ -686,7 +716,7 @@ int spectre_mix_bwd(const SpectreMixBwdArgs* a) {
     if ((rc = get_plan(a->device, a->n_fft, &plan))) return rc;
     const int64_t n = a->n_fft, D = a->D, d_g = D / a->G_tot;
     const TileSize* ts = find_tile_size(n);
-    static const bool force_stockham = [] { const char* e = getenv("SPECTRE_GATE_GRAD"); return e && !strcmp(e, "stockham"); }();
+    static const bool force_stockham = [] { const char* e = tuning_env("SPECTRE_GATE_GRAD"); return e && !strcmp(e, "stockham"); }();
     // (32-bit buffer offsets: a tile's last row has to lie below 2^31 bytes from its first; wider views take the Stockham path)
     if (ts && ts->grad && !force_stockham && std::max<int64_t>(n, 128) * a->v_sn * 4 < ((int64_t)1 << 31) &&
         std::max<int64_t>(n, 128) * a->dout_sn * 4 < ((int64_t)1 << 31) && a->B * a->G_tot * 8 < ((int64_t)1 << 31)) {

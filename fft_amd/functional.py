@@ -176,7 +176,8 @@ def copy_probe(src: torch.Tensor, dst: torch.Tensor, seg_bytes: int = 0, *, tile
                wgs_per_cu: int = 0, warmup: int = 2, iters: int = 5) -> float:
     """Milliseconds per launch of a PURE COPY of `src` into `dst` with the product kernels' access pattern (C ABI `spectre_probe_copy`;
     measurement only, used by bench.py for the driver-visible memory ceilings).  src / dst: contiguous (B, N, D) tensors of one dtype.
-    seg_bytes 0 = dense copy; S = every workgroup moves S bytes of `tile_rows` consecutive rows (64 = the fp32 tile of the 4096 kernel)."""
+    seg_bytes 0 = dense copy; S = every workgroup moves S bytes of `tile_rows` consecutive rows (64 = the fp32 tile of the 4096 kernel);
+    -1 = the plain non-persistent float4 copy (one workgroup per 4 KiB), -2 = the same with non-temporal accesses, -3 = hipMemcpyAsync."""
     lib = _native.load()
     if not (src.is_cuda and dst.is_cuda and src.is_contiguous() and dst.is_contiguous() and src.shape == dst.shape and src.dtype == dst.dtype
             and src.dim() == 3):

@@ -15,7 +15,7 @@ A guard taken in the steady state is checked against the DMA instructions inside
 against the prologue's.  The source says which is which with a comment inside the asm statement (`s_waitcnt vmcnt(N) ; lint: steady` /
 `; lint: first` — the comment survives into the -S listing); an untagged pair is told apart by N (the smaller count is the prologue's).
 
-    python tools/isa_lint.py fft_amd/csrc/regtile_n4096p.hip [--kernel regtile64p] [--asm out.s] [--flags "..."]
+    python -m fft_amd.isa_lint fft_amd/csrc/regtile_n4096p.hip [--kernel regtile64p] [--asm out.s] [--flags "..."]
 
 A second check (--check lds) covers the untracked LDS reads of kernel_regtile_mixedp.h: its exchanges read the image with inline-asm
 `ds_read_b32` whose results hipcc's s_waitcnt insertion does not know about; they are consumed behind rt_lds_barrier() (s_waitcnt
@@ -24,7 +24,7 @@ mentions its destination register before an `s_waitcnt` with lgkmcnt(0) has been
 `ds_write_addtid_b32` (base in M0, set inside each asm statement): --check addtid (part of --check lds) verifies that every one follows
 its own `s_mov_b32 m0` and that no compiler-generated instruction of the kernel touches M0.
 
-    python tools/isa_lint.py fft_amd/csrc/regtile_mixedp.hip --kernel mixedp --check lds
+    python -m fft_amd.isa_lint fft_amd/csrc/regtile_mixedp.hip --kernel mixedp --check lds
 """
 from __future__ import annotations
 
@@ -265,6 +265,29 @@ def lint_addtid(name, blocks):
     if n == 0:
         errors.append(f"{name}: no ds_write_addtid_b32 found")
     return errors, [f"{name}: {n} ds_write_addtid_b32, each behind its own s_mov_b32 m0; no other use of M0"]
+
+
+def lint_listing(asm_path, vmcnt_kernel=None, lds_kernel=None):
+    """Every check that applies to one gfx950 listing (hipcc -S, or the .s that -save-temps leaves behind) -> (errors, notes).
+
+    * every kernel that contains a `ds_write_addtid_b32` gets the M0 check (no name filter: all mixed-radix forward and gate-gradient
+      kernels use those asm statements, ADVICE r03);
+    * kernels whose name contains `vmcnt_kernel` get the hand-counted-guard check, those containing `lds_kernel` the untracked-read check."""
+    errors, notes = [], []
+    for name, blocks in parse_kernels(asm_path).items():
+        if any(x.op == "ds_write_addtid_b32" for b in blocks for x in b["ins"]):
+            e, n = lint_addtid(name, blocks)
+            errors += e
+            notes += n
+        if vmcnt_kernel and vmcnt_kernel in name:
+            e, n = lint_kernel(name, blocks)
+            errors += e
+            notes += n
+        if lds_kernel and lds_kernel in name:
+            e, n = lint_lds_reads(name, blocks)
+            errors += e
+            notes += n
+    return errors, notes
 
 
 def main(argv=None):

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SPECTRE_ABI_VERSION 7
+#define SPECTRE_ABI_VERSION 8
 
 enum {
   SPECTRE_OK = 0,
@@ -90,10 +90,17 @@ int spectre_mix_describe(const SpectreMixArgs* args, char* buf, size_t cap);
  * caches them on demand; explicit creation lets a caller pay the one-time upload outside a timed or
  * graph-captured region.  spectre_plan_destroy takes the plan out of service; it is safe at any time, also while launches that
  * use the plan are in flight or other threads are inside spectre_* calls for the same (device, n_fft): the tables are retired, not
- * freed (a few tens of KiB, reused by the next create / launch for that length, released at process exit).  A call on a CAPTURING stream whose plan
+ * freed (32 KiB at n_fft = 4096, about 1 MiB for a long Bluestein length; reused by the next create / launch for that length, released by
+ * spectre_plans_release_retired below or at process exit).  A call on a CAPTURING stream whose plan
  * does not exist yet returns SPECTRE_E_INVALID instead of building it (the upload would invalidate the capture). */
 int spectre_plan_create(int device, int64_t n_fft);
 int spectre_plan_destroy(int device, int64_t n_fft);
+/* Frees the tables of every plan spectre_plan_destroy has retired on `device` (all devices if device < 0) and returns how many plans were
+ * released.  The CALLER guarantees what the library cannot know: no launch that used those plans is still in flight and no other thread is
+ * inside a spectre_* call for them — call it behind a device synchronisation.  A process that cycles through many n_fft values (long
+ * Bluestein lengths carry about 1 MiB of tables each) uses this to keep device memory bounded.  No counterpart in the reference (torch.fft
+ * keeps its own plan cache: spectre.py:506, :551). */
+int spectre_plans_release_retired(int device);
 
 /* Backward of spectre_mix_fwd (autograd through spectre.py:506, :542-553):
  *   dv    (B, N_in, D)   = mix(dout, conj(gate))  zero-padded back to N_in rows   — same kernels as the forward
@@ -254,6 +261,8 @@ int spectre_decode_head_step(const SpectreDecodeHeadArgs* args);
  *   seg_bytes = S  the product kernels' pattern: a workgroup moves S bytes of `tile_rows` consecutive rows (S = 64: the 16 fp32 channels
  *                  x 4096 rows one workgroup of the 4096 kernel owns; 32: its bf16 rows; 128: a whole L2 line per row), tiles that share
  *                  a 128-byte line walked in step by neighbouring workgroups, like the product kernels do
+ *   seg_bytes = -1 the plain NON-persistent float4 copy (one 256-thread workgroup per 4 KiB — the form MI355X_MICROARCH.md quotes at
+ *                  6.29 TB/s), -2 the same with non-temporal loads and stores, -3 hipMemcpyAsync device-to-device (copy mode only)
  *   mode 0 copy src -> dst, 1 load only, 2 store only.  wgs_per_cu: persistent workgroups per CU (0 = 2).
  * Replaces nothing in the reference (no counterpart in spectre.py). */
 typedef struct SpectreProbeArgs {

@@ -1,7 +1,8 @@
 """bench.py --gpus 2 executed for real: two ranks (one process each, `python -m torch.distributed.run` started by bench.py itself) on the
-ONE GPU of the test box (SPECTRE_BENCH_OVERSUBSCRIBE=1), RCCL ("nccl") process group first, gloo as the fallback if RCCL refuses two
-ranks on one device.  Checks the contract of the N > 1 line: n_gpus, whole-job value = 2 x per-rank rate, MAX-over-ranks timing, and
-that two ranks sharing a device each get about half of it."""
+ONE GPU of the test box (SPECTRE_BENCH_OVERSUBSCRIBE=1), through the SAME rendezvous code an 8-GPU run uses (fft_amd/rendezvous.py: gloo
+control plane, census of devices, RCCL attempted only when every rank drives its own device — here two ranks share one, RCCL refuses
+that, and the line must say `rendezvous: gloo` and why).  Checks the contract of the N > 1 line: n_gpus, whole-job value = 2 x per-rank
+rate, MAX-over-ranks timing, `ranks_seen`, and that two ranks sharing a device each get about half of it."""
 import json
 import os
 import subprocess
@@ -28,12 +29,13 @@ def test_two_ranks_on_one_gpu():
     args = ["--steps", "10", "--warmup", "3", "--prewarm", "30", "--shape", shape, "--no-cpu-baseline"]
     out1, one = _run({}, ["--gpus", "1", *args])
     assert out1.returncode == 0 and one is not None, out1.stderr[-2000:]
-    backend = "nccl"
     out2, two = _run({"SPECTRE_BENCH_OVERSUBSCRIBE": "1"}, ["--gpus", "2", *args])
-    if out2.returncode != 0 or two is None:                # RCCL may refuse two ranks on one device: the data path has no collective, gloo will do
-        backend = "gloo"
-        out2, two = _run({"SPECTRE_BENCH_OVERSUBSCRIBE": "1", "SPECTRE_BENCH_BACKEND": "gloo"}, ["--gpus", "2", *args])
-    assert out2.returncode == 0 and two is not None, (backend, out2.stderr[-3000:])
+    assert out2.returncode == 0 and two is not None, out2.stderr[-3000:]
+    backend = two["rendezvous"]
+    assert backend == "gloo" and two["oversubscribed"] and "share one device" in two["rendezvous_fallback"]
+    assert [r["rank"] for r in two["ranks_seen"]] == [0, 1] and two["distinct_devices"] == 1
+    assert len({r["pid"] for r in two["ranks_seen"]}) == 2
+    assert one["rendezvous"] == "none" and len(one["ranks_seen"]) == 1
     print(f"backend {backend}: 1 rank {one['value']:.4g} tok/s, 2 ranks on one GPU {two['value']:.4g} tok/s whole job")
     assert two["n_gpus"] == 2 and two["scaling"] == "weak" and two["steps"] == 10
     assert two["config"]["global_batch"] == 128 and "batch-shard x2" in two["config"]["parallelism"]
@@ -46,3 +48,32 @@ def test_two_ranks_on_one_gpu():
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "bench_w2_oversubscribed.json"), "w") as f:
         json.dump({"backend": backend, "one_rank": one, "two_ranks_one_gpu": two}, f)
+
+
+def _rccl_world1(rank, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    from fft_amd.rendezvous import Rendezvous, _prove_nccl
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    group = _prove_nccl(dev, 60.0)                        # RCCL group BESIDE the gloo one + barrier + MAX all-reduce of a device tensor
+    rdv = Rendezvous(world=1, rank=0, backend="nccl", _nccl_group=group, _device=dev)
+    rdv.barrier()
+    got = rdv.max_over_ranks([1.25, 7.5])
+    with open(os.path.join(tmp, "ok.json"), "w") as f:
+        json.dump({"got": got}, f)
+    rdv.close()
+
+
+def test_rccl_branch_of_the_rendezvous_runs_on_hardware(tmp_path):
+    """The one part of the 8-GPU rendezvous a 1-GPU box CAN run on hardware: the RCCL group created next to the gloo default group, its
+    barrier (device_ids) and the device-tensor MAX all-reduce — with a world of one rank, which RCCL accepts."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_rccl_world1, args=(port, str(tmp_path)), nprocs=1, join=True)
+    assert json.load(open(tmp_path / "ok.json"))["got"] == [1.25, 7.5]

@@ -1,4 +1,4 @@
-"""tools/isa_lint.py: the build-time recount of the hand-counted `s_waitcnt vmcnt(N)` in front of the LDS-DMA landing slots
+"""fft_amd/isa_lint.py: the build-time recount of the hand-counted `s_waitcnt vmcnt(N)` in front of the LDS-DMA landing slots
 (kernel_regtile64p.h).  Runs on a synthetic assembly listing — no compiler, no GPU."""
 import importlib.util
 import os
@@ -6,7 +6,7 @@ import os
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-spec = importlib.util.spec_from_file_location("isa_lint", os.path.join(ROOT, "tools", "isa_lint.py"))
+spec = importlib.util.spec_from_file_location("isa_lint", os.path.join(ROOT, "fft_amd", "isa_lint.py"))
 isa_lint = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(isa_lint)
 

@@ -12,7 +12,7 @@ def _dev():
     return torch.device("cuda:0")
 
 
-@pytest.mark.parametrize("seg", [0, 128, 64, 32])
+@pytest.mark.parametrize("seg", [0, 128, 64, 32, -1, -2, -3])      # -1 / -2: flat float4 copy (plain / non-temporal), -3: hipMemcpyAsync
 def test_copy_probe_copies_every_byte(seg):
     from fft_amd import copy_probe
     dev = _dev()
@@ -39,6 +39,10 @@ def test_copy_probe_load_and_store_modes_and_bad_arguments():
         copy_probe(src, dst, 48)                             # segment size not a power of two (SPECTRE_E_INVALID)
     with pytest.raises(ValueError):
         copy_probe(src, dst, 64, tile_rows=1000)             # tile_rows does not divide the rows
+    with pytest.raises(ValueError):
+        copy_probe(src, dst, -1, mode="load")                # the flat forms are copies only
+    with pytest.raises(ValueError):
+        copy_probe(src, dst, -4)                             # no such form
 
 
 def test_empty_on_fast_allocation():

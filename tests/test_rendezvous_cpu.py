@@ -1,0 +1,134 @@
+"""fft_amd/rendezvous.py — the rank rendezvous bench.py (and the first 8-GPU run) goes through — driven WITHOUT a GPU: a world of two
+gloo processes exercises the census (`ranks_seen`), the barrier, the MAX over ranks and every way the RCCL attempt can end
+(no device, duplicate devices, an exception on one rank, a call that never returns).  VERDICT r03 item 3."""
+import os
+import socket
+import sys
+import time
+import types
+
+import pytest
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _fake_device(index):
+    return types.SimpleNamespace(index=index)            # what rendezvous() needs of a torch.device: .index (the UUID lookup fails -> None)
+
+
+def _prove_raises_on_rank1(device, timeout_s):
+    import torch.distributed as dist
+    if dist.get_rank() == 1:
+        raise RuntimeError("ncclInvalidUsage: duplicate GPU (simulated)")
+    return object()
+
+
+def _prove_hangs_on_rank0(device, timeout_s):
+    import torch.distributed as dist
+    if dist.get_rank() == 0:
+        time.sleep(3600)
+    return object()
+
+
+def _worker(rank, world, port, scenario, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from fft_amd.rendezvous import rendezvous
+    import json
+    kw = {}
+    if scenario == "cpu_only":                          # no HIP device anywhere: RCCL is not even attempted
+        kw = dict(device=None)
+    elif scenario == "exception":                       # distinct devices, RCCL throws on one rank: EVERY rank must fall back
+        kw = dict(device=_fake_device(rank), prove_nccl=_prove_raises_on_rank1)
+    elif scenario == "hang":                            # RCCL never returns on one rank: the time box ends the attempt everywhere
+        kw = dict(device=_fake_device(rank), prove_nccl=_prove_hangs_on_rank0, timeout_s=1.0)
+    elif scenario == "oversubscribed":                  # both ranks on device 0, allowed: gloo, and the line says so
+        kw = dict(device=_fake_device(0), allow_oversubscribe=True, prove_nccl=_prove_raises_on_rank1)
+    elif scenario == "oversubscribed_refused":
+        kw = dict(device=_fake_device(0))
+    elif scenario == "gloo_requested":
+        kw = dict(device=_fake_device(rank), prefer="gloo", prove_nccl=_prove_raises_on_rank1)
+    try:
+        rdv = rendezvous(world, rank, rank, **kw)
+    except RuntimeError as e:
+        with open(os.path.join(tmp, f"r{rank}.json"), "w") as f:
+            json.dump({"raised": str(e)}, f)
+        return
+    rdv.barrier()
+    wall, kern = rdv.max_over_ranks([0.5 + rank, 10.0 - rank])      # bench.py reduces [wall, kernel_ms] this way
+    rec = dict(rdv.describe(), wall=wall, kern=kern, world=rdv.world, rank=rdv.rank)
+    with open(os.path.join(tmp, f"r{rank}.json"), "w") as f:
+        json.dump(rec, f)
+    if scenario == "hang":
+        os._exit(0)                                     # (bench.py does the same: the stuck thread must not keep the process alive)
+    rdv.close()
+
+
+def _run(tmp_path, scenario):
+    import json
+    mp.spawn(_worker, args=(2, _free_port(), scenario, str(tmp_path)), nprocs=2, join=True)
+    return [json.load(open(tmp_path / f"r{r}.json")) for r in range(2)]
+
+
+def test_single_rank_needs_no_process_group():
+    sys.path.insert(0, ROOT)
+    from fft_amd.rendezvous import rendezvous
+    rdv = rendezvous(1, 0, 0, device=None)
+    assert rdv.backend == "none" and rdv.max_over_ranks([1.5, 2.5]) == [1.5, 2.5]
+    rdv.barrier()
+    d = rdv.describe()
+    assert d["rendezvous"] == "none" and len(d["ranks_seen"]) == 1 and d["rendezvous_fallback"] is None
+    rdv.close()
+
+
+def test_world2_without_devices_uses_gloo(tmp_path):
+    recs = _run(tmp_path, "cpu_only")
+    for r, rec in enumerate(recs):
+        assert rec["rendezvous"] == "gloo" and rec["world"] == 2 and rec["rank"] == r
+        assert rec["wall"] == 1.5 and rec["kern"] == 10.0                    # MAX over ranks
+        assert [x["rank"] for x in rec["ranks_seen"]] == [0, 1]
+        assert len({x["pid"] for x in rec["ranks_seen"]}) == 2               # two processes, both seen by both
+        assert "no HIP device" in rec["rendezvous_fallback"]
+    assert recs[0]["ranks_seen"] == recs[1]["ranks_seen"]
+
+
+def test_exception_on_one_rank_moves_every_rank_to_gloo(tmp_path):
+    recs = _run(tmp_path, "exception")
+    for rec in recs:
+        assert rec["rendezvous"] == "gloo" and rec["wall"] == 1.5 and rec["kern"] == 10.0
+        assert "rank(s) 1" in rec["rendezvous_fallback"] and "duplicate GPU" in rec["rendezvous_fallback"]
+        assert rec["distinct_devices"] == 2 and not rec["oversubscribed"]
+
+
+def test_a_call_that_never_returns_is_time_boxed(tmp_path):
+    t0 = time.time()
+    recs = _run(tmp_path, "hang")
+    assert time.time() - t0 < 60
+    for rec in recs:
+        assert rec["rendezvous"] == "gloo" and rec["wall"] == 1.5
+        assert "rank(s) 0" in rec["rendezvous_fallback"] and "not proven within" in rec["rendezvous_fallback"]
+
+
+def test_two_ranks_on_one_device(tmp_path):
+    recs = _run(tmp_path, "oversubscribed")
+    for rec in recs:
+        assert rec["rendezvous"] == "gloo" and rec["oversubscribed"] and rec["distinct_devices"] == 1
+        assert "share one device" in rec["rendezvous_fallback"]
+    (tmp_path / "b").mkdir()
+    refused = _run(tmp_path / "b", "oversubscribed_refused")
+    assert all("distinct device" in rec.get("raised", "") for rec in refused)
+
+
+def test_gloo_on_request_does_not_touch_rccl(tmp_path):
+    recs = _run(tmp_path, "gloo_requested")
+    for rec in recs:
+        assert rec["rendezvous"] == "gloo" and rec["rendezvous_fallback"] is None and rec["kern"] == 10.0

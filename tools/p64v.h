@@ -1,0 +1,573 @@
+// p64v.h - round-4 experimental copy of fft_amd/csrc/kernel_regtile64p.h (same code, renamed symbols) with measurement knobs as template
+// parameters, timed against the library kernel by tools/p64v_bench.hip.  Nothing in the product includes this file.
+//   GANGX  workgroups that walk through adjacent tiles in step (library: 2 = one 128-byte line per row)
+//   AUXD / AUXL / AUXS  cache-policy bits (gfx940 encoding: 1 = sc0, 2 = nt, 16 = sc1) of the LDS-DMA requests, the register loads, the stores
+//   MAPX   1 = compact window: tile = it * n_wg + wg (all workgroups in adjacent tiles at any time)
+//   PRIO   0 none; 1 = s_setprio 1 for waves 4..7 (static); 2 = s_setprio 1 for waves 0..3; 3 = raised priority around the store / load bursts
+#pragma once
+#include "../fft_amd/csrc/kernel_regtile.h"
+
+namespace sfft {
+
+constexpr int kV64ImageBytes = regtile_image_bytes<64, 64, 1>();
+// LDS: exchange image | half-spectrum gate | the two twiddle vectors of every team index u (W^(u j), W^(8 u j), j = 1..7): 64 x 14 x 8 B.
+// The twiddles are read twice per tile; as global loads they would queue (one in-order vmcnt) behind the LDS-DMA requests of the next
+// tile and behind the last stores.  From LDS they cost 7 ds_read_b128 and no vmcnt.
+constexpr int kV64TwOff = (regtile_lds_total<64, 64, 1>() + 15) & ~15;
+constexpr int kV64LdsTotal = kV64TwOff + 64 * 14 * 8;
+static_assert(kV64LdsTotal <= 160 * 1024, "LDS budget");
+
+typedef unsigned int pv_u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kV64RsrcFlags = 0x00020000;        // raw buffer, 32-bit data format (gfx90a / gfx942 / gfx950 dword 3)
+
+__device__ __forceinline__ void vlane16_swap(float& x, float& y) {   // x of the odd 16-lane rows <-> y of the even rows
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  x = __uint_as_float(r[0]);
+  y = __uint_as_float(r[1]);
+}
+
+// The 8 x 8 in-register transforms of fft_regs.h with a scheduling fence after every radix-8 butterfly: hipcc otherwise interleaves
+// all eight butterflies of a stage (up to 120 temporaries on top of the 128 data registers), and with the deferred-result registers
+// on top it parks those in scratch.  vpin8<BASE, STRIDE>: the eight values z[BASE + STRIDE j] have to exist in registers HERE.
+// sched_barrier only fences the machine scheduler; the IR-level sinking pass still splits a butterfly and leaves half-finished sums
+// alive until their first use hundreds of instructions later (that, not the schedule, is where 250-register peaks come from).
+template <int BASE, int STRIDE>
+__device__ __forceinline__ void vpin8(float2 (&z)[64]) {
+  asm volatile("" : "+v"(z[BASE].x), "+v"(z[BASE].y), "+v"(z[BASE + STRIDE].x), "+v"(z[BASE + STRIDE].y),
+                    "+v"(z[BASE + 2 * STRIDE].x), "+v"(z[BASE + 2 * STRIDE].y), "+v"(z[BASE + 3 * STRIDE].x), "+v"(z[BASE + 3 * STRIDE].y),
+                    "+v"(z[BASE + 4 * STRIDE].x), "+v"(z[BASE + 4 * STRIDE].y), "+v"(z[BASE + 5 * STRIDE].x), "+v"(z[BASE + 5 * STRIDE].y),
+                    "+v"(z[BASE + 6 * STRIDE].x), "+v"(z[BASE + 6 * STRIDE].y), "+v"(z[BASE + 7 * STRIDE].x), "+v"(z[BASE + 7 * STRIDE].y));
+}
+
+template <bool INV, class CB>
+__device__ __forceinline__ void p64v_stageA1_cb(float2 (&z)[64], CB cb) {
+  static_for<0, 8>([&](auto q0c) {
+    constexpr int q0 = decltype(q0c)::value;
+    bfly_plain<8, INV, q0, 8, 64>(z);
+    vpin8<q0, 8>(z);
+    __builtin_amdgcn_sched_barrier(0);
+    cb(q0c);
+    __builtin_amdgcn_sched_barrier(0);
+  });
+}
+template <bool INV>
+__device__ __forceinline__ void p64v_stageA1(float2 (&z)[64]) {      // type A stage 1: radix-8 over q1 (positions 8 q1 + q0); W_64^(q0 ka) is stage 2's
+  static_for<0, 8>([&](auto q0c) {
+    constexpr int q0 = decltype(q0c)::value;
+    bfly_plain<8, INV, q0, 8, 64>(z);
+    vpin8<q0, 8>(z);
+    __builtin_amdgcn_sched_barrier(0);
+  });
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence + s_barrier, and hipcc implements the
+// fence with s_waitcnt vmcnt(0): every barrier of the exchanges would drain the deferred stores and the prefetches that are meant to
+// travel DURING the exchanges.  Nothing that crosses waves goes through global memory here (a lane reads back only what its own wave
+// requested by LDS-DMA, after its own vmcnt wait), so the LDS counter is all a barrier has to wait for.
+__device__ __forceinline__ void p64v_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <bool IN_BF16> constexpr int kV64Gang = IN_BF16 ? 4 : 2;   // workgroups per 128-byte line (launch: n_wg is a multiple of it)
+
+// One exchange = position j of thread (p, u) -> image row j, column (p, u); thread (p, u) then reads row u, slots 0..63.  One float
+// plane at a time (the tile is 256 KiB, the image 136 KiB).  The scattered dword writes are ds_write2st64_b32 (the LDS takes a store's
+// address and data registers at 2 cycles per dword: 6 cycles for two dwords instead of 8 for two ds_write_b32); the instruction's two
+// 8-bit offsets count units of 256 bytes, and rows 8 apart are 8 * 2176 = 68 * 256 bytes apart.
+//
+// p64v_write_col<KA, IM>: the real (imaginary) parts of positions KA + 8 kb, kb = 0..7 -> rows KA + 8 kb: four ds_write2st64_b32 with two
+// opaque base addresses (kb < 4, kb >= 4: the offsets reach 3 * 68 units).  Called by the PRODUCER for the real plane right after the
+// butterfly that finished those eight positions, so the writes travel while the next butterfly runs.
+template <int KA, bool IM>
+__device__ __forceinline__ void p64v_write_col(float2 (&z)[64], float* img, int p, int u) {
+  constexpr int RW = 8 * 68, PS = 68;              // image row / column strides in floats (16-byte layout of kernel_regtile.h)
+  typedef __attribute__((address_space(3))) float lds_float;
+  lds_float* lo = (lds_float*)(img + p * PS + u) + KA * RW;
+  lds_float* hi = lo + 32 * RW;
+  asm volatile("" : "+v"(lo), "+v"(hi));           // keep them apart: base + 16-bit offset would fold them back into one ds_write_b32 each
+  if constexpr (IM) {
+    lo[0] = z[KA].y;            lo[8 * RW] = z[KA + 8].y;
+    lo[16 * RW] = z[KA + 16].y; lo[24 * RW] = z[KA + 24].y;
+    hi[0] = z[KA + 32].y;       hi[8 * RW] = z[KA + 40].y;
+    hi[16 * RW] = z[KA + 48].y; hi[24 * RW] = z[KA + 56].y;
+  } else {
+    lo[0] = z[KA].x;            lo[8 * RW] = z[KA + 8].x;
+    lo[16 * RW] = z[KA + 16].x; lo[24 * RW] = z[KA + 24].x;
+    hi[0] = z[KA + 32].x;       hi[8 * RW] = z[KA + 40].x;
+    hi[16 * RW] = z[KA + 48].x; hi[24 * RW] = z[KA + 56].x;
+  }
+}
+// The rest of an exchange, entered with the real plane already written by every wave's producer code:
+//   barrier | read re | barrier | write im | barrier | read im [| barrier].
+// The chunk order of the reads (slots 0-3, 8-11, ..., then 4-7, 12-15, ...) is the order in which the next stage's first butterflies
+// consume them.  LAST_BARRIER = false leaves the image busy: the caller puts the barrier in front of its next write.
+template <bool LAST_BARRIER>
+__device__ __forceinline__ void p64v_exchange_rest(float2 (&z)[64], float* img, int p, int u) {
+  constexpr int RW = 8 * 68, PS = 68;
+  const float* rd = img + u * RW + p * PS;
+  auto read_plane = [&](auto is_im) {
+    static_for<0, 16>([&](auto ic) {
+      constexpr int i = decltype(ic)::value, m = 4 * ((i / 8) + 2 * (i % 8));
+      const float4 v = *reinterpret_cast<const float4*>(rd + m);
+      if constexpr (decltype(is_im)::value) { z[m].y = v.x; z[m + 1].y = v.y; z[m + 2].y = v.z; z[m + 3].y = v.w; }
+      else { z[m].x = v.x; z[m + 1].x = v.y; z[m + 2].x = v.z; z[m + 3].x = v.w; }
+    });
+  };
+  p64v_barrier();
+  read_plane(std::false_type{});
+  p64v_barrier();
+  static_for<0, 8>([&](auto cc) { p64v_write_col<decltype(cc)::value, true>(z, img, p, u); });
+  p64v_barrier();
+  read_plane(std::true_type{});
+  if constexpr (LAST_BARRIER) p64v_barrier();       // image free again
+}
+
+// VMEM instructions a wave issues between its last LDS-DMA request of a burst and the s_waitcnt that guards the landing slots at the
+// top of the next tile (completion is in order, so vmcnt(N) with N = that count means "everything up to and including the LDS-DMA has
+// landed").  Steady state: per reloaded group 4 stores + 4 loads, per LDS-staged group 4 stores, the 5 gate loads.  First tile (the
+// prologue): the 4 loads of every register-loaded group and the 5 gate loads.  tools/isa_lint.py checks both against the ISA.
+template <int SPLIT, int PF> constexpr int p64v_younger() { return 8 * (8 - PF - SPLIT) + 4 * SPLIT + 5; }
+template <int SPLIT> constexpr int p64v_younger_first() { return 4 * (8 - SPLIT) + 5; }
+
+// SPLIT = row groups (of 8) of the next tile that travel through LDS.
+// PF    = row groups whose I/O is moved out of the store/load burst into the exchange / middle phase, when this CU has no other
+//         memory traffic in flight (3 in the library: 245 VGPRs; 4 spills).
+// IN_BF16 = bf16 rows in (spectre.py's activations under autocast), fp32 arithmetic: a lane still moves the 4 channels of a row —
+//         8 bytes, two packed dwords = its two sequences — so the lane map, the swap and everything after it are the fp32 kernel's;
+//         only the staging differs: a DMA instruction fetches 32 whole 32-byte row segments (16 bytes per lane, lane = (row, half)), and
+//         every lane reads its 8 bytes back out of its wave's slot (a permutation of 512 contiguous bytes: conflict-free).  A bf16 row
+//         group is 16 KiB, so ALL EIGHT groups of the next tile fit the image (SPLIT = 8, PF = 0): every load of a tile is requested
+//         right behind E2 of the previous one, none behind its stores (round 3: the fp32 kernel's late groups cost a memory latency
+//         per tile — same-box ablation: loads only 1.11 ms, stores only 0.90, neither 0.84).
+// OUT_BF16 = bf16 rows out (round to nearest even, like every other kernel here): a lane stores its 4 channels as 8 bytes.
+template <int SPLIT, int PF, bool WITH_MEM = false, bool IN_BF16 = false, bool OUT_BF16 = false, int GANGX = 0, int AUXD = 0, int AUXL = 0, int AUXS = 0, int PRIO = 0, int MAPX = 0, int DSPREAD = 0>
+__global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) {
+  constexpr int ESI = IN_BF16 ? 2 : 4, ESO = OUT_BF16 ? 2 : 4;   // bytes per input / output element
+  constexpr float inv_n = 1.0f / 4096.0f;
+  constexpr int GROUP_SLOT = IN_BF16 ? 2 * 1024 : 4 * 1024;     // bytes of one row group in a wave's landing slots
+  static_assert(SPLIT >= 1 && SPLIT <= 8 && SPLIT * GROUP_SLOT * 8 <= kV64ImageBytes, "staging lives in the exchange image");
+  static_assert(PF >= 0 && SPLIT + PF <= 8, "row groups: SPLIT through LDS, PF deferred / prefetched in registers, the rest behind their stores");
+  constexpr int GP = 8 - PF;                       // first deferred / prefetched group
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* img = reinterpret_cast<float*>(smem);
+  float2* glds = reinterpret_cast<float2*>(smem + kV64ImageBytes);
+  float2* twl = reinterpret_cast<float2*>(smem + kV64TwOff);
+  for (int i = threadIdx.x; i < 64 * 14; i += 512) {
+    const int uu = i / 14, e = i - 14 * uu, j = (e % 7) + 1;
+    twl[i] = a.tw[e < 7 ? uu * j : uu * 8 * j];
+  }
+  __syncthreads();
+  auto load_twiddles = [&](float2 (&wa)[8], float2 (&wb)[8], int uu) {
+    const float4* t = reinterpret_cast<const float4*>(twl + 14 * uu);
+    const float4 q0 = t[0], q1 = t[1], q2 = t[2], q3 = t[3], q4 = t[4], q5 = t[5], q6 = t[6];
+    wa[1] = make_float2(q0.x, q0.y); wa[2] = make_float2(q0.z, q0.w); wa[3] = make_float2(q1.x, q1.y); wa[4] = make_float2(q1.z, q1.w);
+    wa[5] = make_float2(q2.x, q2.y); wa[6] = make_float2(q2.z, q2.w); wa[7] = make_float2(q3.x, q3.y); wb[1] = make_float2(q3.z, q3.w);
+    wb[2] = make_float2(q4.x, q4.y); wb[3] = make_float2(q4.z, q4.w); wb[4] = make_float2(q5.x, q5.y); wb[5] = make_float2(q5.z, q5.w);
+    wb[6] = make_float2(q6.x, q6.y); wb[7] = make_float2(q6.z, q6.w);
+  };
+
+  // Only threadIdx.x stays live across the tile loop; the lane coordinates are re-derived from an opaque copy per tile
+  // (otherwise LICM hoists every per-lane address out of the loop and the allocator spills them).
+  const int tid0 = threadIdx.x;
+  int lane, pp, h, p, u;
+  char* slot;
+  auto coords = [&]() {
+    int t = tid0;
+    asm volatile("" : "+v"(t));
+    lane = t & 63;
+    pp = lane & 3; h = (lane >> 4) & 1;
+    p = 2 * pp + h;
+    u = ((lane >> 2) & 3) + 4 * (lane >> 5) + 8 * (t >> 6);
+    slot = smem + __builtin_amdgcn_readfirstlane(t >> 6) * (SPLIT * GROUP_SLOT);   // this wave's landing slots
+  };
+  coords();
+  if constexpr (PRIO == 1) { if (__builtin_amdgcn_readfirstlane(tid0 >> 6) >= 4) __builtin_amdgcn_s_setprio(1); }
+  if constexpr (PRIO == 2) { if (__builtin_amdgcn_readfirstlane(tid0 >> 6) < 4) __builtin_amdgcn_s_setprio(1); }
+
+  // GANG neighbouring workgroups (same L2) walk through GANG adjacent tiles in step = one 128-byte line per row: the L2 fetches a
+  // line once and the neighbours' requests hit (fp32: two 64-byte halves; bf16: four 32-byte quarters)
+  constexpr int GANG = GANGX > 0 ? GANGX : kV64Gang<(IN_BF16 || OUT_BF16)>;
+  const int wg_lin = xcd_contiguous(blockIdx.x, a.n_wg);
+  // MAPX = 1: compact window — iteration `it` of the whole grid covers tiles [it * n_wg, (it + 1) * n_wg)
+  // MAPX = 2: compact window with neighbouring PAIRS on different XCDs (the two workgroups of a pair, blocks b and b + 8, share one)
+  const int bx = blockIdx.x;
+  const int pair_base = MAPX == 2 ? ((bx / 16) * 8 + bx % 8) * 2 + (bx / 8) % 2 : MAPX ? wg_lin : (wg_lin / GANG) * a.tpw * GANG + (wg_lin % GANG);
+  const int TS = MAPX ? a.n_wg : GANG;
+  if (pair_base >= a.n_tiles) return;
+
+  float2 z[64];
+  float4 dfr[PF > 0 ? 4 * PF : 1];                 // deferred results of the previous tile / prefetched rows of the next one
+  static_for<0, 4 * PF>([&](auto ic) { dfr[decltype(ic)::value] = make_float4(0.f, 0.f, 0.f, 0.f); });   // (stored into an empty range before the first tile)
+  char* obp = nullptr;                             // output tile of the deferred results
+  float2 gstage[5];      // the next tile's gate bins on their way to LDS (4097 bins / 512 threads, rounded up; + 1 for the last)
+
+  // lane offset of an LDS-DMA request: fp32 = the lane's own 16 bytes (the register-load offset); bf16 = lane l fetches the 16-byte half
+  // l & 1 of the 32-byte segment of row  (l >> 1 & 7) + 8 wave + 512 (l >> 4 & 1) + 1024 (l >> 5)   [+ 64 g + 2048 (m >> 1) per instruction]
+  auto dma_voff = [&](uint32_t voff, long long sn) -> uint32_t {
+    if constexpr (IN_BF16) return (uint32_t)(((long long)(((lane >> 1) & 7) + 8 * (u >> 3) + 512 * ((lane >> 4) & 1) + 1024 * (lane >> 5)) * sn) * ESI + (lane & 1) * 16);
+    else return voff;
+  };
+  auto tile_ptrs = [&](int tile, const char*& vb, char*& ob, const float2*& gp) {
+    const int b = tile / a.tiles_per_row, ct = tile - b * a.tiles_per_row;
+    vb = reinterpret_cast<const char*>(a.v) + ((size_t)b * a.v_sb + (size_t)ct * 16) * ESI;
+    ob = reinterpret_cast<char*>(a.out) + ((size_t)b * a.out_sb + (size_t)ct * 16) * ESO;
+    gp = a.gate + ((size_t)b * a.G + (ct * 16) / a.d_g) * a.F;
+  };
+  // row of this lane in load / store instruction (g, m):  u + 512 h + 64 g + 1024 m; addresses = workgroup-uniform base of the
+  // instruction (SGPRs) + one 32-bit lane offset (spectre_hip.hip bounds 4095 * row stride * 4 + 64 below 2^31)
+  // Buffer resources: base = the tile's first row, num_records = the bytes of its rows that exist (a.rows_in input rows are read, the
+  // rest are rfft's zero padding; a.rows_out output rows are written).  The range check covers the VGPR offset (lane offset + row-block
+  // offset; the SGPR offset operand is not checked on gfx9), so both go there.
+  // live = false: an empty range.  Every request of the tile loop is issued UNCONDITIONALLY — after the last tile (and, for the deferred
+  // stores, before the first) with an empty range, which costs nothing: hipcc computes its s_waitcnt vmcnt(N) from the requests that are
+  // GUARANTEED to be younger than the one waited for, so a request inside `if (more)` does not count, N comes out too small, and a wait
+  // for a prefetched register early in I2 turned into a wait for the LDS-DMA issued just before it (a full HBM round trip per tile).
+  auto rsrc_in = [&](const char* vb, long long sn, bool live = true) {
+    const int rows = live ? a.rows_in : 0;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(vb), 0, (int)((long long)rows * sn * ESI), kV64RsrcFlags);
+  };
+  auto rsrc_out = [&](char* ob, long long sn, bool live = true) {
+    const int rows = live ? a.rows_out : 0;
+    return __builtin_amdgcn_make_buffer_rsrc(ob, 0, (int)((long long)rows * sn * ESO), kV64RsrcFlags);
+  };
+  auto unpack_lo = [](uint32_t d) { return make_float2(__uint_as_float(d << 16), __uint_as_float(d & 0xffff0000u)); };   // two bf16 -> (re, im)
+  auto load_group = [&](__amdgpu_buffer_rsrc_t rs, uint32_t voff, long long sn, auto gc) {       // straight into the registers of group g
+    constexpr int g = decltype(gc)::value;
+    static_for<0, 4>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      if constexpr (IN_BF16) {
+        const rt_u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, voff + (uint32_t)((64 * g + 1024 * m) * sn * ESI), 0, 0);
+        z[8 * g + 2 * m] = unpack_lo(t.x);
+        z[8 * g + 2 * m + 1] = unpack_lo(t.y);
+      } else {
+        const pv_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + (uint32_t)((64 * g + 1024 * m) * sn * 4), 0, AUXL);
+        z[8 * g + 2 * m] = make_float2(__uint_as_float(t.x), __uint_as_float(t.y));
+        z[8 * g + 2 * m + 1] = make_float2(__uint_as_float(t.z), __uint_as_float(t.w));
+      }
+    });
+  };
+  // 1 KiB per instruction, lane l's 16 bytes at slot + 16 l.  fp32: four instructions per group (m = 0..3); bf16: two (m >> 1 = 0, 1),
+  // each with the rows of both h and of m & 1 (dma_voff).
+  auto dma_group = [&](__amdgpu_buffer_rsrc_t rs, uint32_t voff, long long sn, auto gc) {        // into this wave's LDS slots
+    constexpr int g = decltype(gc)::value;
+    if constexpr (IN_BF16) {
+      static_for<0, 2>([&](auto mc) {
+        constexpr int mh = decltype(mc)::value;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(slot + (2 * g + mh) * 1024), 16,
+                                                 voff + (uint32_t)((64 * g + 2048 * mh) * sn * ESI), 0, 0, 0);
+      });
+    } else {
+      static_for<0, 4>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(slot + (4 * g + m) * 1024), 16,
+                                                 voff + (uint32_t)((64 * g + 1024 * m) * sn * 4), 0, 0, AUXD);
+      });
+    }
+  };
+  auto store16 = [&](__amdgpu_buffer_rsrc_t rs, uint32_t off, const float4 v) {   // this lane's 4 channels of one row
+    if constexpr (OUT_BF16) {
+      rt_u32x2 t;
+      t.x = f32_to_bf16_rne(v.x) | (f32_to_bf16_rne(v.y) << 16); t.y = f32_to_bf16_rne(v.z) | (f32_to_bf16_rne(v.w) << 16);
+      __builtin_amdgcn_raw_buffer_store_b64(t, rs, off, 0, 0);
+    } else {
+      pv_u32x4 t;
+      t.x = __float_as_uint(v.x); t.y = __float_as_uint(v.y); t.z = __float_as_uint(v.z); t.w = __float_as_uint(v.w);
+      __builtin_amdgcn_raw_buffer_store_b128(t, rs, off, 0, AUXS);
+    }
+  };
+  auto read_group = [&](auto gc) {                                       // this lane's bytes back out of the slot
+    constexpr int g = decltype(gc)::value;
+    static_for<0, 4>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      if constexpr (IN_BF16) {
+        // DMA lane 2 (rcl + 4 rch + 8 h + 16 (m & 1)) + (pp >> 1) of instruction (g, m >> 1), half pp & 1 of its 16 bytes
+        const rt_u32x2 t = *reinterpret_cast<const rt_u32x2*>(slot + (2 * g + (m >> 1)) * 1024 + ((((lane >> 2) & 3) + 4 * (lane >> 5)) + 8 * h + 16 * (m & 1)) * 32 + pp * 8);
+        z[8 * g + 2 * m] = unpack_lo(t.x);
+        z[8 * g + 2 * m + 1] = unpack_lo(t.y);
+      } else {
+        const float4 t = *reinterpret_cast<const float4*>(slot + (4 * g + m) * 1024 + lane * 16);
+        z[8 * g + 2 * m] = make_float2(t.x, t.y);
+        z[8 * g + 2 * m + 1] = make_float2(t.z, t.w);
+      }
+    });
+  };
+  auto swap_group = [&](auto gc) {      // rows (g + 16 m, g + 16 m + 8) of sequences (2pp, 2pp+1)  <->  both rows of sequence p
+    constexpr int g = decltype(gc)::value;
+    static_for<0, 4>([&](auto mc) {
+      constexpr int j = 8 * g + 2 * decltype(mc)::value;
+      vlane16_swap(z[j].x, z[j + 1].x);
+      vlane16_swap(z[j].y, z[j + 1].y);
+    });
+  };
+  // gate_fetch only REQUESTS the bins: the staging registers cross the loop's back edge, and anything computed from them before it
+  // (the edge rule, the conj, the 1/N scale) would have to wait for the loads right there, at the end of the burst — i.e. for every
+  // store of the tile (one in-order vmcnt).  All arithmetic happens in gate_commit, a phase and a half later.
+  auto gate_fetch = [&](const float2* gp) {
+    static_for<0, 5>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const int k = lane + 64 * (u >> 3) + 512 * i;
+      // (every lane loads — the lanes beyond bin 2048 re-read it and gate_commit ignores them: a predicated fifth load becomes a
+      //  branch with `s_waitcnt vmcnt(0)` behind it, and the waves that skip it would have one request less in flight than the
+      //  vmcnt() at the top of the loop counts on)
+      gstage[i] = gp[i < 4 ? k : (k <= 2048 ? k : 2048)];
+    });
+  };
+  auto gate_commit = [&]() {
+    static_for<0, 5>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const int k = lane + 64 * (u >> 3) + 512 * i;
+      float2 g = gstage[i];
+      asm volatile("" : "+v"(g.x), "+v"(g.y));     // consumed HERE by every wave: the fifth bin's write below is lane-predicated, and a wave
+                                                   // that branches around it would carry the pending load into the exchange, where hipcc then
+                                                   // protects a reused register with s_waitcnt vmcnt(0) — behind the deferred requests
+      if (k == 0 || k == 2048) g.y = 0.f;          // irfft ignores Im(DC), Im(Nyquist) (spectre.py:551)
+      if (a.conj_gate) g.y = -g.y;
+      if (i < 4 || k <= 2048) glds[k] = make_float2(g.x * inv_n, g.y * inv_n);
+    });
+  };
+
+  // ---- prologue: request tile 0 the same way every later tile is requested --------------------------------------------
+  {
+    const char* vb; char* ob; const float2* gp;
+    tile_ptrs(pair_base, vb, ob, gp);
+    const uint32_t voff = (uint32_t)(((long long)(u + 512 * h) * a.v_sn + 4 * pp) * ESI);
+    const __amdgpu_buffer_rsrc_t rs = rsrc_in(vb, a.v_sn);
+    static_for<0, SPLIT>([&](auto gc) { dma_group(rs, dma_voff(voff, a.v_sn), a.v_sn, gc); });
+    asm volatile("" ::: "memory");
+    static_for<SPLIT, 8>([&](auto gc) { load_group(rs, voff, a.v_sn, gc); });
+    gate_fetch(gp);
+  }
+
+  for (int it = 0; it < a.tpw; ++it) {
+    const int tile = pair_base + TS * it;
+    if (tile >= a.n_tiles) break;                  // workgroup-uniform
+    const bool more = (it + 1 < a.tpw) && (tile + TS < a.n_tiles);
+    coords();
+    long long v_sn = a.v_sn, out_sn = a.out_sn;
+    asm volatile("" : "+s"(v_sn), "+s"(out_sn));
+    const char* vb; char* ob; const float2* gp;
+    tile_ptrs(tile, vb, ob, gp);
+    const char* vbn = vb; char* obn = ob; const float2* gpn = gp;
+    if (more) tile_ptrs(tile + TS, vbn, obn, gpn);
+    const __amdgpu_buffer_rsrc_t rs_next = rsrc_in(vbn, v_sn, more), rs_out = rsrc_out(ob, out_sn);
+
+    [[maybe_unused]] const uint32_t pf_ooff = (uint32_t)(((long long)(u + 512 * h) * out_sn + 4 * pp) * ESO);
+    [[maybe_unused]] const uint32_t pf_voff = (uint32_t)(((long long)(u + 512 * h) * v_sn + 4 * pp) * ESI);
+    [[maybe_unused]] auto pf_store = [&](auto ic) {
+      constexpr int g = GP + decltype(ic)::value / 4, m = decltype(ic)::value % 4;
+      store16(rsrc_out(obp, out_sn, it > 0), pf_ooff + (uint32_t)((64 * g + 1024 * m) * out_sn * ESO), dfr[decltype(ic)::value]);
+    };
+    [[maybe_unused]] auto pf_load = [&](auto ic) {
+      constexpr int g = GP + decltype(ic)::value / 4, m = decltype(ic)::value % 4;
+      if constexpr (IN_BF16) {                       // stays packed (two dwords) until it trades places with the results in I2
+        const rt_u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs_next, pf_voff + (uint32_t)((64 * g + 1024 * m) * v_sn * ESI), 0, 0);
+        dfr[decltype(ic)::value].x = __uint_as_float(t.x); dfr[decltype(ic)::value].y = __uint_as_float(t.y);
+      } else {
+        const pv_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_next, pf_voff + (uint32_t)((64 * g + 1024 * m) * v_sn * 4), 0, AUXL);
+        dfr[decltype(ic)::value] = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
+      }
+    };
+
+    // ---- F1: 64-point forward transform over n1 (register position 8g + e holds row g + 8e), then W_N^(u*k1) ------------
+    //      Stage 1 works group by group, in the order the groups arrive: the deferred groups (prefetched a tile ago) first, then the
+    //      LDS-staged ones — only now does the wave wait for the LDS-DMA of the burst it has just left — and the groups reloaded
+    //      behind the stores last.
+    static_for<0, 8>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      constexpr int g = i < PF ? GP + i : i - PF;                            // [GP, 8), [0, SPLIT), [SPLIT, GP)
+      if constexpr (i == PF) {
+        // the tile arrives: completion is in order, so once everything but the requests younger than the last LDS-DMA has retired the
+        // staged groups are in the slots (p64v_younger; checked against the ISA by tools/isa_lint.py)
+        if (it == 0) asm volatile("s_waitcnt vmcnt(%0) ; lint: first" :: "n"(p64v_younger_first<SPLIT>()) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) ; lint: steady" :: "n"(p64v_younger<SPLIT, PF>()) : "memory");
+        static_for<0, SPLIT>([&](auto gc) { read_group(gc); });
+      }
+      swap_group(std::integral_constant<int, g>{});
+      bfly_plain<8, false, 8 * g, 1, 64>(z);       // over e -> ka at position 8g + ka (W_64^(g ka) is applied by the column butterflies below)
+      vpin8<8 * g, 1>(z);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    {
+      float2 wa[8], wb[8];
+      __builtin_amdgcn_sched_barrier(0);           // keep the base loads (and their registers) out of stage 1
+      load_twiddles(wa, wb, u);
+      // column by column: butterfly over g -> kb at position 8 kb + ka (k1 = position), both twiddle factors W^(u ka) W^(8 u kb), and the
+      // real parts straight into the image while the next column is computed
+      static_for<0, 8>([&](auto kac) {
+        constexpr int ka = decltype(kac)::value;
+        bfly_tw<8, false, ka, 8, 1, ka, 64>(z);    // input g still needs W_64^(g ka): scaled form (fft_regs.h)
+        static_for<0, 8>([&](auto kbc) {
+          constexpr int kb = decltype(kbc)::value, j = 8 * kb + ka;
+          if constexpr (ka > 0) z[j] = cmul(z[j], wa[ka]);
+          if constexpr (kb > 0) z[j] = cmul(z[j], wb[kb]);
+        });
+        vpin8<ka, 8>(z);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (ka == 0) p64v_barrier();      // every wave has emptied its landing slots (and finished E2's reads of the previous
+                                                   // tile): the image may be written
+        p64v_write_col<ka, false>(z, img, p, u);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    }
+    // this tile's gate bins -> LDS.  They were requested behind the previous tile's last stores, so waiting for them means waiting
+    // for every store of that tile to be acknowledged: as late as possible (the bins are first read after E1's barriers) — but BEFORE
+    // the deferred requests below: hipcc waits for registers that were loaded before the loop's back edge with vmcnt(0), which behind
+    // those requests would mean a full HBM round trip at the end of every F1.
+    gate_commit();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- the quiet part of the tile starts: the deferred results of the previous tile leave, the same row groups of the next tile
+    //      are requested into the registers they vacate
+    static_for<0, 4 * PF>([&](auto ic) { pf_store(ic); });
+    static_for<0, 4 * PF>([&](auto ic) { pf_load(ic); });
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- E1: position k1 -> image row k1, column (p, u); thread (p, s = u) reads row u, slot n2.  No barrier behind the last read:
+    //      the image stays busy until the barrier in front of the middle phase's last stage.
+    p64v_exchange_rest<false>(z, img, p, u);
+
+    // ---- middle: F2 -> gate -> I1 (kernel_regtile.h; bin of register (ka, kb): k = k1 + 64 k2, k2 = ka + 8 kb) -------------
+    {
+      const int k1 = u;
+      p64v_stageA1<false>(z);
+      auto fetch_gate = [&](int k2, bool upper) -> float2 {
+        float2 g = glds[upper ? 64 * (64 - k2) - k1 : k1 + 64 * k2];      // scaled by 1/N, edges fixed, conj applied
+        if (upper) g.y = -g.y;                                          // Hermitian extension above N/2
+        return g;
+      };
+      // the gate bins of one register group are fetched right where they are used (16 registers)
+      float2 gcur[8];
+      // memory_fft (spectre.py:548-549): row k of the (F, D) complex buffer, this lane's two channels = 16 bytes; one register
+      // group (8 bins) at a time, requested right after the previous group has been consumed (L2 / Infinity-Cache resident:
+      // 12.6 MB at the headline shape, re-read by every batch element).  These loads sit in the exchange / middle phase, when the
+      // CU has no other memory traffic in flight.
+      [[maybe_unused]] float4 mcur[WITH_MEM ? 8 : 1];
+      [[maybe_unused]] const float* mbase = nullptr;
+      if constexpr (WITH_MEM) mbase = a.mem + (size_t)((tile - (tile / a.tiles_per_row) * a.tiles_per_row) * 16 + 2 * p) * 2;
+      auto fetch_mem = [&](int k2, bool upper) -> float4 {
+        return *reinterpret_cast<const float4*>(mbase + (size_t)(upper ? 64 * (64 - k2) - k1 : k1 + 64 * k2) * a.D * 2);
+      };
+      static_for<0, 8>([&](auto kbc) {
+        constexpr int k2 = 8 * decltype(kbc)::value;
+        gcur[decltype(kbc)::value] = fetch_gate(k2, k2 >= 32);
+        if constexpr (WITH_MEM) mcur[decltype(kbc)::value] = fetch_mem(k2, k2 >= 32);
+      });
+      static_for<0, 8>([&](auto kac) {
+        constexpr int ka = decltype(kac)::value;
+        fftA_stage2_group<8, 8, false, ka>(z);
+        static_for<0, 8>([&](auto kbc) {
+          constexpr int kb = decltype(kbc)::value, j = 8 * ka + kb, k2 = ka + 8 * kb;
+          z[j] = cmul(z[j], gcur[kb]);                                   // spectre.py:545
+          if constexpr (WITH_MEM) {                                      // Mf[k] = mem_c[k] + i mem_{c+1}[k] below N/2, conj(mem_c[N-k]) + i conj(mem_{c+1}[N-k]) above
+            const float4 m = mcur[kb];
+            float2 add;
+            if ((k2 == 0 || k2 == 32) && k1 == 0) add = make_float2(m.x, m.z);          // DC, Nyquist: real parts only
+            else if (k2 >= 32)                    add = make_float2(m.x + m.w, m.z - m.y);
+            else                                  add = make_float2(m.x - m.w, m.y + m.z);
+            z[j].x += add.x * inv_n; z[j].y += add.y * inv_n;
+          }
+        });
+        vpin8<8 * ka, 1>(z);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (ka + 1 < 8)
+          static_for<0, 8>([&](auto kbc) {
+            constexpr int k2n = ka + 1 + 8 * decltype(kbc)::value;
+            gcur[decltype(kbc)::value] = fetch_gate(k2n, k2n >= 32);
+            if constexpr (WITH_MEM) mcur[decltype(kbc)::value] = fetch_mem(k2n, k2n >= 32);
+          });
+        fftB_stage1_group<8, 8, true, ka>(z);
+        vpin8<8 * ka, 1>(z);
+        __builtin_amdgcn_sched_barrier(0);         // keep the gate prefetch one group deep (register budget)
+      });
+      // type B stage 2: radix-8 over ka (positions 8 ka + n_lo) -> natural order, position n2 = n_lo + 8 n_hi.  Every wave has long
+      // finished E1's reads; behind this barrier the image is written again, column by column like in F1.
+      p64v_barrier();
+      static_for<0, 8>([&](auto nc) {
+        constexpr int nlo = decltype(nc)::value;
+        fftB_stage2_group<8, 8, true, nlo>(z);
+        vpin8<nlo, 8>(z);
+        __builtin_amdgcn_sched_barrier(0);
+        p64v_write_col<nlo, false>(z, img, p, u);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    }
+
+    // ---- E2: position n2 -> image row n2, column (p, k1 = u); thread (p, u) reads row u, slot k1.  The barrier behind the last read
+    //      frees the image for the LDS-DMA below.
+    p64v_exchange_rest<true>(z, img, p, u);
+
+    // ---- the image is idle until the next F1: let the first row groups of the next tile land in it, and fetch its gate -----
+    const uint32_t voff = (uint32_t)(((long long)(u + 512 * h) * v_sn + 4 * pp) * ESI);
+    // (the twiddles of I2 are read BEFORE the LDS-DMA is issued: hipcc orders every LDS read behind a pending LDS-DMA with
+    //  s_waitcnt vmcnt(0) — the whole HBM round trip of the requests below, at the start of every burst)
+    float2 wa[8], wb[8];
+    load_twiddles(wa, wb, u);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // DSPREAD: 0 = all 4 * SPLIT LDS-DMA requests in one burst; 1 = spread over the conj-twiddle multiplications (one share per 8 positions);
+    // 2 = spread over the twiddle multiplications and the eight butterflies of I2's first stage
+    auto dma_one = [&](auto qc) {
+      constexpr int q = decltype(qc)::value, g = q / 4, m = q % 4;
+      static_assert(!IN_BF16 || DSPREAD == 0, "fp32 rows only");
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_next, (__attribute__((address_space(3))) void*)(slot + (4 * g + m) * 1024), 16,
+                                               voff + (uint32_t)((64 * g + 1024 * m) * v_sn * 4), 0, 0, AUXD);
+    };
+    constexpr int NDMA = 4 * SPLIT, NSLOT = DSPREAD == 2 ? 16 : 8;
+    if constexpr (DSPREAD == 0) static_for<0, SPLIT>([&](auto gc) { dma_group(rs_next, dma_voff(voff, v_sn), v_sn, gc); });
+    asm volatile("" ::: "memory");                 // the vmcnt() at the top of the loop counts on these being older than every store below
+
+    // ---- conj twiddle, I2, stores (spectre.py:553) interleaved with the loads that refill the released registers -----------
+    static_for<1, 64>([&](auto jc) {
+      constexpr int j = decltype(jc)::value, ja = j % 8, jb = j / 8;     // position j carries k1 = j
+      if constexpr (ja > 0) z[j] = cmulc(z[j], wa[ja]);
+      if constexpr (jb > 0) z[j] = cmulc(z[j], wb[jb]);
+      if constexpr (ja == 7) {
+        vpin8<8 * jb, 1>(z); __builtin_amdgcn_sched_barrier(0);   // one wb at a time
+        if constexpr (DSPREAD != 0) {
+          static_for<jb * NDMA / NSLOT, (jb + 1) * NDMA / NSLOT>([&](auto qc) { dma_one(qc); });
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (DSPREAD == 2) p64v_stageA1_cb<true>(z, [&](auto q0c) {
+      constexpr int sl = 8 + decltype(q0c)::value;
+      static_for<sl * NDMA / NSLOT, (sl + 1) * NDMA / NSLOT>([&](auto qc) { dma_one(qc); });
+    });
+    else p64v_stageA1<true>(z);
+    asm volatile("" ::: "memory");
+    {
+      const uint32_t ooff = (uint32_t)(((long long)(u + 512 * h) * out_sn + 4 * pp) * ESO);
+      static_for<0, 8>([&](auto ic) {
+        constexpr int g = (decltype(ic)::value + SPLIT) % 8;             // register-loaded groups first: their reloads start earliest
+        fftA_stage2_group<8, 8, true, g>(z);                              // rows g + 8e at positions 8g + e
+        vpin8<8 * g, 1>(z);
+        swap_group(std::integral_constant<int, g>{});
+        static_for<0, 4>([&](auto mc) {
+          constexpr int m = decltype(mc)::value;
+          const float4 res = make_float4(z[8 * g + 2 * m].x, z[8 * g + 2 * m].y, z[8 * g + 2 * m + 1].x, z[8 * g + 2 * m + 1].y);
+          if constexpr (g >= GP) {
+            if (more) {                              // trade places: results wait for the next quiet part, the prefetched rows move in
+              const float4 nx = dfr[4 * (g - GP) + m];
+              dfr[4 * (g - GP) + m] = res;
+              if constexpr (IN_BF16) {
+                z[8 * g + 2 * m] = unpack_lo(__float_as_uint(nx.x));
+                z[8 * g + 2 * m + 1] = unpack_lo(__float_as_uint(nx.y));
+              } else {
+                z[8 * g + 2 * m] = make_float2(nx.x, nx.y);
+                z[8 * g + 2 * m + 1] = make_float2(nx.z, nx.w);
+              }
+            } else {
+              store16(rs_out, ooff + (uint32_t)((64 * g + 1024 * m) * out_sn * ESO), res);
+            }
+          } else {
+            store16(rs_out, ooff + (uint32_t)((64 * g + 1024 * m) * out_sn * ESO), res);
+          }
+        });
+        if constexpr (g >= SPLIT && g < GP) load_group(rs_next, voff, v_sn, std::integral_constant<int, g>{});
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    }
+    obp = ob;
+    gate_fetch(gpn);     // committed to LDS at the end of the next tile's F1 (after the last tile: a harmless re-read of this tile's bins)
+  }  // tile loop
+}
+
+hipError_t launch_p64v_unused(const RegtileArgs& a, bool in_bf16, bool out_bf16, hipStream_t stream);
+
+}  // namespace sfft

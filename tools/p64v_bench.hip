@@ -1,0 +1,101 @@
+// p64v_bench — round-4 experiments on the pipelined 4096 kernel: tools/p64v.h (a copy of kernel_regtile64p.h with knobs) against the
+// library kernel, interleaved A/B timing of every variant in ONE process on ONE (V, out) pair, outputs compared with the library's.
+// (256, 4096, 768) fp32, pseudo-random data.   usage: p64v_bench [rounds] [name-filter]
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -Wno-inline-asm tools/p64v_bench.hip -o tools/p64v_bench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <string>
+#include <functional>
+#include <cmath>
+#include <algorithm>
+#include <cstdint>
+#include "../fft_amd/csrc/kernel_regtile64p.h"
+#include "p64v.h"
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
+using namespace sfft;
+
+struct Variant { std::string name; std::function<void()> launch; std::vector<float> ms; };
+
+template <class K> std::function<void()> mk(K kern, RegtileArgs a, int gang, int lds = kV64LdsTotal) {
+  a.tpw = 48;
+  a.n_wg = gang * ((a.n_tiles + gang * a.tpw - 1) / (gang * a.tpw));
+  CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  return [=] { hipLaunchKernelGGL(kern, dim3(a.n_wg), dim3(512), lds, 0, a); };
+}
+
+int main(int argc, char** argv) {
+  const int rounds = argc > 1 ? atoi(argv[1]) : 5;
+  const char* filter = argc > 2 ? argv[2] : "";
+  const int B = 256, N = 4096, D = 768, G = 4, F = N / 2 + 1;
+  float *v, *out, *out_ref; float2 *gate, *tw;
+  CK(hipMalloc(&v, (size_t)B * N * D * 4)); CK(hipMalloc(&out, (size_t)B * N * D * 4)); CK(hipMalloc(&out_ref, (size_t)B * N * D * 4));
+  CK(hipMalloc(&gate, (size_t)B * G * F * 8)); CK(hipMalloc(&tw, N * 8));
+  {
+    std::vector<float> hr(1 << 24);
+    uint32_t st = 12345u;
+    for (auto& x : hr) { st = st * 1664525u + 1013904223u; x = ((st >> 8) & 0xffff) / 32768.0f - 1.0f; }
+    for (size_t off = 0; off < (size_t)B * N * D; off += hr.size())
+      CK(hipMemcpy(v + off, hr.data(), std::min(hr.size(), (size_t)B * N * D - off) * 4, hipMemcpyHostToDevice));
+    for (size_t off = 0; off < (size_t)B * G * F * 2; off += hr.size())
+      CK(hipMemcpy((float*)gate + off, hr.data(), std::min(hr.size(), (size_t)B * G * F * 2 - off) * 4, hipMemcpyHostToDevice));
+  }
+  std::vector<float2> h(N);
+  for (int m = 0; m < N; ++m) h[m] = make_float2((float)cos(2 * M_PI * m / N), (float)-sin(2 * M_PI * m / N));
+  CK(hipMemcpy(tw, h.data(), N * 8, hipMemcpyHostToDevice));
+  RegtileArgs la{};
+  la.v = v; la.gate = gate; la.mem = nullptr; la.out = out; la.tw = tw;
+  la.B = B; la.N_in = N; la.D = D; la.G = G; la.d_g = D / G; la.F = F; la.rows_in = la.rows_out = N;
+  la.v_sb = (long long)N * D; la.v_sn = D; la.out_sb = (long long)N * D; la.out_sn = D;
+  la.tiles_per_row = D / 16; la.n_tiles = B * (D / 16);
+
+  std::vector<Variant> vs;
+  auto add = [&](const char* name, std::function<void()> f) { if (strstr(name, filter)) vs.push_back({name, f, {}}); };
+  add("LIBRARY <4,2>", mk(spectre_mix_regtile64p<4, 2>, la, 2, kP64LdsTotal));
+  add("copy    <4,2> (must equal the library)", mk(spectre_mix_p64v<4, 2>, la, 2));
+#include "p64v_variants.inc"
+
+  // ---- correctness against the library kernel
+  {
+    RegtileArgs r = la; r.out = out_ref;
+    mk(spectre_mix_regtile64p<4, 2>, r, 2, kP64LdsTotal)();
+    CK(hipDeviceSynchronize());
+    std::vector<float> ho((size_t)N * D), hr((size_t)N * D);
+    for (auto& x : vs) {
+      CK(hipMemset(out, 0xff, (size_t)B * N * D * 4));
+      x.launch(); CK(hipDeviceSynchronize());
+      double worst = 0; size_t bad = 0;
+      for (int b : {0, 97, 255}) {
+        CK(hipMemcpy(ho.data(), out + (size_t)b * N * D, (size_t)N * D * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(hr.data(), out_ref + (size_t)b * N * D, (size_t)N * D * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < (size_t)N * D; ++i) { const double d = std::fabs((double)ho[i] - hr[i]); if (!(d <= worst)) worst = d; if (!(d < 1e-4)) ++bad; }
+      }
+      printf("check %-56s max |diff| vs library %.3e, elements off by > 1e-4: %zu\n", x.name.c_str(), worst, bad);
+    }
+  }
+  // ---- interleaved timing
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 40; ++i) vs[0].launch();
+  CK(hipDeviceSynchronize());
+  for (int r = 0; r < rounds; ++r)
+    for (size_t k = 0; k < vs.size(); ++k) {
+      Variant& x = vs[(k + r) % vs.size()];            // rotate the order: no variant always follows the same neighbour
+      for (int i = 0; i < 8; ++i) x.launch();
+      CK(hipEventRecord(e0));
+      for (int i = 0; i < 16; ++i) x.launch();
+      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      x.ms.push_back(ms / 16);
+    }
+  printf("\n%-58s   min     median   | per round\n", "variant");
+  const float base = [&] { auto m = vs[0].ms; std::sort(m.begin(), m.end()); return m[m.size() / 2]; }();
+  for (auto& x : vs) {
+    auto m = x.ms; std::sort(m.begin(), m.end());
+    printf("%-58s %7.4f %7.4f (%+5.1f%%) |", x.name.c_str(), m[0], m[m.size() / 2], 100.0 * (m[m.size() / 2] / base - 1.0));
+    for (float t : x.ms) printf(" %.4f", t);
+    printf("\n");
+  }
+  return 0;
+}
