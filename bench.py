@@ -198,7 +198,8 @@ def main():
             seg = 16 * V.element_size()
             byt = 2.0 * B * N * D * V.element_size()
             for name, sg, md in (("dense_copy", 0, "copy"), ("pattern_copy", 128, "copy"), ("half_line_copy", seg, "copy"),
-                                 ("pattern_load_only", 128, "load"), ("pattern_store_only", 128, "store"), ("dense_load_only", 0, "load")):
+                                 ("pattern_load_only", 128, "load"), ("pattern_store_only", 128, "store"), ("dense_load_only", 0, "load"),
+                                 ("half_line_load_only", seg, "load"), ("half_line_store_only", seg, "store")):
                 best = None
                 for per_cu in (1, 2, 4):                                  # persistent workgroups per CU: report the best of three
                     ms = copy_probe(V, out, sg, mode=md, wgs_per_cu=per_cu, warmup=3, iters=max(5, a.steps // 2))
@@ -214,6 +215,13 @@ def main():
                 ms = copy_probe(V, out, sg, mode="copy", warmup=3, iters=max(5, a.steps // 2))
                 ceilings[name + "_GBps"] = byt / ms / 1e6
                 ceilings[name + "_ms"] = ms
+            # What bounds the product (round 4): a workgroup owns 16 channels = HALF a 128-byte line per row, and the L2 takes a half-line
+            # STORE at about two thirds of the rate of a full-line one (store-only probes: 3.4-3.6 TB/s in 64-byte segments against 5.3-5.5 in
+            # 128-byte segments; loads 5.3-5.5 against 5.9-6.1) although every byte still reaches HBM exactly once (PMC: all write requests
+            # leave the L2 as full 64-byte bursts).  The product's own requests, issued alone, take half_line_load_only_ms +
+            # half_line_store_only_ms; `frac_of_half_line_requests` = that sum / the product's time (1 = the two directions do not overlap
+            # in the request path at all, > 1 = they do).
+            ceilings["half_line_requests_ms"] = ceilings["half_line_load_only_ms"] + ceilings["half_line_store_only_ms"]
             ceilings["best_copy_GBps"] = max(ceilings[k] for k in ("dense_copy_GBps", "pattern_copy_GBps", "flat_copy_GBps", "flat_nt_copy_GBps", "hipMemcpyDtoD_GBps"))
             for _ in range(10):
                 step()                                                    # (the probes overwrote `out`; leave a valid result behind)
@@ -335,6 +343,7 @@ def main():
             res["roofline"]["frac_of_pattern_copy"] = achieved / ceilings["pattern_copy_GBps"]
             res["roofline"]["frac_of_dense_copy"] = achieved / ceilings["dense_copy_GBps"]
             res["roofline"]["frac_of_best_copy"] = achieved / ceilings["best_copy_GBps"]
+            res["roofline"]["frac_of_half_line_requests"] = ceilings["half_line_requests_ms"] / kern_ms
             res["roofline"]["ceilings_note"] = ("pure copies of this launch's V -> out bytes measured in this process through the C ABI "
                                                 "(spectre_probe_copy): dense = contiguous 16 B per lane; pattern = 128-byte row segments of 4096 rows "
                                                 "at the row stride (the product's 64-byte halves merged per pair of workgroups); half_line = free-running "
