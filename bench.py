@@ -244,7 +244,7 @@ def main():
                 variants[name].update({"pattern_copy_GBps": cb / pm / 1e6, "pattern_copy_ms": pm, "frac_of_pattern_copy": pm / ms * (byt / cb),
                                        "flat_copy_GBps": cb / fm / 1e6})
             del Vv, ov
-        # Where the driver places an allocation is worth +-5 % to this kernel and +-10 % to a copy (DESIGN.md section 5, round 3, item 7;
+        # Where the driver places an allocation is worth +-5 % to this kernel and +-10 % to a copy (LABNOTES.md section 5, round 3, item 7;
         # tools/placement_time.py): allocations fall into two classes, one of which takes stores ~19 % faster.  The headline above uses the
         # tensors as torch allocated them (no shopping).  Informational: the same launch on the fastest of 4 candidate allocations each for
         # V and out, chosen by the load-only / store-only copy probes — what an application that probes its long-lived buffers would see.

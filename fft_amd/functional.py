@@ -197,7 +197,7 @@ def copy_probe(src: torch.Tensor, dst: torch.Tensor, seg_bytes: int = 0, *, tile
 def empty_on_fast_allocation(shape, dtype=torch.float32, device="cuda", candidates: int = 4):
     """`torch.empty(shape)` on the fastest of `candidates` fresh allocations, by a store-only pass of the copy probe over each.
 
-    On MI355X device allocations come in two classes; one takes stores ~19 % faster, and the class belongs to the allocation (DESIGN.md
+    On MI355X device allocations come in two classes; one takes stores ~19 % faster, and the class belongs to the allocation (LABNOTES.md
     section 5, round 3, item 7; tools/placement_classes.py).  For long-lived (B, N, D) activation buffers it is worth half a millisecond
     per candidate, once.  The losers go back to torch's caching allocator, which may hand them out again: allocate what must be fast
     first.  Returns (tensor, store_ms_of_every_candidate); tensors the dense probe cannot take (not 3-D, not a multiple of 256 KiB) come

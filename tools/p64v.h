@@ -3,6 +3,8 @@
 //   GANGX  workgroups that walk through adjacent tiles in step (library: 2 = one 128-byte line per row)
 //   AUXD / AUXL / AUXS  cache-policy bits (gfx940 encoding: 1 = sc0, 2 = nt, 16 = sc1) of the LDS-DMA requests, the register loads, the stores
 //   MAPX   1 = compact window: tile = it * n_wg + wg (all workgroups in adjacent tiles at any time)
+//   SYNCP  the workgroups of a gang MEET once per tile through a device-scope counter (a.mem = counter buffer, one word per gang, zeroed before
+//          the launch): 1 = behind E2 (in front of the LDS-DMA burst and the stores of I2), 2 = at the end of F1 (in front of the deferred stores)
 //   PRIO   0 none; 1 = s_setprio 1 for waves 4..7 (static); 2 = s_setprio 1 for waves 0..3; 3 = raised priority around the store / load bursts
 #pragma once
 #include "../fft_amd/csrc/kernel_regtile.h"
@@ -138,7 +140,7 @@ template <int SPLIT> constexpr int p64v_younger_first() { return 4 * (8 - SPLIT)
 //         right behind E2 of the previous one, none behind its stores (round 3: the fp32 kernel's late groups cost a memory latency
 //         per tile — same-box ablation: loads only 1.11 ms, stores only 0.90, neither 0.84).
 // OUT_BF16 = bf16 rows out (round to nearest even, like every other kernel here): a lane stores its 4 channels as 8 bytes.
-template <int SPLIT, int PF, bool WITH_MEM = false, bool IN_BF16 = false, bool OUT_BF16 = false, int GANGX = 0, int AUXD = 0, int AUXL = 0, int AUXS = 0, int PRIO = 0, int MAPX = 0, int DSPREAD = 0>
+template <int SPLIT, int PF, bool WITH_MEM = false, bool IN_BF16 = false, bool OUT_BF16 = false, int GANGX = 0, int AUXD = 0, int AUXL = 0, int AUXS = 0, int PRIO = 0, int MAPX = 0, int DSPREAD = 0, int SYNCP = 0>
 __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) {
   constexpr int ESI = IN_BF16 ? 2 : 4, ESO = OUT_BF16 ? 2 : 4;   // bytes per input / output element
   constexpr float inv_n = 1.0f / 4096.0f;
@@ -192,6 +194,29 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
   const int pair_base = MAPX == 2 ? ((bx / 16) * 8 + bx % 8) * 2 + (bx / 8) % 2 : MAPX ? wg_lin : (wg_lin / GANG) * a.tpw * GANG + (wg_lin % GANG);
   const int TS = MAPX ? a.n_wg : GANG;
   if (pair_base >= a.n_tiles) return;
+  // SYNCP: wave 0 announces the workgroup (one atomic add, no return value: older than every request the hand-counted waits look at) and
+  // polls the gang's counter with SCALAR loads (lgkmcnt, not the in-order vmcnt the stores sit in); the other waves wait at a barrier.
+  // Performance only: the spin is bounded, and a gang whose partner never shows up stops waiting after the first time-out.
+  [[maybe_unused]] unsigned nsync = 0;
+  [[maybe_unused]] bool sync_on = true;
+  [[maybe_unused]] auto gang_meet = [&]() {
+    unsigned* cp = reinterpret_cast<unsigned*>(const_cast<float*>(a.mem)) + (MAPX ? 0 : wg_lin / GANG);
+    ++nsync;
+    if (__builtin_amdgcn_readfirstlane(tid0 >> 6) == 0) {
+      if (lane == 0) __hip_atomic_fetch_add(cp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (sync_on) {
+        int i = 0;
+        for (; i < 128; ++i) {
+          unsigned val;
+          asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(val) : "s"(cp) : "memory");
+          if (val >= (unsigned)GANG * nsync) break;
+          __builtin_amdgcn_s_sleep(2);
+        }
+        if (i == 128) sync_on = false;
+      }
+    }
+    p64v_barrier();
+  };
 
   float2 z[64];
   float4 dfr[PF > 0 ? 4 * PF : 1];                 // deferred results of the previous tile / prefetched rows of the next one
@@ -415,6 +440,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
     __builtin_amdgcn_sched_barrier(0);
     // ---- the quiet part of the tile starts: the deferred results of the previous tile leave, the same row groups of the next tile
     //      are requested into the registers they vacate
+    if constexpr (SYNCP == 2) gang_meet();
     static_for<0, 4 * PF>([&](auto ic) { pf_store(ic); });
     static_for<0, 4 * PF>([&](auto ic) { pf_load(ic); });
     __builtin_amdgcn_sched_barrier(0);
@@ -491,6 +517,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
     // ---- E2: position n2 -> image row n2, column (p, k1 = u); thread (p, u) reads row u, slot k1.  The barrier behind the last read
     //      frees the image for the LDS-DMA below.
     p64v_exchange_rest<true>(z, img, p, u);
+    if constexpr (SYNCP == 1) gang_meet();
 
     // ---- the image is idle until the next F1: let the first row groups of the next tile land in it, and fetch its gate -----
     const uint32_t voff = (uint32_t)(((long long)(u + 512 * h) * v_sn + 4 * pp) * ESI);

@@ -51,6 +51,9 @@ int main(int argc, char** argv) {
   la.v_sb = (long long)N * D; la.v_sn = D; la.out_sb = (long long)N * D; la.out_sn = D;
   la.tiles_per_row = D / 16; la.n_tiles = B * (D / 16);
 
+  unsigned* cnt_buf; CK(hipMalloc(&cnt_buf, 4096)); CK(hipMemset(cnt_buf, 0, 4096));
+  RegtileArgs ls = la; ls.mem = reinterpret_cast<const float*>(cnt_buf);      // SYNCP variants: a.mem carries the gang counters
+  auto synced = [&](std::function<void()> f) { return std::function<void()>([=] { CK(hipMemsetAsync(cnt_buf, 0, 4096, 0)); f(); }); };
   std::vector<Variant> vs;
   auto add = [&](const char* name, std::function<void()> f) { if (strstr(name, filter)) vs.push_back({name, f, {}}); };
   add("LIBRARY <4,2>", mk(spectre_mix_regtile64p<4, 2>, la, 2, kP64LdsTotal));
