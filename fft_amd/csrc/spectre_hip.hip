@@ -18,6 +18,7 @@
 
 #include "../../include/spectre_hip.h"
 #include "kernel_regtile_grad.h"
+#include "kernel_regtile_wide.h"
 #include "kernel_regtile_mixed_grad.h"
 #include "kernel_stockham.h"
 #include "kernel_gate.h"
@@ -151,7 +152,7 @@ const char* tuning_env(const char* name) {
 }
 std::string tuning_overrides() {
   std::string r;
-  for (const char* n : {"SPECTRE_P64", "SPECTRE_P64_BF16", "SPECTRE_MIXEDP", "SPECTRE_STOCKHAM_PMAX", "SPECTRE_TPW", "SPECTRE_P64_TPW", "SPECTRE_GATE_GRAD"})
+  for (const char* n : {"SPECTRE_P64", "SPECTRE_P64_BF16", "SPECTRE_WIDE", "SPECTRE_MIXEDP", "SPECTRE_STOCKHAM_PMAX", "SPECTRE_TPW", "SPECTRE_P64_TPW", "SPECTRE_GATE_GRAD"})
     if (const char* e = tuning_env(n)) r += std::string(r.empty() ? "" : " ") + n + "=" + e;
   return r;
 }
@@ -317,6 +318,7 @@ struct Choice {
   bool regtile = false;
   const TileSize* tile = nullptr;
   int RF = 0, RS = 0;      // n_fft = RF * RS
+  bool wide = false;       // 32-channel tiles: whole 128-byte lines per row (kernel_regtile_wide.h; n_fft <= 1024, fast mode)
   int mode = 0;            // 0 fast, 1 general (row predicates / gate from global), 2 general + memory_fft, 3 row predicates only
   bool mixedp = false;     // n_fft = 3000 / 2560 / 2400 / 3072 / 3600 / 3840, fp32 in/out, gate in LDS, 8-byte aligned rows: persistent kernel with deferred row blocks (kernel_regtile_mixedp.h)
   bool pipelined = false;  // n_fft = 4096 fast mode, fp32, 16-byte aligned rows: persistent software-pipelined kernel (kernel_regtile64p.h)
@@ -399,6 +401,10 @@ int choose(const SpectreMixArgs* a, const Plan* plan, Choice* c) {
     c->tile = ts; c->RF = ts->RF; c->RS = ts->RS;
     c->mode = mode;
     c->pipelined = pipelined_ok;
+    // whole-line tiles (round 4): a workgroup owns 32 channels, so every request is a full 128-byte line (bf16 rows: 64 bytes) instead of
+    // half of one — the L2 takes half-line stores at two thirds of the rate (profiles/r04_store_lab_half_line_stores.log)
+    static const bool wide_off = [] { const char* e = tuning_env("SPECTRE_WIDE"); return e && atoi(e) == 0; }();
+    c->wide = !wide_off && !ts->mixed && ts->tile_ch == 16 && n <= 1024 && mode == 0 && d_g % 32 == 0 && D % 32 == 0 && (!out_bf || in_bf);
     static const bool mixedp_off = [] { const char* e = tuning_env("SPECTRE_MIXEDP"); return e && atoi(e) == 0; }();
     c->mixedp = !mixedp_off && ts->mixed && (n == 3000 || n == 2560 || n == 2400 || n == 3072 || n == 3600 || n == 3840) && (mode == 0 || mode == 3) && a->in_dtype == SPECTRE_F32 && a->out_dtype == SPECTRE_F32 &&
                 reinterpret_cast<uintptr_t>(a->v) % 8 == 0 && reinterpret_cast<uintptr_t>(a->out) % 8 == 0 &&
@@ -478,7 +484,12 @@ int launch(const SpectreMixArgs* a, const Plan* plan, const Choice& c, bool conj
     k.n_wg = 2 * ((k.n_tiles + 2 * k.tpw - 1) / (2 * k.tpw));
     const bool ib = a->in_dtype == SPECTRE_BF16, ob = a->out_dtype == SPECTRE_BF16;
     if (c.tile->mixed) { k.tpw = 1; k.n_wg = 2 * ((k.n_tiles + 1) / 2); }
-    if (c.pipelined) {   // one workgroup per CU walks through tpw tiles; pairs of workgroups stay on adjacent tiles
+    if (c.wide) {          // one whole-line tile per workgroup (kernel_regtile_wide.h)
+      k.tiles_per_row = (int)(a->D / 32); k.n_tiles = (int)(a->B * (a->D / 32)); k.tpw = 1; k.n_wg = k.n_tiles;
+      const int64_t n = a->n_fft;
+      e = n == 1024 ? sfft::launch_regtile_wide<32, 32>(k, ib, ob, stream) : n == 512 ? sfft::launch_regtile_wide<32, 16>(k, ib, ob, stream)
+                                                                                          : sfft::launch_regtile_wide<16, 16>(k, ib, ob, stream);
+    } else if (c.pipelined) {   // one workgroup per CU walks through tpw tiles; pairs of workgroups stay on adjacent tiles
       const int ncu = cu_count(a->device);
       static const int forced = [] { const char* e = tuning_env("SPECTRE_P64_TPW"); return e ? atoi(e) : 0; }();
       const int gang = (ib || ob) ? 4 : 2;                  // kP64Gang: workgroups that share a 128-byte line walk through adjacent tiles
@@ -608,8 +619,8 @@ int spectre_mix_describe(const SpectreMixArgs* a, char* buf, size_t cap) {
   const char* in = a->in_dtype == SPECTRE_BF16 ? "bf16" : "f32";
   const char* out = a->out_dtype == SPECTRE_BF16 ? "bf16" : "f32";
   if (c.regtile) {
-    snprintf(buf, cap, "regtile%s %dx%d in=%s out=%s mode=%d tiles=%lld", c.pipelined ? "-pipelined" : c.mixedp ? "-mixed-pipelined" : c.tile->tile_ch == 4 ? "-quad" : c.tile->tile_ch == 8 ? "-long" : c.tile->mixed ? "-mixed" : "", c.RF, c.RS,
-             in, out, c.mode, (long long)(a->B * ((a->D + c.tile->tile_ch - 1) / c.tile->tile_ch)));
+    snprintf(buf, cap, "regtile%s %dx%d in=%s out=%s mode=%d tiles=%lld", c.wide ? "-wide" : c.pipelined ? "-pipelined" : c.mixedp ? "-mixed-pipelined" : c.tile->tile_ch == 4 ? "-quad" : c.tile->tile_ch == 8 ? "-long" : c.tile->mixed ? "-mixed" : "", c.RF, c.RS,
+             in, out, c.mode, (long long)(a->B * ((a->D + (c.wide ? 32 : c.tile->tile_ch) - 1) / (c.wide ? 32 : c.tile->tile_ch))));
   } else {
     std::string r;
     const std::vector<int>& rad = plan->bluestein ? plan->radix_m : plan->radix_n;
