@@ -30,8 +30,10 @@ template <int RF, int RS> constexpr int regtile_wide_image_bytes() {
   return (RF * kPCW * (RS + 4) > RS * kPCW * (RF + 4) ? RF * kPCW * (RS + 4) : RS * kPCW * (RF + 4)) * 4;
 }
 template <int RF, int RS> constexpr int regtile_wide_lds_total() { return regtile_wide_image_bytes<RF, RS>() + regtile_gate_lds_bytes<RF, RS>(); }
-template <int RF, int RS, bool IN_BF16, bool OUT_BF16>
-__global__ void __launch_bounds__(kPCW * RS, 4)   // four waves per SIMD = 128 registers: two 512-thread workgroups per CU at n_fft = 1024
+// WPS = waves per SIMD the kernel is compiled for: 4 (128 registers: two 512-thread workgroups per CU at n_fft = 1024); the 64 x 32
+// instantiation (n_fft = 2048: one 512-thread workgroup per CU, 155 KiB of LDS) takes 2
+template <int RF, int RS, bool IN_BF16, bool OUT_BF16, int WPS = (RF >= 64 ? 2 : 4)>
+__global__ void __launch_bounds__(kPCW * RS, WPS)
 spectre_mix_regtile_wide(const RegtileArgs a) {
   static_assert(RF == RS || RF == 2 * RS, "n_fft = RS*RS or 2*RS*RS");
   static_assert(RS % 4 == 0 && (64 / kPCW) * (kPCW * RS / 64) == RS, "row classes: 4 per wave");

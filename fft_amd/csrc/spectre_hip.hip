@@ -152,7 +152,7 @@ const char* tuning_env(const char* name) {
 }
 std::string tuning_overrides() {
   std::string r;
-  for (const char* n : {"SPECTRE_P64", "SPECTRE_P64_BF16", "SPECTRE_WIDE", "SPECTRE_MIXEDP", "SPECTRE_STOCKHAM_PMAX", "SPECTRE_TPW", "SPECTRE_P64_TPW", "SPECTRE_GATE_GRAD"})
+  for (const char* n : {"SPECTRE_P64", "SPECTRE_P64_BF16", "SPECTRE_WIDE", "SPECTRE_WIDE_MAX", "SPECTRE_MIXEDP", "SPECTRE_STOCKHAM_PMAX", "SPECTRE_TPW", "SPECTRE_P64_TPW", "SPECTRE_GATE_GRAD"})
     if (const char* e = tuning_env(n)) r += std::string(r.empty() ? "" : " ") + n + "=" + e;
   return r;
 }
@@ -404,7 +404,8 @@ int choose(const SpectreMixArgs* a, const Plan* plan, Choice* c) {
     // whole-line tiles (round 4): a workgroup owns 32 channels, so every request is a full 128-byte line (bf16 rows: 64 bytes) instead of
     // half of one — the L2 takes half-line stores at two thirds of the rate (profiles/r04_store_lab_half_line_stores.log)
     static const bool wide_off = [] { const char* e = tuning_env("SPECTRE_WIDE"); return e && atoi(e) == 0; }();
-    c->wide = !wide_off && !ts->mixed && ts->tile_ch == 16 && n <= 1024 && mode == 0 && d_g % 32 == 0 && D % 32 == 0 && (!out_bf || in_bf);
+    static const int wide_max = [] { const char* e = tuning_env("SPECTRE_WIDE_MAX"); return e ? atoi(e) : 1024; }();
+    c->wide = !wide_off && !ts->mixed && ts->tile_ch == 16 && n <= wide_max && n <= 2048 && mode == 0 && d_g % 32 == 0 && D % 32 == 0 && (!out_bf || in_bf);
     static const bool mixedp_off = [] { const char* e = tuning_env("SPECTRE_MIXEDP"); return e && atoi(e) == 0; }();
     c->mixedp = !mixedp_off && ts->mixed && (n == 3000 || n == 2560 || n == 2400 || n == 3072 || n == 3600 || n == 3840) && (mode == 0 || mode == 3) && a->in_dtype == SPECTRE_F32 && a->out_dtype == SPECTRE_F32 &&
                 reinterpret_cast<uintptr_t>(a->v) % 8 == 0 && reinterpret_cast<uintptr_t>(a->out) % 8 == 0 &&
@@ -487,7 +488,7 @@ int launch(const SpectreMixArgs* a, const Plan* plan, const Choice& c, bool conj
     if (c.wide) {          // one whole-line tile per workgroup (kernel_regtile_wide.h)
       k.tiles_per_row = (int)(a->D / 32); k.n_tiles = (int)(a->B * (a->D / 32)); k.tpw = 1; k.n_wg = k.n_tiles;
       const int64_t n = a->n_fft;
-      e = n == 1024 ? sfft::launch_regtile_wide<32, 32>(k, ib, ob, stream) : n == 512 ? sfft::launch_regtile_wide<32, 16>(k, ib, ob, stream)
+      e = n == 2048 ? sfft::launch_regtile_wide<64, 32>(k, ib, ob, stream) : n == 1024 ? sfft::launch_regtile_wide<32, 32>(k, ib, ob, stream) : n == 512 ? sfft::launch_regtile_wide<32, 16>(k, ib, ob, stream)
                                                                                           : sfft::launch_regtile_wide<16, 16>(k, ib, ob, stream);
     } else if (c.pipelined) {   // one workgroup per CU walks through tpw tiles; pairs of workgroups stay on adjacent tiles
       const int ncu = cu_count(a->device);
