@@ -272,6 +272,14 @@ def main():
             byt = algorithmic_bytes(Bc, Nc, Nc, Dc, G, 4, 4)
             variants[name] = {"tokens_per_s": Bc * Nc / (ms * 1e-3), "kernel_ms": ms, "achieved_GBps": byt / ms / 1e6,
                               "roofline_frac": byt / ms / 1e6 / HBM_PEAK_GBS, "kernel": describe(Vc, gc, None, Nc)}
+            # this configuration's own pattern ceiling: a pure copy in the kernel's tile shape on its own tensors — whole 128-byte lines
+            # of all Nc rows for the whole-line tiles of n_fft <= 1024 (kernel_regtile_wide.h), 64-byte halves in pairs otherwise
+            if (Bc * Nc * Dc * 4) % (256 * 1024) == 0:
+                sgc = 128 if "wide" in variants[name]["kernel"] else 64
+                if (sgc * Nc) % (128 * 1024) == 0:
+                    pm = min(copy_probe(Vc, oc, sgc, tile_rows=Nc, mode="copy", wgs_per_cu=w, warmup=3, iters=max(5, a.steps // 2)) for w in (1, 2, 4))
+                    variants[name].update({"pattern_copy_ms": pm, "pattern_copy_GBps": 2.0 * Bc * Nc * Dc * 4 / pm / 1e6,
+                                           "frac_of_pattern_copy": pm / ms * (byt / (2.0 * Bc * Nc * Dc * 4)), "pattern_segment_bytes": sgc})
             del Vc, gc, oc
         # backward of the same op (row N1), informational: dV = the forward kernels with conj(gate); dgate = gate-gradient kernel
         from fft_amd import spectral_mix_backward

@@ -20,9 +20,11 @@
 // 8-byte aligned fp32 rows (4-byte aligned bf16 rows).
 #pragma once
 #include "kernel_regtile.h"
+#include <cstdlib>
 
 namespace sfft {
 
+typedef float wide_f32x2 __attribute__((ext_vector_type(2)));
 constexpr int kPCW = 16;                     // pair-columns per wide tile: 32 channels, 128-byte fp32 row segments
 
 template <int RF, int RS> constexpr int regtile_wide_threads() { return kPCW * RS; }
@@ -32,7 +34,7 @@ template <int RF, int RS> constexpr int regtile_wide_image_bytes() {
 template <int RF, int RS> constexpr int regtile_wide_lds_total() { return regtile_wide_image_bytes<RF, RS>() + regtile_gate_lds_bytes<RF, RS>(); }
 // WPS = waves per SIMD the kernel is compiled for: 4 (128 registers: two 512-thread workgroups per CU at n_fft = 1024); the 64 x 32
 // instantiation (n_fft = 2048: one 512-thread workgroup per CU, 155 KiB of LDS) takes 2
-template <int RF, int RS, bool IN_BF16, bool OUT_BF16, int WPS = (RF >= 64 ? 2 : 4)>
+template <int RF, int RS, bool IN_BF16, bool OUT_BF16, int WPS = (RF >= 64 ? 2 : 4), int NT = 0>   // NT: 1 = non-temporal loads, 2 = stores, 3 = both
 __global__ void __launch_bounds__(kPCW * RS, WPS)
 spectre_mix_regtile_wide(const RegtileArgs a) {
   static_assert(RF == RS || RF == 2 * RS, "n_fft = RS*RS or 2*RS*RS");
@@ -84,10 +86,12 @@ spectre_mix_regtile_wide(const RegtileArgs a) {
       constexpr int q = (decltype(ic)::value / RAF) + RBF * (decltype(ic)::value % RAF);   // order of use in F1
       const char* ptr = vb + (size_t)q * RS * v_sn * ES_IN + voff;
       if constexpr (IN_BF16) {
-        const uint32_t wv = *reinterpret_cast<const uint32_t*>(ptr);
+        uint32_t wv;
+        if constexpr (NT & 1) wv = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(ptr)); else wv = *reinterpret_cast<const uint32_t*>(ptr);
         z[q] = make_float2(__uint_as_float(wv << 16), __uint_as_float(wv & 0xffff0000u));
       } else {
-        z[q] = *reinterpret_cast<const float2*>(ptr);
+        if constexpr (NT & 1) { const wide_f32x2 t = __builtin_nontemporal_load(reinterpret_cast<const wide_f32x2*>(ptr)); z[q] = make_float2(t.x, t.y); }
+        else z[q] = *reinterpret_cast<const float2*>(ptr);
       }
     });
   }
@@ -181,7 +185,11 @@ spectre_mix_regtile_wide(const RegtileArgs a) {
       if constexpr ((j % RBF) == 0) fftA_stage2_group<RAF, RBF, true, j / RBF>(z);
       constexpr int n1 = (j / RBF) + RAF * (j % RBF);
       char* ptr = ob + (size_t)n1 * RS * out_sn * ES_OUT + ooff;
-      if constexpr (OUT_BF16) *reinterpret_cast<uint32_t*>(ptr) = f32_to_bf16_rne(z[j].x) | (f32_to_bf16_rne(z[j].y) << 16);
+      if constexpr (OUT_BF16) {
+        const uint32_t w = f32_to_bf16_rne(z[j].x) | (f32_to_bf16_rne(z[j].y) << 16);
+        if constexpr (NT & 2) __builtin_nontemporal_store(w, reinterpret_cast<uint32_t*>(ptr)); else *reinterpret_cast<uint32_t*>(ptr) = w;
+      }
+      else if constexpr (NT & 2) { wide_f32x2 t; t.x = z[j].x; t.y = z[j].y; __builtin_nontemporal_store(t, reinterpret_cast<wide_f32x2*>(ptr)); }
       else *reinterpret_cast<float2*>(ptr) = z[j];
     });
   }
@@ -196,23 +204,36 @@ hipError_t launch_regtile_wide(const RegtileArgs& a, bool in_bf16, bool out_bf16
     const dim3 grid(a.n_wg), block(regtile_wide_threads<RF_, RS_>());                                        \
     const size_t lds = regtile_wide_lds_total<RF_, RS_>();                                                   \
     const int key = (in_bf16 ? 2 : 0) | (out_bf16 ? 1 : 0);                                                  \
-    static std::atomic<bool> lds_opt_in[16][4];                                                              \
+    /* non-temporal accesses: whole-line requests that nobody else shares.  Measured (tools/wide_nt_ab.py, wide_nt_bf16_ab.py, one box,  */ \
+    /* interleaved): fp32 rows, both directions nt: -4.8 % at 1024, -4.5 % at 512; bf16 -> fp32: -2.8 %; bf16 -> bf16 (64-byte halves    */ \
+    /* shared with the neighbouring tile in BOTH directions): +3 %, stays plain.  SPECTRE_WIDE_NT (under SPECTRE_TUNING=1) overrides.     */ \
+    static const int nt_env = [] { const char* t = getenv("SPECTRE_TUNING"); const char* e = getenv("SPECTRE_WIDE_NT"); return (t && atoi(t) == 1 && e) ? atoi(e) : -1; }(); \
+    const int nt = nt_env >= 0 ? (nt_env & 3) : (key == 0 || key == 2 ? 3 : 0);                                         \
+    static std::atomic<bool> lds_opt_in[16][16];                                                             \
     auto go = [&](auto kern) -> hipError_t {                                                                 \
       int dev = 0;                                                                                           \
       (void)hipGetDevice(&dev);                                                                              \
-      if (dev < 0 || dev >= 16 || !lds_opt_in[dev][key]) {                                                   \
+      if (dev < 0 || dev >= 16 || !lds_opt_in[dev][key * 4 + nt]) {                                                   \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                              \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
         if (e != hipSuccess) return e;                                                                       \
-        if (dev >= 0 && dev < 16) lds_opt_in[dev][key] = true;                                               \
+        if (dev >= 0 && dev < 16) lds_opt_in[dev][key * 4 + nt] = true;                                               \
       }                                                                                                      \
       hipLaunchKernelGGL(kern, grid, block, lds, stream, a);                                                 \
       return hipGetLastError();                                                                              \
     };                                                                                                       \
-    switch (key) {                                                                                           \
-      case 0: return go(spectre_mix_regtile_wide<RF_, RS_, false, false>);                                   \
-      case 2: return go(spectre_mix_regtile_wide<RF_, RS_, true, false>);                                    \
-      case 3: return go(spectre_mix_regtile_wide<RF_, RS_, true, true>);                                     \
+    constexpr int W = (RF_ >= 64 ? 2 : 4);                                                                   \
+    switch (key * 4 + nt) {                                                                                  \
+      case 0: return go(spectre_mix_regtile_wide<RF_, RS_, false, false, W, 0>);                             \
+      case 1: return go(spectre_mix_regtile_wide<RF_, RS_, false, false, W, 1>);                             \
+      case 2: return go(spectre_mix_regtile_wide<RF_, RS_, false, false, W, 2>);                             \
+      case 3: return go(spectre_mix_regtile_wide<RF_, RS_, false, false, W, 3>);                             \
+      case 8: return go(spectre_mix_regtile_wide<RF_, RS_, true, false, W, 0>);                              \
+      case 11: return go(spectre_mix_regtile_wide<RF_, RS_, true, false, W, 3>);                             \
+      case 12: return go(spectre_mix_regtile_wide<RF_, RS_, true, true, W, 0>);                              \
+      case 15: return go(spectre_mix_regtile_wide<RF_, RS_, true, true, W, 3>);                              \
+      case 9: case 10: return go(spectre_mix_regtile_wide<RF_, RS_, true, false, W, 0>);                     \
+      case 13: case 14: return go(spectre_mix_regtile_wide<RF_, RS_, true, true, W, 0>);                     \
       default: return hipErrorInvalidValue;   /* f32 -> bf16 stays with kernel_regtile.h */                   \
     }                                                                                                        \
   }
