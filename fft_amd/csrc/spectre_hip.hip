@@ -152,7 +152,7 @@ const char* tuning_env(const char* name) {
 }
 std::string tuning_overrides() {
   std::string r;
-  for (const char* n : {"SPECTRE_P64", "SPECTRE_P64_BF16", "SPECTRE_WIDE", "SPECTRE_WIDE_MAX", "SPECTRE_MIXEDP", "SPECTRE_STOCKHAM_PMAX", "SPECTRE_TPW", "SPECTRE_P64_TPW", "SPECTRE_GATE_GRAD"})
+  for (const char* n : {"SPECTRE_P64", "SPECTRE_P64_BF16", "SPECTRE_WIDE", "SPECTRE_WIDE_MAX", "SPECTRE_WIDE_NT", "SPECTRE_MIXEDP", "SPECTRE_STOCKHAM_PMAX", "SPECTRE_TPW", "SPECTRE_P64_TPW", "SPECTRE_GATE_GRAD"})
     if (const char* e = tuning_env(n)) r += std::string(r.empty() ? "" : " ") + n + "=" + e;
   return r;
 }
