@@ -34,7 +34,10 @@ template <int RF, int RS> constexpr int regtile_wide_image_bytes() {
 template <int RF, int RS> constexpr int regtile_wide_lds_total() { return regtile_wide_image_bytes<RF, RS>() + regtile_gate_lds_bytes<RF, RS>(); }
 // WPS = waves per SIMD the kernel is compiled for: 4 (128 registers: two 512-thread workgroups per CU at n_fft = 1024); the 64 x 32
 // instantiation (n_fft = 2048: one 512-thread workgroup per CU, 155 KiB of LDS) takes 2
-template <int RF, int RS, bool IN_BF16, bool OUT_BF16, int WPS = (RF >= 64 ? 2 : 4), int NT = 0>   // NT: 1 = non-temporal loads, 2 = stores, 3 = both
+// PADDED: N_in < n_fft (spectre.py:506 zero-pads, :553 keeps the first N_in rows): rows >= N_in are the out-of-range case of buffer
+// instructions — loads return 0, stores are dropped — so a padded sequence costs what a full one costs, without a predicate
+// (kernel_regtile64p.h; the range check covers the VGPR offset only, so the row-block offset is added there).
+template <int RF, int RS, bool IN_BF16, bool OUT_BF16, int WPS = (RF >= 64 ? 2 : 4), int NT = 0, bool PADDED = false>   // NT: 1 = non-temporal loads, 2 = stores, 3 = both
 __global__ void __launch_bounds__(kPCW * RS, WPS)
 spectre_mix_regtile_wide(const RegtileArgs a) {
   static_assert(RF == RS || RF == 2 * RS, "n_fft = RS*RS or 2*RS*RS");
@@ -82,8 +85,20 @@ spectre_mix_regtile_wide(const RegtileArgs a) {
   {
     const char* vb = reinterpret_cast<const char*>(a.v) + ((size_t)b * a.v_sb + (size_t)ct * (2 * kPCW)) * ES_IN;
     const uint32_t voff = (uint32_t)(((long long)u * v_sn + 2 * p) * ES_IN);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(vb), 0, (int)((long long)a.rows_in * v_sn * ES_IN), kRsrcFlags);
     static_for<0, RF>([&](auto ic) {
       constexpr int q = (decltype(ic)::value / RAF) + RBF * (decltype(ic)::value % RAF);   // order of use in F1
+      if constexpr (PADDED) {
+        const uint32_t off = voff + (uint32_t)((long long)q * RS * v_sn * ES_IN);
+        if constexpr (IN_BF16) {
+          const uint32_t wv = __builtin_amdgcn_raw_buffer_load_b32(rs_in, off, 0, (NT & 1) ? 2 : 0);
+          z[q] = make_float2(__uint_as_float(wv << 16), __uint_as_float(wv & 0xffff0000u));
+        } else {
+          const rt_u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs_in, off, 0, (NT & 1) ? 2 : 0);
+          z[q] = make_float2(__uint_as_float(t.x), __uint_as_float(t.y));
+        }
+        return;
+      }
       const char* ptr = vb + (size_t)q * RS * v_sn * ES_IN + voff;
       if constexpr (IN_BF16) {
         uint32_t wv;
@@ -180,10 +195,22 @@ spectre_mix_regtile_wide(const RegtileArgs a) {
   {
     char* ob = reinterpret_cast<char*>(a.out) + ((size_t)b * a.out_sb + (size_t)ct * (2 * kPCW)) * ES_OUT;
     const uint32_t ooff = (uint32_t)(((long long)u * out_sn + 2 * p) * ES_OUT);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(ob, 0, (int)((long long)a.rows_out * out_sn * ES_OUT), kRsrcFlags);
     static_for<0, RF>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
       if constexpr ((j % RBF) == 0) fftA_stage2_group<RAF, RBF, true, j / RBF>(z);
       constexpr int n1 = (j / RBF) + RAF * (j % RBF);
+      if constexpr (PADDED) {
+        const uint32_t off = ooff + (uint32_t)((long long)n1 * RS * out_sn * ES_OUT);
+        if constexpr (OUT_BF16) {
+          __builtin_amdgcn_raw_buffer_store_b32(f32_to_bf16_rne(z[j].x) | (f32_to_bf16_rne(z[j].y) << 16), rs_out, off, 0, (NT & 2) ? 2 : 0);
+        } else {
+          rt_u32x2 t;
+          t.x = __float_as_uint(z[j].x); t.y = __float_as_uint(z[j].y);
+          __builtin_amdgcn_raw_buffer_store_b64(t, rs_out, off, 0, (NT & 2) ? 2 : 0);
+        }
+        return;
+      }
       char* ptr = ob + (size_t)n1 * RS * out_sn * ES_OUT + ooff;
       if constexpr (OUT_BF16) {
         const uint32_t w = f32_to_bf16_rne(z[j].x) | (f32_to_bf16_rne(z[j].y) << 16);
@@ -196,33 +223,41 @@ spectre_mix_regtile_wide(const RegtileArgs a) {
 }
 
 template <int RF, int RS>
-hipError_t launch_regtile_wide(const RegtileArgs& a, bool in_bf16, bool out_bf16, hipStream_t stream);
+hipError_t launch_regtile_wide(const RegtileArgs& a, bool in_bf16, bool out_bf16, bool padded, hipStream_t stream);
 
 #define SFFT_DEFINE_REGTILE_WIDE_LAUNCHER(RF_, RS_)                                                          \
   template <>                                                                                                \
-  hipError_t launch_regtile_wide<RF_, RS_>(const RegtileArgs& a, bool in_bf16, bool out_bf16, hipStream_t stream) { \
+  hipError_t launch_regtile_wide<RF_, RS_>(const RegtileArgs& a, bool in_bf16, bool out_bf16, bool padded, hipStream_t stream) { \
     const dim3 grid(a.n_wg), block(regtile_wide_threads<RF_, RS_>());                                        \
     const size_t lds = regtile_wide_lds_total<RF_, RS_>();                                                   \
     const int key = (in_bf16 ? 2 : 0) | (out_bf16 ? 1 : 0);                                                  \
+    constexpr int W = (RF_ >= 64 ? 2 : 4);                                                                   \
     /* non-temporal accesses: whole-line requests that nobody else shares.  Measured (tools/wide_nt_ab.py, wide_nt_bf16_ab.py, one box,  */ \
     /* interleaved): fp32 rows, both directions nt: -4.8 % at 1024, -4.5 % at 512; bf16 -> fp32: -2.8 %; bf16 -> bf16 (64-byte halves    */ \
     /* shared with the neighbouring tile in BOTH directions): +3 %, stays plain.  SPECTRE_WIDE_NT (under SPECTRE_TUNING=1) overrides.     */ \
     static const int nt_env = [] { const char* t = getenv("SPECTRE_TUNING"); const char* e = getenv("SPECTRE_WIDE_NT"); return (t && atoi(t) == 1 && e) ? atoi(e) : -1; }(); \
     const int nt = nt_env >= 0 ? (nt_env & 3) : (key == 0 || key == 2 ? 3 : 0);                                         \
-    static std::atomic<bool> lds_opt_in[16][16];                                                             \
+    static std::atomic<bool> lds_opt_in[16][32];                                                             \
     auto go = [&](auto kern) -> hipError_t {                                                                 \
       int dev = 0;                                                                                           \
       (void)hipGetDevice(&dev);                                                                              \
-      if (dev < 0 || dev >= 16 || !lds_opt_in[dev][key * 4 + nt]) {                                                   \
+      if (dev < 0 || dev >= 16 || !lds_opt_in[dev][key * 4 + nt + (padded ? 16 : 0)]) {                                                   \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                              \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
         if (e != hipSuccess) return e;                                                                       \
-        if (dev >= 0 && dev < 16) lds_opt_in[dev][key * 4 + nt] = true;                                               \
+        if (dev >= 0 && dev < 16) lds_opt_in[dev][key * 4 + nt + (padded ? 16 : 0)] = true;                                               \
       }                                                                                                      \
       hipLaunchKernelGGL(kern, grid, block, lds, stream, a);                                                 \
       return hipGetLastError();                                                                              \
     };                                                                                                       \
-    constexpr int W = (RF_ >= 64 ? 2 : 4);                                                                   \
+    if (padded) {   /* N_in < n_fft: buffer instructions with the rows that exist as their range */              \
+      switch (key) {                                                                                         \
+        case 0: return nt ? go(spectre_mix_regtile_wide<RF_, RS_, false, false, W, 3, true>) : go(spectre_mix_regtile_wide<RF_, RS_, false, false, W, 0, true>); \
+        case 2: return nt ? go(spectre_mix_regtile_wide<RF_, RS_, true, false, W, 3, true>) : go(spectre_mix_regtile_wide<RF_, RS_, true, false, W, 0, true>);   \
+        case 3: return go(spectre_mix_regtile_wide<RF_, RS_, true, true, W, 0, true>);                         \
+        default: return hipErrorInvalidValue;                                                                \
+      }                                                                                                      \
+    }                                                                                                        \
     switch (key * 4 + nt) {                                                                                  \
       case 0: return go(spectre_mix_regtile_wide<RF_, RS_, false, false, W, 0>);                             \
       case 1: return go(spectre_mix_regtile_wide<RF_, RS_, false, false, W, 1>);                             \

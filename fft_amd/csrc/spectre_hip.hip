@@ -405,7 +405,7 @@ int choose(const SpectreMixArgs* a, const Plan* plan, Choice* c) {
     // half of one — the L2 takes half-line stores at two thirds of the rate (profiles/r04_store_lab_half_line_stores.log)
     static const bool wide_off = [] { const char* e = tuning_env("SPECTRE_WIDE"); return e && atoi(e) == 0; }();
     static const int wide_max = [] { const char* e = tuning_env("SPECTRE_WIDE_MAX"); return e ? atoi(e) : 1024; }();
-    c->wide = !wide_off && !ts->mixed && ts->tile_ch == 16 && n <= wide_max && n <= 2048 && mode == 0 && d_g % 32 == 0 && D % 32 == 0 && (!out_bf || in_bf);
+    c->wide = !wide_off && !ts->mixed && ts->tile_ch == 16 && n <= wide_max && n <= 2048 && (mode == 0 || mode == 3) && d_g % 32 == 0 && D % 32 == 0 && (!out_bf || in_bf);
     static const bool mixedp_off = [] { const char* e = tuning_env("SPECTRE_MIXEDP"); return e && atoi(e) == 0; }();
     c->mixedp = !mixedp_off && ts->mixed && (n == 3000 || n == 2560 || n == 2400 || n == 3072 || n == 3600 || n == 3840) && (mode == 0 || mode == 3) && a->in_dtype == SPECTRE_F32 && a->out_dtype == SPECTRE_F32 &&
                 reinterpret_cast<uintptr_t>(a->v) % 8 == 0 && reinterpret_cast<uintptr_t>(a->out) % 8 == 0 &&
@@ -488,8 +488,8 @@ int launch(const SpectreMixArgs* a, const Plan* plan, const Choice& c, bool conj
     if (c.wide) {          // one whole-line tile per workgroup (kernel_regtile_wide.h)
       k.tiles_per_row = (int)(a->D / 32); k.n_tiles = (int)(a->B * (a->D / 32)); k.tpw = 1; k.n_wg = k.n_tiles;
       const int64_t n = a->n_fft;
-      e = n == 2048 ? sfft::launch_regtile_wide<64, 32>(k, ib, ob, stream) : n == 1024 ? sfft::launch_regtile_wide<32, 32>(k, ib, ob, stream) : n == 512 ? sfft::launch_regtile_wide<32, 16>(k, ib, ob, stream)
-                                                                                          : sfft::launch_regtile_wide<16, 16>(k, ib, ob, stream);
+      e = n == 2048 ? sfft::launch_regtile_wide<64, 32>(k, ib, ob, c.mode == 3, stream) : n == 1024 ? sfft::launch_regtile_wide<32, 32>(k, ib, ob, c.mode == 3, stream) : n == 512 ? sfft::launch_regtile_wide<32, 16>(k, ib, ob, c.mode == 3, stream)
+                                                                                          : sfft::launch_regtile_wide<16, 16>(k, ib, ob, c.mode == 3, stream);
     } else if (c.pipelined) {   // one workgroup per CU walks through tpw tiles; pairs of workgroups stay on adjacent tiles
       const int ncu = cu_count(a->device);
       static const int forced = [] { const char* e = tuning_env("SPECTRE_P64_TPW"); return e ? atoi(e) : 0; }();

@@ -62,7 +62,7 @@ def test_dispatcher_leaves_the_wide_kernel_when_it_must():
     V, gate = _problem(1, 2, 1024, 64, 2)
     Vd, gd = V.to(DEV), gate.to(DEV)
     assert describe(Vd, gd, None, 1024).startswith("regtile-wide 32x32")
-    assert describe(Vd[:, :1000], gd, None, 1024).startswith("regtile 32x32") and "mode=3" in describe(Vd[:, :1000], gd, None, 1024)   # padded sequence
+    assert describe(Vd[:, :1000], gd, None, 1024).startswith("regtile-wide 32x32 in=f32 out=f32 mode=3")   # padded sequence: same kernel, buffer ranges
     V48, g48 = _problem(2, 2, 1024, 48, 1)                                  # D % 32 != 0
     assert describe(V48.to(DEV), g48.to(DEV), None, 1024).startswith("regtile 32x32")
     V2, g2 = _problem(3, 2, 1024, 64, 4)                                    # d_g = 16: a 32-channel tile would straddle two groups
@@ -121,3 +121,27 @@ def test_full_size_properties_at_baseline_config_1():
     for b in (0, 255):
         e = spectral_mix_numpy(V[b:b + 1].cpu().numpy(), gate[b:b + 1].cpu().numpy(), None, N)
         assert_close(y[b:b + 1, :, cols].cpu().numpy(), e[:, :, cols], what=f"full-size columns, b={b}")
+
+
+@pytest.mark.parametrize("n", [256, 512, 1024])
+@pytest.mark.parametrize("short", [24, 1, "half"])
+def test_padded_sequences_on_wide_tiles(n, short):
+    """N_in < n_fft: rfft zero-pads (spectre.py:506), the output keeps N_in rows (:553) — the out-of-range case of the buffer instructions."""
+    from fft_amd import describe
+    N_in = n // 2 + 3 if short == "half" else n - short
+    g = torch.Generator().manual_seed(n + N_in)
+    V = torch.randn(3, N_in, 64, generator=g)
+    F = n // 2 + 1
+    gate = (torch.complex(torch.randn(3, 2, F, generator=g), torch.randn(3, 2, F, generator=g)) * 0.3).to(torch.complex64)
+    assert describe(V.to(DEV), gate.to(DEV), None, n).startswith("regtile-wide") and "mode=3" in describe(V.to(DEV), gate.to(DEV), None, n)
+    guard = torch.full((3, N_in + 8, 64), 7.0, device=DEV)                  # rows behind the output must stay untouched
+    out = guard[:, :N_in]
+    from fft_amd import spectral_mix
+    y = spectral_mix(V.to(DEV), gate.to(DEV), None, n, out=out)
+    torch.cuda.synchronize()
+    assert y.shape == (3, N_in, 64)
+    assert_close(y.cpu().numpy(), spectral_mix_numpy(V.numpy(), gate.numpy(), None, n), what=f"padded wide {n} <- {N_in}")
+    assert bool((guard[:, N_in:] == 7.0).all())
+    Vb = V.to(torch.bfloat16)
+    yb = _run(Vb, gate, n, out_dtype=torch.float32)
+    assert_close(yb.cpu().numpy(), spectral_mix_numpy(Vb.float().numpy(), gate.numpy(), None, n), what=f"padded wide bf16 {n} <- {N_in}")
