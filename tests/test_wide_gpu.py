@@ -145,3 +145,15 @@ def test_padded_sequences_on_wide_tiles(n, short):
     Vb = V.to(torch.bfloat16)
     yb = _run(Vb, gate, n, out_dtype=torch.float32)
     assert_close(yb.cpu().numpy(), spectral_mix_numpy(Vb.float().numpy(), gate.numpy(), None, n), what=f"padded wide bf16 {n} <- {N_in}")
+
+
+def test_wide_tiles_write_into_strided_output_views():
+    """`out` as a channel-chunk view of a wider buffer (row stride 160, 64 channels at offset 32): only the view's elements change."""
+    from fft_amd import spectral_mix
+    V, gate = _problem(21, 3, 512, 64, 2)
+    big = torch.full((3, 512, 160), -3.0, device=DEV)
+    out = big[:, :, 32:96]
+    spectral_mix(V.to(DEV), gate.to(DEV), None, 512, out=out)
+    torch.cuda.synchronize()
+    assert_close(out.cpu().numpy(), spectral_mix_numpy(V.numpy(), gate.numpy(), None, 512), what="strided out")
+    assert bool((big[:, :, :32] == -3.0).all()) and bool((big[:, :, 96:] == -3.0).all())
