@@ -31,7 +31,16 @@
 //    positions at a time), and the barrier that frees the image sits in front of that stage instead of behind the previous read:
 //    1.62 -> 1.45 ms on one box;
 //  * requests are issued as early and as bunched as the registers allow, and pairs of workgroups walk through adjacent tiles: a
-//    64-byte row segment is half an L2 line, the L2 fetches whole lines, and the neighbour's request a few microseconds later hits.
+//    64-byte row segment is half an L2 line, the L2 fetches whole lines, and the neighbour's request a few microseconds later hits;
+//  * (round 4) STORE BURST.  The L2 takes a half-line store at two thirds of the rate of a whole-line one — unless the two halves of a
+//    line arrive within about a microsecond of each other (tools/store_lab.hip: both halves from one CU back to back 0.66 ms, two
+//    workgroups free-running 0.94 / 0.68, the same two meeting once per tile 0.58, whole lines 0.61 / 0.49).  So in the fp32 kernel every
+//    butterfly of I2's last stage runs first, the eight waves meet at an LDS-only barrier, and all stores of the tile leave back to back
+//    (BURST): the pair's two 192-KiB bursts overlap in time far more often than stores that trickle out between butterflies.  Same
+//    box, interleaved, through the library (tools/burst_ab.py, profiles/r04_burst_ab.log): 1.551 -> 1.480 ms and 1.455 -> 1.392 ms
+//    (-4.0 ... -4.6 %).  Letting the two workgroups of a pair MEET in front of the burst as well (device-scope counter, scalar polling;
+//    tools/p64v.h SYNCP) adds nothing measurable on top in the library (-0.3 ... +0.2 %) and is not shipped; bf16 rows and memory_fft do
+//    not gain from the burst (+-0.3 %, +0.5 %) and keep the round-3 order.
 //
 // Thread <-> data:  lane = (pp = lane & 3, rcl = (lane >> 2) & 3, h = (lane >> 4) & 1, rch = lane >> 5);
 //   sequence p = 2 pp + h, team index u = rcl + 4 rch + 8 wave  (n2 in F1 / I2, k1 in the middle phase);
@@ -162,7 +171,8 @@ template <int SPLIT> constexpr int p64_younger_first() { return 4 * (8 - SPLIT) 
 //         right behind E2 of the previous one, none behind its stores (round 3: the fp32 kernel's late groups cost a memory latency
 //         per tile — same-box ablation: loads only 1.11 ms, stores only 0.90, neither 0.84).
 // OUT_BF16 = bf16 rows out (round to nearest even, like every other kernel here): a lane stores its 4 channels as 8 bytes.
-template <int SPLIT, int PF, bool WITH_MEM = false, bool IN_BF16 = false, bool OUT_BF16 = false>
+// BURST   = the stores of a tile leave back to back behind I2's last butterfly and a workgroup barrier (header comment)
+template <int SPLIT, int PF, bool WITH_MEM = false, bool IN_BF16 = false, bool OUT_BF16 = false, bool BURST = false>
 __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileArgs a) {
   constexpr int ESI = IN_BF16 ? 2 : 4, ESO = OUT_BF16 ? 2 : 4;   // bytes per input / output element
   constexpr float inv_n = 1.0f / 4096.0f;
@@ -531,6 +541,43 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
     p64_stageA1<true>(z);
     {
       const uint32_t ooff = (uint32_t)(((long long)(u + 512 * h) * out_sn + 4 * pp) * ESO);
+      if constexpr (BURST) {
+        static_for<0, 8>([&](auto ic) {
+          constexpr int g = (decltype(ic)::value + SPLIT) % 8;
+          fftA_stage2_group<8, 8, true, g>(z);                            // rows g + 8e at positions 8g + e
+          pin8<8 * g, 1>(z);
+          swap_group(std::integral_constant<int, g>{});
+          __builtin_amdgcn_sched_barrier(0);
+        });
+        p64_barrier();                                  // the eight waves start the burst together
+        static_for<0, 8>([&](auto ic) {
+          constexpr int g = (decltype(ic)::value + SPLIT) % 8;
+          static_for<0, 4>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            const float4 res = make_float4(z[8 * g + 2 * m].x, z[8 * g + 2 * m].y, z[8 * g + 2 * m + 1].x, z[8 * g + 2 * m + 1].y);
+            if constexpr (g >= GP) {
+              if (more) {                            // trade places: results wait for the next quiet part, the prefetched rows move in
+                const float4 nx = dfr[4 * (g - GP) + m];
+                dfr[4 * (g - GP) + m] = res;
+                if constexpr (IN_BF16) {
+                  z[8 * g + 2 * m] = unpack_lo(__float_as_uint(nx.x));
+                  z[8 * g + 2 * m + 1] = unpack_lo(__float_as_uint(nx.y));
+                } else {
+                  z[8 * g + 2 * m] = make_float2(nx.x, nx.y);
+                  z[8 * g + 2 * m + 1] = make_float2(nx.z, nx.w);
+                }
+              } else {
+                store16(rs_out, ooff + (uint32_t)((64 * g + 1024 * m) * out_sn * ESO), res);
+              }
+            } else {
+              store16(rs_out, ooff + (uint32_t)((64 * g + 1024 * m) * out_sn * ESO), res);
+            }
+          });
+          __builtin_amdgcn_sched_barrier(0);
+        });
+        static_for<SPLIT, GP>([&](auto gc) { load_group(rs_next, voff, v_sn, gc); });
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
       static_for<0, 8>([&](auto ic) {
         constexpr int g = (decltype(ic)::value + SPLIT) % 8;             // register-loaded groups first: their reloads start earliest
         fftA_stage2_group<8, 8, true, g>(z);                              // rows g + 8e at positions 8g + e
@@ -561,11 +608,12 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
         __builtin_amdgcn_sched_barrier(0);
       });
     }
+      }
     obp = ob;
     gate_fetch(gpn);     // committed to LDS at the end of the next tile's F1 (after the last tile: a harmless re-read of this tile's bins)
   }  // tile loop
 }
 
-hipError_t launch_regtile64p(const RegtileArgs& a, bool in_bf16, bool out_bf16, hipStream_t stream);
+hipError_t launch_regtile64p(const RegtileArgs& a, bool in_bf16, bool out_bf16, bool burst, hipStream_t stream);
 
 }  // namespace sfft

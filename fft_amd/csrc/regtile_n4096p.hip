@@ -1,10 +1,11 @@
 // n_fft = 4096, persistent software-pipelined kernel (kernel_regtile64p.h)
 #include "kernel_regtile64p.h"
 #include <atomic>
+#include <cstdlib>
 namespace sfft {
-hipError_t launch_regtile64p(const RegtileArgs& a, bool in_bf16, bool out_bf16, hipStream_t stream) {
+hipError_t launch_regtile64p(const RegtileArgs& a, bool in_bf16, bool out_bf16, bool burst, hipStream_t stream) {
   const bool with_mem = a.mem != nullptr;
-  static std::atomic<bool> lds_opt_in[16][4];   // [device]: > 64 KiB of dynamic LDS needs a one-time opt-in (idempotent; the flag only saves the call)
+  static std::atomic<bool> lds_opt_in[16][5];   // [device]: > 64 KiB of dynamic LDS needs a one-time opt-in (idempotent; the flag only saves the call)
   // <SPLIT, PF>: SPLIT row groups of the next tile travel through LDS (LDS-DMA, requested before the stores), PF row groups have their
   // stores / loads moved out of the store/load burst to the end of F1 (16 registers each); the other 8 - SPLIT - PF groups are reloaded
   // behind their own stores.  Interleaved A/B on one box (profiles/r02_p64_ab_waits.log): (4,1) 1.591 ms, (4,2) 1.563, (4,3) 1.548,
@@ -12,13 +13,17 @@ hipError_t launch_regtile64p(const RegtileArgs& a, bool in_bf16, bool out_bf16, 
   // (profiles/r03_p64x_ab_12.log, _13.log): (3,3) 1.595 / 1.457, (4,3) 1.591 / 1.455, (4,2) 1.544 / 1.402, (3,2) 1.609 / 1.464, (4,1) 1.612 / 1.466,
   // (2,3) 1.618 / 1.471 — the round-2 kernel on the same boxes 1.602 / -.  bf16 rows: (8,0) = every load through the image.
   auto kern = spectre_mix_regtile64p<4, 2>;                                           // fp32: 4 groups by LDS-DMA, 2 deferred, 2 behind their stores
+  // round 4: the stores of a tile as one burst behind I2's last butterfly and a workgroup barrier: -4.0 ... -4.6 % for fp32 rows
+  // (profiles/r04_burst_ab.log); bf16 rows +-0.3 %, memory_fft +0.5 %: those keep the round-3 order
+  if (burst && !with_mem && !in_bf16) kern = spectre_mix_regtile64p<4, 2, false, false, false, true>;
   if (with_mem) kern = spectre_mix_regtile64p<4, 1, true>;                            // + memory_fft (spectre.py:548-549)
   // bf16 rows in: a row group is 16 KiB, so up to all eight groups of the next tile fit the image — measured on one box
   // (profiles/r03_p64x_ab_14.log, bf16 -> f32 / bf16 -> bf16): (3,3) 1.476 / 1.329 ms, (4,2) 1.481 / 1.329, (6,2) 1.485 / 1.361,
   // (7,1) 1.509 / 1.383, (6,0) 1.528 / 1.369, (8,0) 1.566 / 1.435: requesting everything early does NOT pay, the deferred stores do
   if (in_bf16) kern = spectre_mix_regtile64p<3, 3, false, true>;
   if (in_bf16 && out_bf16) kern = spectre_mix_regtile64p<3, 3, false, true, true>;
-  const int variant = in_bf16 ? (out_bf16 ? 3 : 2) : with_mem ? 1 : 0;
+
+  const int variant = in_bf16 ? (out_bf16 ? 3 : 2) : with_mem ? 1 : burst ? 4 : 0;
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev < 0 || dev >= 16 || !lds_opt_in[dev][variant]) {

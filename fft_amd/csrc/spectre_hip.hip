@@ -33,7 +33,7 @@ template <> hipError_t launch_regtile<32, 32>(const RegtileArgs&, bool, bool, in
 template <> hipError_t launch_regtile<64, 32>(const RegtileArgs&, bool, bool, int, hipStream_t);
 template <> hipError_t launch_regtile<64, 64>(const RegtileArgs&, bool, bool, int, hipStream_t);
 int probe_copy(const SpectreProbeArgs*, int warmup, int iters, float* ms_per_launch, const char** why);                  // copy_probe.hip
-hipError_t launch_regtile64p(const RegtileArgs&, bool in_bf16, bool out_bf16, hipStream_t);                           // regtile_n4096p.hip (persistent, pipelined)
+hipError_t launch_regtile64p(const RegtileArgs&, bool in_bf16, bool out_bf16, bool burst, hipStream_t);                           // regtile_n4096p.hip (persistent, pipelined)
 template <int RF, int RS> hipError_t launch_regtile_mixedp(const RegtileArgs&, hipStream_t);        // kernel_regtile_mixedp.h (persistent, deferred row blocks)
 template <> hipError_t launch_regtile_mixedp<60, 50>(const RegtileArgs&, hipStream_t);               // regtile_mixedp.hip
 template <> hipError_t launch_regtile_mixedp<64, 40>(const RegtileArgs&, hipStream_t);
@@ -152,7 +152,7 @@ const char* tuning_env(const char* name) {
 }
 std::string tuning_overrides() {
   std::string r;
-  for (const char* n : {"SPECTRE_P64", "SPECTRE_P64_BF16", "SPECTRE_WIDE", "SPECTRE_WIDE_MAX", "SPECTRE_WIDE_NT", "SPECTRE_MIXEDP", "SPECTRE_STOCKHAM_PMAX", "SPECTRE_TPW", "SPECTRE_P64_TPW", "SPECTRE_GATE_GRAD"})
+  for (const char* n : {"SPECTRE_P64", "SPECTRE_P64_BF16", "SPECTRE_P64_BURST", "SPECTRE_WIDE", "SPECTRE_WIDE_MAX", "SPECTRE_WIDE_NT", "SPECTRE_MIXEDP", "SPECTRE_STOCKHAM_PMAX", "SPECTRE_TPW", "SPECTRE_P64_TPW", "SPECTRE_GATE_GRAD"})
     if (const char* e = tuning_env(n)) r += std::string(r.empty() ? "" : " ") + n + "=" + e;
   return r;
 }
@@ -497,7 +497,9 @@ int launch(const SpectreMixArgs* a, const Plan* plan, const Choice& c, bool conj
       const int slots = std::max(gang, ncu / gang * gang);
       k.tpw = forced > 0 ? forced : std::max(1, (k.n_tiles + slots - 1) / slots);
       k.n_wg = gang * ((k.n_tiles + gang * k.tpw - 1) / (gang * k.tpw));
-      e = sfft::launch_regtile64p(k, ib, ob, stream);
+      // round 4: store burst behind a workgroup barrier (fp32 rows).  SPECTRE_P64_BURST=0: the round-3 order of stores (tuning aid)
+      static const bool burst_off = [] { const char* e2 = tuning_env("SPECTRE_P64_BURST"); return e2 && atoi(e2) == 0; }();
+      e = sfft::launch_regtile64p(k, ib, ob, !burst_off, stream);
     } else if (c.mixedp) {   // one workgroup per CU, pairs of workgroups on adjacent tiles (kernel_regtile_mixedp.h)
       const int ncu = cu_count(a->device);
       const int slots = std::max(2, ncu / 2 * 2);

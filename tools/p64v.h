@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
           unsigned val;
           asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(val) : "s"(cp) : "memory");
           if (val >= (unsigned)GANG * nsync) break;
-          __builtin_amdgcn_s_sleep(2);
+          if constexpr (SYNCP != 7) __builtin_amdgcn_s_sleep(2);
         }
         if (i == 128) sync_on = false;
       }
@@ -440,7 +440,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
     __builtin_amdgcn_sched_barrier(0);
     // ---- the quiet part of the tile starts: the deferred results of the previous tile leave, the same row groups of the next tile
     //      are requested into the registers they vacate
-    if constexpr (SYNCP == 2) gang_meet();
+    if constexpr (SYNCP == 2 || SYNCP == 5) gang_meet();
     static_for<0, 4 * PF>([&](auto ic) { pf_store(ic); });
     static_for<0, 4 * PF>([&](auto ic) { pf_load(ic); });
     __builtin_amdgcn_sched_barrier(0);
@@ -517,7 +517,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
     // ---- E2: position n2 -> image row n2, column (p, k1 = u); thread (p, u) reads row u, slot k1.  The barrier behind the last read
     //      frees the image for the LDS-DMA below.
     p64v_exchange_rest<true>(z, img, p, u);
-    if constexpr (SYNCP == 1) gang_meet();
+    if constexpr (SYNCP == 1 || SYNCP == 6) gang_meet();
 
     // ---- the image is idle until the next F1: let the first row groups of the next tile land in it, and fetch its gate -----
     const uint32_t voff = (uint32_t)(((long long)(u + 512 * h) * v_sn + 4 * pp) * ESI);
@@ -560,6 +560,41 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
     asm volatile("" ::: "memory");
     {
       const uint32_t ooff = (uint32_t)(((long long)(u + 512 * h) * out_sn + 4 * pp) * ESO);
+      if constexpr (SYNCP >= 3) {
+        // store BURST: every butterfly of I2's last stage first, then (SYNCP 3: the gang meets) all stores back to back, then the reloads —
+        // the two workgroups of a pair put both halves of every line into the L2 within a couple of microseconds (tools/store_lab.hip: halves
+        // that arrive within ~1 us of each other cost what a whole line costs)
+        static_for<0, 8>([&](auto ic) {
+          constexpr int g = (decltype(ic)::value + SPLIT) % 8;
+          fftA_stage2_group<8, 8, true, g>(z);
+          vpin8<8 * g, 1>(z);
+          swap_group(std::integral_constant<int, g>{});
+          __builtin_amdgcn_sched_barrier(0);
+        });
+        if constexpr (SYNCP == 3 || SYNCP == 5 || SYNCP == 7) gang_meet();
+        static_for<0, 8>([&](auto ic) {
+          constexpr int g = (decltype(ic)::value + SPLIT) % 8;
+          static_for<0, 4>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            const float4 res = make_float4(z[8 * g + 2 * m].x, z[8 * g + 2 * m].y, z[8 * g + 2 * m + 1].x, z[8 * g + 2 * m + 1].y);
+            if constexpr (g >= GP) {
+              if (more) {
+                const float4 nx = dfr[4 * (g - GP) + m];
+                dfr[4 * (g - GP) + m] = res;
+                z[8 * g + 2 * m] = make_float2(nx.x, nx.y);
+                z[8 * g + 2 * m + 1] = make_float2(nx.z, nx.w);
+              } else {
+                store16(rs_out, ooff + (uint32_t)((64 * g + 1024 * m) * out_sn * ESO), res);
+              }
+            } else {
+              store16(rs_out, ooff + (uint32_t)((64 * g + 1024 * m) * out_sn * ESO), res);
+            }
+          });
+          __builtin_amdgcn_sched_barrier(0);
+        });
+        static_for<SPLIT, GP>([&](auto gc) { load_group(rs_next, voff, v_sn, gc); });
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
       static_for<0, 8>([&](auto ic) {
         constexpr int g = (decltype(ic)::value + SPLIT) % 8;             // register-loaded groups first: their reloads start earliest
         fftA_stage2_group<8, 8, true, g>(z);                              // rows g + 8e at positions 8g + e
@@ -590,6 +625,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
         __builtin_amdgcn_sched_barrier(0);
       });
     }
+      }
     obp = ob;
     gate_fetch(gpn);     // committed to LDS at the end of the next tile's F1 (after the last tile: a harmless re-read of this tile's bins)
   }  // tile loop
