@@ -38,7 +38,12 @@
 //    butterfly of I2's last stage runs first, the eight waves meet at an LDS-only barrier, and all stores of the tile leave back to back
 //    (BURST): the pair's two 192-KiB bursts overlap in time far more often than stores that trickle out between butterflies.  Same
 //    box, interleaved, through the library (tools/burst_ab.py, profiles/r04_burst_ab.log): 1.551 -> 1.480 ms and 1.455 -> 1.392 ms
-//    (-4.0 ... -4.6 %).  Letting the two workgroups of a pair MEET in front of the burst as well (device-scope counter, scalar polling;
+//    (-4.0 ... -4.6 %).  PHASED I/O on top: one more LDS-only barrier between the burst and the reloads behind it, and one between the
+//    deferred stores and the deferred loads of the quiet part, so that a CU's eight waves never mix the two directions inside a burst:
+//    -6.3 ... -6.5 % in all against the round-3 order (tools/p64v_bench.hip batches 10-12: burst alone -2.2 %, barrier alone -0.7 %,
+//    barrier + burst -4.0 ... -4.6 %, + barrier in front of the reloads -5.4 ... -6.0 %, + barrier between the deferred stores and loads
+//    -6.3 ... -6.4 %; a barrier in front of the deferred stores or of the gate fetch, the LDS-DMA requests moved in front of the burst,
+//    an s_sleep between burst and reloads, other (SPLIT, PF): all worse).  Letting the two workgroups of a pair MEET in front of the burst as well (device-scope counter, scalar polling;
 //    tools/p64v.h SYNCP) adds nothing measurable on top in the library (-0.3 ... +0.2 %) and is not shipped; bf16 rows and memory_fft do
 //    not gain from the burst (+-0.3 %, +0.5 %) and keep the round-3 order.
 //
@@ -444,6 +449,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
     // ---- the quiet part of the tile starts: the deferred results of the previous tile leave, the same row groups of the next tile
     //      are requested into the registers they vacate
     static_for<0, 4 * PF>([&](auto ic) { pf_store(ic); });
+    if constexpr (BURST) p64_barrier();            // PHASED I/O: every wave has issued its deferred stores before any wave requests the next rows
     static_for<0, 4 * PF>([&](auto ic) { pf_load(ic); });
     __builtin_amdgcn_sched_barrier(0);
     // ---- E1: position k1 -> image row k1, column (p, u); thread (p, s = u) reads row u, slot n2.  No barrier behind the last read:
@@ -575,6 +581,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
           });
           __builtin_amdgcn_sched_barrier(0);
         });
+        p64_barrier();                                  // ... and the reloads start when every wave's stores are out
         static_for<SPLIT, GP>([&](auto gc) { load_group(rs_next, voff, v_sn, gc); });
         __builtin_amdgcn_sched_barrier(0);
       } else {

@@ -441,7 +441,9 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
     // ---- the quiet part of the tile starts: the deferred results of the previous tile leave, the same row groups of the next tile
     //      are requested into the registers they vacate
     if constexpr (SYNCP == 2 || SYNCP == 5) gang_meet();
+    if constexpr (SYNCP == 13) p64v_barrier();
     static_for<0, 4 * PF>([&](auto ic) { pf_store(ic); });
+    if constexpr (SYNCP == 12 || SYNCP == 13 || SYNCP >= 15) p64v_barrier();
     static_for<0, 4 * PF>([&](auto ic) { pf_load(ic); });
     __builtin_amdgcn_sched_barrier(0);
     // ---- E1: position k1 -> image row k1, column (p, u); thread (p, s = u) reads row u, slot n2.  No barrier behind the last read:
@@ -535,7 +537,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
                                                voff + (uint32_t)((64 * g + 1024 * m) * v_sn * 4), 0, 0, AUXD);
     };
     constexpr int NDMA = 4 * SPLIT, NSLOT = DSPREAD == 2 ? 16 : 8;
-    if constexpr (DSPREAD == 0) static_for<0, SPLIT>([&](auto gc) { dma_group(rs_next, dma_voff(voff, v_sn), v_sn, gc); });
+    if constexpr (DSPREAD == 0 && SYNCP != 10) static_for<0, SPLIT>([&](auto gc) { dma_group(rs_next, dma_voff(voff, v_sn), v_sn, gc); });
     asm volatile("" ::: "memory");                 // the vmcnt() at the top of the loop counts on these being older than every store below
 
     // ---- conj twiddle, I2, stores (spectre.py:553) interleaved with the loads that refill the released registers -----------
@@ -560,7 +562,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
     asm volatile("" ::: "memory");
     {
       const uint32_t ooff = (uint32_t)(((long long)(u + 512 * h) * out_sn + 4 * pp) * ESO);
-      if constexpr (SYNCP >= 3) {
+      if constexpr (SYNCP >= 3 && SYNCP != 8) {
         // store BURST: every butterfly of I2's last stage first, then (SYNCP 3: the gang meets) all stores back to back, then the reloads —
         // the two workgroups of a pair put both halves of every line into the L2 within a couple of microseconds (tools/store_lab.hip: halves
         // that arrive within ~1 us of each other cost what a whole line costs)
@@ -572,6 +574,8 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
           __builtin_amdgcn_sched_barrier(0);
         });
         if constexpr (SYNCP == 3 || SYNCP == 5 || SYNCP == 7) gang_meet();
+        if constexpr (SYNCP >= 9) p64v_barrier();
+        if constexpr (SYNCP == 10) static_for<0, NDMA>([&](auto qc) { dma_one(qc); });
         static_for<0, 8>([&](auto ic) {
           constexpr int g = (decltype(ic)::value + SPLIT) % 8;
           static_for<0, 4>([&](auto mc) {
@@ -592,9 +596,13 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
           });
           __builtin_amdgcn_sched_barrier(0);
         });
+        if constexpr (SYNCP >= 11) p64v_barrier();
+        if constexpr (SYNCP == 15) __builtin_amdgcn_s_sleep(4);
+        if constexpr (SYNCP == 16) __builtin_amdgcn_s_sleep(16);
         static_for<SPLIT, GP>([&](auto gc) { load_group(rs_next, voff, v_sn, gc); });
         __builtin_amdgcn_sched_barrier(0);
       } else {
+      if constexpr (SYNCP == 8) p64v_barrier();
       static_for<0, 8>([&](auto ic) {
         constexpr int g = (decltype(ic)::value + SPLIT) % 8;             // register-loaded groups first: their reloads start earliest
         fftA_stage2_group<8, 8, true, g>(z);                              // rows g + 8e at positions 8g + e
@@ -627,6 +635,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
     }
       }
     obp = ob;
+    if constexpr (SYNCP == 14) p64v_barrier();
     gate_fetch(gpn);     // committed to LDS at the end of the next tile's F1 (after the last tile: a harmless re-read of this tile's bins)
   }  // tile loop
 }
