@@ -104,7 +104,10 @@ __device__ __forceinline__ void p64_stageA1(float2 (&z)[64]) {      // type A st
 // requested by LDS-DMA, after its own vmcnt wait), so the LDS counter is all a barrier has to wait for.
 __device__ __forceinline__ void p64_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <bool IN_BF16> constexpr int kP64Gang = IN_BF16 ? 4 : 2;   // workgroups per 128-byte line (launch: n_wg is a multiple of it)
+// workgroups that walk through adjacent tiles in step (launch: n_wg is a multiple of it): the 2 that share a 128-byte line of fp32 rows,
+// the 4 that share a line of bf16 rows.  bf16 rows in / fp32 rows out with the round-4 phased I/O: 2 — the pair that matters is the one
+// whose half-line STORES meet (gang 4: 1.466 ms, gang 2: 1.435 on one box; profiles/r04_p64v_bf16_in_ab.log)
+constexpr int p64_gang(bool in_bf16, bool out_bf16, bool burst) { return (in_bf16 && out_bf16) || (in_bf16 && !burst) || (out_bf16 && !in_bf16) ? 4 : 2; }
 
 // One exchange = position j of thread (p, u) -> image row j, column (p, u); thread (p, u) then reads row u, slots 0..63.  One float
 // plane at a time (the tile is 256 KiB, the image 136 KiB).  The scattered dword writes are ds_write2st64_b32 (the LDS takes a store's
@@ -221,7 +224,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
 
   // GANG neighbouring workgroups (same L2) walk through GANG adjacent tiles in step = one 128-byte line per row: the L2 fetches a
   // line once and the neighbours' requests hit (fp32: two 64-byte halves; bf16: four 32-byte quarters)
-  constexpr int GANG = kP64Gang<(IN_BF16 || OUT_BF16)>;
+  constexpr int GANG = p64_gang(IN_BF16, OUT_BF16, BURST);
   const int wg_lin = xcd_contiguous(blockIdx.x, a.n_wg);
   const int pair_base = (wg_lin / GANG) * a.tpw * GANG + (wg_lin % GANG);
   if (pair_base >= a.n_tiles) return;

@@ -585,8 +585,13 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
               if (more) {
                 const float4 nx = dfr[4 * (g - GP) + m];
                 dfr[4 * (g - GP) + m] = res;
-                z[8 * g + 2 * m] = make_float2(nx.x, nx.y);
-                z[8 * g + 2 * m + 1] = make_float2(nx.z, nx.w);
+                if constexpr (IN_BF16) {
+                  z[8 * g + 2 * m] = unpack_lo(__float_as_uint(nx.x));
+                  z[8 * g + 2 * m + 1] = unpack_lo(__float_as_uint(nx.y));
+                } else {
+                  z[8 * g + 2 * m] = make_float2(nx.x, nx.y);
+                  z[8 * g + 2 * m + 1] = make_float2(nx.z, nx.w);
+                }
               } else {
                 store16(rs_out, ooff + (uint32_t)((64 * g + 1024 * m) * out_sn * ESO), res);
               }

@@ -17,6 +17,10 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 using namespace sfft;
 
+__global__ void to_bf16(const float* src, uint16_t* dst, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = (uint16_t)sfft::f32_to_bf16_rne(src[i]);
+}
+
 struct Variant { std::string name; std::function<void()> launch; std::vector<float> ms; };
 
 template <class K> std::function<void()> mk(K kern, RegtileArgs a, int gang, int lds = kV64LdsTotal) {
@@ -54,16 +58,27 @@ int main(int argc, char** argv) {
   unsigned* cnt_buf; CK(hipMalloc(&cnt_buf, 4096)); CK(hipMemset(cnt_buf, 0, 4096));
   RegtileArgs ls = la; ls.mem = reinterpret_cast<const float*>(cnt_buf);      // SYNCP variants: a.mem carries the gang counters
   auto synced = [&](std::function<void()> f) { return std::function<void()>([=] { CK(hipMemsetAsync(cnt_buf, 0, 4096, 0)); f(); }); };
+  // bf16 rows in: the same values rounded to bf16 (device-side conversion)
+  uint16_t* vb16; CK(hipMalloc(&vb16, (size_t)B * N * D * 2));
+  hipLaunchKernelGGL(to_bf16, dim3(4096), dim3(256), 0, 0, v, vb16, (size_t)B * N * D);
+  CK(hipDeviceSynchronize());
+  RegtileArgs lb = la; lb.v = vb16;
+  const bool bf = argc > 3 && !strcmp(argv[3], "bf16");
   std::vector<Variant> vs;
   auto add = [&](const char* name, std::function<void()> f) { if (strstr(name, filter)) vs.push_back({name, f, {}}); };
-  add("LIBRARY <4,2>", mk(spectre_mix_regtile64p<4, 2>, la, 2, kP64LdsTotal));
-  add("copy    <4,2> (must equal the library)", mk(spectre_mix_p64v<4, 2>, la, 2));
+  if (!bf) {
+    add("LIBRARY <4,2>", mk(spectre_mix_regtile64p<4, 2>, la, 2, kP64LdsTotal));
+    add("copy    <4,2> (must equal the library)", mk(spectre_mix_p64v<4, 2>, la, 2));
 #include "p64v_variants.inc"
+  } else {
+    add("LIBRARY <3,3> bf16 rows in, fp32 out", mk(spectre_mix_regtile64p<3, 3, false, true>, lb, 4, kP64LdsTotal));
+#include "p64v_variants_bf16.inc"
+  }
 
   // ---- correctness against the library kernel
   {
-    RegtileArgs r = la; r.out = out_ref;
-    mk(spectre_mix_regtile64p<4, 2>, r, 2, kP64LdsTotal)();
+    RegtileArgs r = bf ? lb : la; r.out = out_ref;
+    if (bf) mk(spectre_mix_regtile64p<3, 3, false, true>, r, 4, kP64LdsTotal)(); else mk(spectre_mix_regtile64p<4, 2>, r, 2, kP64LdsTotal)();
     CK(hipDeviceSynchronize());
     std::vector<float> ho((size_t)N * D), hr((size_t)N * D);
     for (auto& x : vs) {
