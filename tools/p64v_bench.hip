@@ -63,22 +63,28 @@ int main(int argc, char** argv) {
   hipLaunchKernelGGL(to_bf16, dim3(4096), dim3(256), 0, 0, v, vb16, (size_t)B * N * D);
   CK(hipDeviceSynchronize());
   RegtileArgs lb = la; lb.v = vb16;
-  const bool bf = argc > 3 && !strcmp(argv[3], "bf16");
+  const bool bfo = argc > 3 && !strcmp(argv[3], "bf16out");      // bf16 rows in AND out
+  const bool bf = (argc > 3 && !strcmp(argv[3], "bf16")) || bfo;
   std::vector<Variant> vs;
   auto add = [&](const char* name, std::function<void()> f) { if (strstr(name, filter)) vs.push_back({name, f, {}}); };
   if (!bf) {
     add("LIBRARY <4,2>", mk(spectre_mix_regtile64p<4, 2>, la, 2, kP64LdsTotal));
     add("copy    <4,2> (must equal the library)", mk(spectre_mix_p64v<4, 2>, la, 2));
 #include "p64v_variants.inc"
-  } else {
+  } else if (!bfo) {
     add("LIBRARY <3,3> bf16 rows in, fp32 out", mk(spectre_mix_regtile64p<3, 3, false, true>, lb, 4, kP64LdsTotal));
 #include "p64v_variants_bf16.inc"
+  } else {
+    add("LIBRARY <3,3> bf16 rows in and out", mk(spectre_mix_regtile64p<3, 3, false, true, true>, lb, 4, kP64LdsTotal));
+#include "p64v_variants_bf16out.inc"
   }
 
   // ---- correctness against the library kernel
   {
     RegtileArgs r = bf ? lb : la; r.out = out_ref;
-    if (bf) mk(spectre_mix_regtile64p<3, 3, false, true>, r, 4, kP64LdsTotal)(); else mk(spectre_mix_regtile64p<4, 2>, r, 2, kP64LdsTotal)();
+    CK(hipMemset(out_ref, 0xff, (size_t)B * N * D * 4));
+    if (bfo) mk(spectre_mix_regtile64p<3, 3, false, true, true>, r, 4, kP64LdsTotal)();
+    else if (bf) mk(spectre_mix_regtile64p<3, 3, false, true>, r, 4, kP64LdsTotal)(); else mk(spectre_mix_regtile64p<4, 2>, r, 2, kP64LdsTotal)();
     CK(hipDeviceSynchronize());
     std::vector<float> ho((size_t)N * D), hr((size_t)N * D);
     for (auto& x : vs) {
@@ -88,7 +94,8 @@ int main(int argc, char** argv) {
       for (int b : {0, 97, 255}) {
         CK(hipMemcpy(ho.data(), out + (size_t)b * N * D, (size_t)N * D * 4, hipMemcpyDeviceToHost));
         CK(hipMemcpy(hr.data(), out_ref + (size_t)b * N * D, (size_t)N * D * 4, hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < (size_t)N * D; ++i) { const double d = std::fabs((double)ho[i] - hr[i]); if (!(d <= worst)) worst = d; if (!(d < 1e-4)) ++bad; }
+        if (bfo) { for (size_t i = 0; i < (size_t)N * D; ++i) { uint32_t x, y; memcpy(&x, &ho[i], 4); memcpy(&y, &hr[i], 4); if (x != y) { ++bad; worst = 1; } } }
+        else for (size_t i = 0; i < (size_t)N * D; ++i) { const double d = std::fabs((double)ho[i] - hr[i]); if (!(d <= worst)) worst = d; if (!(d < 1e-4)) ++bad; }
       }
       printf("check %-56s max |diff| vs library %.3e, elements off by > 1e-4: %zu\n", x.name.c_str(), worst, bad);
     }
