@@ -14,6 +14,6 @@ ref = spectral_mix(V[:1], g[:1], None, N, algo="stockham")
 print("MS %%.4f %%.4f %%.4f  maxdiff %%.1e" %% (ms[0], ms[1], ms[2], float((out[:1] - ref).abs().max())))
 ''' % ROOT
 for r in range(3):
-    for bar in ("0", "1", "2", "3"):
+    for bar in ("0", "4", "8", "12"):
         out = subprocess.run([sys.executable, "-c", CHILD], env=dict(os.environ, SPECTRE_TUNING="1", SPECTRE_MIXEDP_BAR=bar), capture_output=True, text=True)
         print("bar=" + bar, [l for l in out.stdout.splitlines() if l.startswith("MS")], out.stderr[-400:] if out.returncode else "")
