@@ -41,6 +41,7 @@ __device__ __forceinline__ void vpin8(float2 (&z)[64]) {
                     "+v"(z[BASE + 6 * STRIDE].x), "+v"(z[BASE + 6 * STRIDE].y), "+v"(z[BASE + 7 * STRIDE].x), "+v"(z[BASE + 7 * STRIDE].y));
 }
 
+__device__ __forceinline__ void vpin4(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
 template <bool INV, class CB>
 __device__ __forceinline__ void p64v_stageA1_cb(float2 (&z)[64], CB cb) {
   static_for<0, 8>([&](auto q0c) {
@@ -140,7 +141,7 @@ template <int SPLIT> constexpr int p64v_younger_first() { return 4 * (8 - SPLIT)
 //         right behind E2 of the previous one, none behind its stores (round 3: the fp32 kernel's late groups cost a memory latency
 //         per tile — same-box ablation: loads only 1.11 ms, stores only 0.90, neither 0.84).
 // OUT_BF16 = bf16 rows out (round to nearest even, like every other kernel here): a lane stores its 4 channels as 8 bytes.
-template <int SPLIT, int PF, bool WITH_MEM = false, bool IN_BF16 = false, bool OUT_BF16 = false, int GANGX = 0, int AUXD = 0, int AUXL = 0, int AUXS = 0, int PRIO = 0, int MAPX = 0, int DSPREAD = 0, int SYNCP = 0>
+template <int SPLIT, int PF, bool WITH_MEM = false, bool IN_BF16 = false, bool OUT_BF16 = false, int GANGX = 0, int AUXD = 0, int AUXL = 0, int AUXS = 0, int PRIO = 0, int MAPX = 0, int DSPREAD = 0, int SYNCP = 0, int TSTAMP = 0, int PFL2 = 0, int STAG = 0>
 __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) {
   constexpr int ESI = IN_BF16 ? 2 : 4, ESO = OUT_BF16 ? 2 : 4;   // bytes per input / output element
   constexpr float inv_n = 1.0f / 4096.0f;
@@ -191,9 +192,35 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
   // MAPX = 1: compact window — iteration `it` of the whole grid covers tiles [it * n_wg, (it + 1) * n_wg)
   // MAPX = 2: compact window with neighbouring PAIRS on different XCDs (the two workgroups of a pair, blocks b and b + 8, share one)
   const int bx = blockIdx.x;
-  const int pair_base = MAPX == 2 ? ((bx / 16) * 8 + bx % 8) * 2 + (bx / 8) % 2 : MAPX ? wg_lin : (wg_lin / GANG) * a.tpw * GANG + (wg_lin % GANG);
+  // MAPX = 3: DYNAMIC tickets, one counter per XCD (a.mem = counters, 16 words apart, zeroed before the launch): XCD x owns tiles
+  // [x * n_tiles / 8, (x + 1) * n_tiles / 8) and its workgroups take them in order, one ticket per tile, drawn a tile and a half ahead by wave 0
+  // with a SCALAR atomic (lgkmcnt, not the in-order vmcnt) and handed to the other waves through one LDS word behind the tile's barriers.
+  // Adjacent tickets = the two halves of a line go to the two workgroups of the XCD that arrive next to each other in time.
+  [[maybe_unused]] const int per_xcd = a.n_tiles / 8, xcd_base = (bx % 8) * per_xcd;
+  [[maybe_unused]] unsigned* tick_cnt = reinterpret_cast<unsigned*>(const_cast<float*>(a.mem)) + 16 * (bx % 8);
+  [[maybe_unused]] volatile unsigned* tick_lds = reinterpret_cast<volatile unsigned*>(smem + kV64LdsTotal);
+  [[maybe_unused]] int cur_t = 0, nxt_t = 0;
+  [[maybe_unused]] unsigned long long t_start = 0;
+  if constexpr (TSTAMP) t_start = __builtin_amdgcn_s_memrealtime();
+  [[maybe_unused]] unsigned long long c_start = 0;
+  if constexpr (TSTAMP) c_start = __builtin_readcyclecounter();
+  // TSTAMP = 2: wave 0 adds up, over its tiles, the time between phase marks (s_memrealtime, 100 MHz; every mark waits for lgkmcnt(0))
+  [[maybe_unused]] unsigned long long ph_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ph_last = 0;
+  [[maybe_unused]] auto mark = [&](int k) {
+    if constexpr (TSTAMP == 2) {
+      const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+      ph_acc[k] += t - ph_last; ph_last = t;
+    }
+  };
+  if constexpr (MAPX == 3) {
+    if (tid0 == 0) { tick_lds[0] = atomicAdd(tick_cnt, 1u); tick_lds[1] = atomicAdd(tick_cnt, 1u); }
+    __syncthreads();
+    cur_t = __builtin_amdgcn_readfirstlane((int)tick_lds[0]); nxt_t = __builtin_amdgcn_readfirstlane((int)tick_lds[1]);
+    __syncthreads();
+  }
+  const int pair_base = MAPX == 3 ? xcd_base + cur_t : MAPX == 2 ? ((bx / 16) * 8 + bx % 8) * 2 + (bx / 8) % 2 : MAPX ? wg_lin : (wg_lin / GANG) * a.tpw * GANG + (wg_lin % GANG);
   const int TS = MAPX ? a.n_wg : GANG;
-  if (pair_base >= a.n_tiles) return;
+  if (MAPX == 3 ? cur_t >= per_xcd : pair_base >= a.n_tiles) return;
   // SYNCP: wave 0 announces the workgroup (one atomic add, no return value: older than every request the hand-counted waits look at) and
   // polls the gang's counter with SCALAR loads (lgkmcnt, not the in-order vmcnt the stores sit in); the other waves wait at a barrier.
   // Performance only: the spin is bounded, and a gang whose partner never shows up stops waiting after the first time-out.
@@ -361,18 +388,34 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
     gate_fetch(gp);
   }
 
-  for (int it = 0; it < a.tpw; ++it) {
-    const int tile = pair_base + TS * it;
-    if (tile >= a.n_tiles) break;                  // workgroup-uniform
-    const bool more = (it + 1 < a.tpw) && (tile + TS < a.n_tiles);
+  for (int it = 0; MAPX == 3 || it < a.tpw; ++it) {
+    const int tile = MAPX == 3 ? xcd_base + cur_t : pair_base + TS * it;
+    if (MAPX == 3 ? cur_t >= per_xcd : tile >= a.n_tiles) break;                  // workgroup-uniform
+    const bool more = MAPX == 3 ? nxt_t < per_xcd : (it + 1 < a.tpw) && (tile + TS < a.n_tiles);
     coords();
+    if constexpr (TSTAMP == 2) { if (it == 0) ph_last = __builtin_amdgcn_s_memrealtime(); }
+    mark(0);                                       // (gate fetch of the previous iteration .. here)
+    [[maybe_unused]] unsigned fut = 1;
+    if constexpr (MAPX == 3) {                     // the ticket of the tile after next: requested now, in the LDS word behind F1's barrier
+      if (__builtin_amdgcn_readfirstlane(tid0 >> 6) == 0) asm volatile("s_atomic_add %0, %1, 0x0 glc" : "+s"(fut) : "s"(tick_cnt) : "memory");
+    }
     long long v_sn = a.v_sn, out_sn = a.out_sn;
     asm volatile("" : "+s"(v_sn), "+s"(out_sn));
     const char* vb; char* ob; const float2* gp;
     tile_ptrs(tile, vb, ob, gp);
     const char* vbn = vb; char* obn = ob; const float2* gpn = gp;
-    if (more) tile_ptrs(tile + TS, vbn, obn, gpn);
+    if (more) tile_ptrs(MAPX == 3 ? xcd_base + nxt_t : tile + TS, vbn, obn, gpn);
     const __amdgpu_buffer_rsrc_t rs_next = rsrc_in(vbn, v_sn, more), rs_out = rsrc_out(ob, out_sn);
+    // PFL2: touch the half lines of the row groups that will be RELOADED behind this tile's stores (one dword per row, LDS-DMA into a dump
+    // word area: no register, tracked by vmcnt like every other request) so that the reloads find their lines in the L2.  Wave w covers the
+    // 64 rows of its (h, m) = (w & 1, w >> 1) per group.  1 = right in front of the LDS-DMA burst, 2 = in the quiet part behind the deferred loads,
+    // 3 = both row-group sets (also the LDS-staged groups) in the quiet part
+    [[maybe_unused]] auto l2_touch = [&](auto gc) {
+      constexpr int g = decltype(gc)::value;
+      const int w = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+      const uint32_t off = (uint32_t)((long long)(64 * g + lane + 512 * (w & 1) + 1024 * (w >> 1)) * v_sn * ESI);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_next, (__attribute__((address_space(3))) void*)(smem + kV64LdsTotal + 16), 4, off, 0, 0, 0);
+    };
 
     [[maybe_unused]] const uint32_t pf_ooff = (uint32_t)(((long long)(u + 512 * h) * out_sn + 4 * pp) * ESO);
     [[maybe_unused]] const uint32_t pf_voff = (uint32_t)(((long long)(u + 512 * h) * v_sn + 4 * pp) * ESI);
@@ -403,13 +446,16 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
         // staged groups are in the slots (p64v_younger; checked against the ISA by tools/isa_lint.py)
         if (it == 0) asm volatile("s_waitcnt vmcnt(%0) ; lint: first" :: "n"(p64v_younger_first<SPLIT>()) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0) ; lint: steady" :: "n"(p64v_younger<SPLIT, PF>()) : "memory");
+        mark(1);                                   // stage 1 of the deferred groups, wait for the LDS-DMA
         static_for<0, SPLIT>([&](auto gc) { read_group(gc); });
       }
+      if constexpr (i == PF + SPLIT && TSTAMP == 2) { vpin8<8 * ((PF + SPLIT - 1) < PF ? GP + PF + SPLIT - 1 : SPLIT - 1), 1>(z); mark(2); }   // staged groups read + stage 1
       swap_group(std::integral_constant<int, g>{});
       bfly_plain<8, false, 8 * g, 1, 64>(z);       // over e -> ka at position 8g + ka (W_64^(g ka) is applied by the column butterflies below)
       vpin8<8 * g, 1>(z);
       __builtin_amdgcn_sched_barrier(0);
     });
+    if constexpr (TSTAMP == 2) { vpin8<8 * (GP - 1), 1>(z); mark(3); }   // wait for the reloaded groups + their stage 1
     {
       float2 wa[8], wb[8];
       __builtin_amdgcn_sched_barrier(0);           // keep the base loads (and their registers) out of stage 1
@@ -428,6 +474,9 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (ka == 0) p64v_barrier();      // every wave has emptied its landing slots (and finished E2's reads of the previous
                                                    // tile): the image may be written
+        if constexpr (ka == 0 && MAPX == 3) {       // (the barrier waited for lgkmcnt(0): the scalar atomic has returned)
+          if (__builtin_amdgcn_readfirstlane(tid0 >> 6) == 0) { asm volatile("" : "+s"(fut)); if (lane == 0) tick_lds[0] = fut; }
+        }
         p64v_write_col<ka, false>(z, img, p, u);
         __builtin_amdgcn_sched_barrier(0);
       });
@@ -436,8 +485,10 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
     // for every store of that tile to be acknowledged: as late as possible (the bins are first read after E1's barriers) — but BEFORE
     // the deferred requests below: hipcc waits for registers that were loaded before the loop's back edge with vmcnt(0), which behind
     // those requests would mean a full HBM round trip at the end of every F1.
+    mark(4);                                       // F1 stage 2 + twiddles + first barrier + real-plane writes
     gate_commit();
     __builtin_amdgcn_sched_barrier(0);
+    mark(5);                                       // gate commit (waits for the gate loads = for the previous tile's stores)
     // ---- the quiet part of the tile starts: the deferred results of the previous tile leave, the same row groups of the next tile
     //      are requested into the registers they vacate
     if constexpr (SYNCP == 2 || SYNCP == 5) gang_meet();
@@ -445,6 +496,17 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
     static_for<0, 4 * PF>([&](auto ic) { pf_store(ic); });
     if constexpr (SYNCP == 12 || SYNCP == 13 || SYNCP >= 15) p64v_barrier();
     static_for<0, 4 * PF>([&](auto ic) { pf_load(ic); });
+    // (in the quiet part the touch is a plain dword load into a register that is looked at once, behind E2: an LDS-DMA here would put a
+    //  vmcnt(0) in front of the exchange's LDS reads)
+    [[maybe_unused]] uint32_t tch[8];
+    [[maybe_unused]] auto l2_touch_reg = [&](auto gc) {
+      constexpr int g = decltype(gc)::value;
+      const int w = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+      const uint32_t off = (uint32_t)((long long)(64 * g + lane + 512 * (w & 1) + 1024 * (w >> 1)) * v_sn * ESI);
+      tch[g] = __builtin_amdgcn_raw_buffer_load_b32(rs_next, off, 0, 0);
+    };
+    if constexpr (PFL2 == 2) static_for<SPLIT, GP>([&](auto gc) { l2_touch_reg(gc); });
+    if constexpr (PFL2 == 3) static_for<0, GP>([&](auto gc) { l2_touch_reg(gc); });
     __builtin_amdgcn_sched_barrier(0);
     // ---- E1: position k1 -> image row k1, column (p, u); thread (p, s = u) reads row u, slot n2.  No barrier behind the last read:
     //      the image stays busy until the barrier in front of the middle phase's last stage.
@@ -519,6 +581,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
     // ---- E2: position n2 -> image row n2, column (p, k1 = u); thread (p, u) reads row u, slot k1.  The barrier behind the last read
     //      frees the image for the LDS-DMA below.
     p64v_exchange_rest<true>(z, img, p, u);
+    mark(6);                                       // deferred stores / loads issue, E1, middle, E2
     if constexpr (SYNCP == 1 || SYNCP == 6) gang_meet();
 
     // ---- the image is idle until the next F1: let the first row groups of the next tile land in it, and fetch its gate -----
@@ -527,6 +590,8 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
     //  s_waitcnt vmcnt(0) — the whole HBM round trip of the requests below, at the start of every burst)
     float2 wa[8], wb[8];
     load_twiddles(wa, wb, u);
+    [[maybe_unused]] int fut_t = 0;
+    if constexpr (MAPX == 3) fut_t = __builtin_amdgcn_readfirstlane((int)tick_lds[0]);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // DSPREAD: 0 = all 4 * SPLIT LDS-DMA requests in one burst; 1 = spread over the conj-twiddle multiplications (one share per 8 positions);
     // 2 = spread over the twiddle multiplications and the eight butterflies of I2's first stage
@@ -537,6 +602,18 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
                                                voff + (uint32_t)((64 * g + 1024 * m) * v_sn * 4), 0, 0, AUXD);
     };
     constexpr int NDMA = 4 * SPLIT, NSLOT = DSPREAD == 2 ? 16 : 8;
+    if constexpr (PFL2 == 1) static_for<SPLIT, GP>([&](auto gc) { l2_touch(gc); });
+    if constexpr (PFL2 == 2) static_for<SPLIT, GP>([&](auto gc) { const uint32_t t = tch[decltype(gc)::value]; asm volatile("" :: "v"(t)); });
+    if constexpr (PFL2 == 3) static_for<0, GP>([&](auto gc) { const uint32_t t = tch[decltype(gc)::value]; asm volatile("" :: "v"(t)); });
+    // STAG: the two waves of a SIMD (w, w + 4) take turns — a wave that issues its 16 LDS-DMA requests sits in the issue stage until the
+    // texture path has taken them (~40 clocks each with the memory system busy: batch 15's phase times), and with all eight waves doing that
+    // at once nobody computes.  Waves 0-3 issue theirs here, waves 4-7 behind I2's first stage; each set computes while the other one waits.
+    // (The prefetched rows are looked at first: hipcc counts only UNCONDITIONAL requests as younger, so with the burst inside a branch its
+    //  wait for those registers at the trade in the store burst would become a wait for the LDS-DMA.  They were requested a phase and a half ago.)
+    [[maybe_unused]] const bool set_y = __builtin_amdgcn_readfirstlane(tid0 >> 6) >= 4;
+    if constexpr (STAG != 0 && PF > 0) static_for<0, 4 * PF>([&](auto ic) { vpin4(dfr[decltype(ic)::value]); });
+    if constexpr (STAG != 0) { if (!set_y) static_for<0, SPLIT>([&](auto gc) { dma_group(rs_next, dma_voff(voff, v_sn), v_sn, gc); }); }
+    else
     if constexpr (DSPREAD == 0 && SYNCP != 10) static_for<0, SPLIT>([&](auto gc) { dma_group(rs_next, dma_voff(voff, v_sn), v_sn, gc); });
     asm volatile("" ::: "memory");                 // the vmcnt() at the top of the loop counts on these being older than every store below
 
@@ -558,11 +635,68 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
       constexpr int sl = 8 + decltype(q0c)::value;
       static_for<sl * NDMA / NSLOT, (sl + 1) * NDMA / NSLOT>([&](auto qc) { dma_one(qc); });
     });
+    else if constexpr (STAG == 2) {                 // waves 4-7 issue half way through the first stage
+      p64v_stageA1_cb<true>(z, [&](auto q0c) {
+        if constexpr (decltype(q0c)::value == 3) { if (set_y) static_for<0, SPLIT>([&](auto gc) { dma_group(rs_next, dma_voff(voff, v_sn), v_sn, gc); }); }
+      });
+    }
     else p64v_stageA1<true>(z);
+    asm volatile("" ::: "memory");
+    if constexpr (STAG == 1) { if (set_y) static_for<0, SPLIT>([&](auto gc) { dma_group(rs_next, dma_voff(voff, v_sn), v_sn, gc); }); }
     asm volatile("" ::: "memory");
     {
       const uint32_t ooff = (uint32_t)(((long long)(u + 512 * h) * out_sn + 4 * pp) * ESO);
-      if constexpr (SYNCP >= 3 && SYNCP != 8) {
+      if constexpr (SYNCP == 17) {
+        // SPLIT BURST: the groups that are reloaded behind their stores go first — last stage, barrier, their stores, barrier, their reloads —
+        // and those loads travel while the other groups' last stage and store burst run
+        static_for<SPLIT, GP>([&](auto gc) {
+          constexpr int g = decltype(gc)::value;
+          fftA_stage2_group<8, 8, true, g>(z);
+          vpin8<8 * g, 1>(z);
+          swap_group(gc);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+        p64v_barrier();
+        static_for<SPLIT, GP>([&](auto gc) {
+          constexpr int g = decltype(gc)::value;
+          static_for<0, 4>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            store16(rs_out, ooff + (uint32_t)((64 * g + 1024 * m) * out_sn * ESO), make_float4(z[8 * g + 2 * m].x, z[8 * g + 2 * m].y, z[8 * g + 2 * m + 1].x, z[8 * g + 2 * m + 1].y));
+          });
+          __builtin_amdgcn_sched_barrier(0);
+        });
+        p64v_barrier();
+        static_for<SPLIT, GP>([&](auto gc) { load_group(rs_next, voff, v_sn, gc); });
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, 8 - (GP - SPLIT)>([&](auto ic) {
+          constexpr int g = (decltype(ic)::value + GP) % 8;
+          fftA_stage2_group<8, 8, true, g>(z);
+          vpin8<8 * g, 1>(z);
+          swap_group(std::integral_constant<int, g>{});
+          __builtin_amdgcn_sched_barrier(0);
+        });
+        p64v_barrier();
+        static_for<0, 8 - (GP - SPLIT)>([&](auto ic) {
+          constexpr int g = (decltype(ic)::value + GP) % 8;
+          static_for<0, 4>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            const float4 res = make_float4(z[8 * g + 2 * m].x, z[8 * g + 2 * m].y, z[8 * g + 2 * m + 1].x, z[8 * g + 2 * m + 1].y);
+            if constexpr (g >= GP) {
+              if (more) {
+                const float4 nx = dfr[4 * (g - GP) + m];
+                dfr[4 * (g - GP) + m] = res;
+                z[8 * g + 2 * m] = make_float2(nx.x, nx.y);
+                z[8 * g + 2 * m + 1] = make_float2(nx.z, nx.w);
+              } else {
+                store16(rs_out, ooff + (uint32_t)((64 * g + 1024 * m) * out_sn * ESO), res);
+              }
+            } else {
+              store16(rs_out, ooff + (uint32_t)((64 * g + 1024 * m) * out_sn * ESO), res);
+            }
+          });
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      } else if constexpr (SYNCP >= 3 && SYNCP != 8) {
         // store BURST: every butterfly of I2's last stage first, then (SYNCP 3: the gang meets) all stores back to back, then the reloads —
         // the two workgroups of a pair put both halves of every line into the L2 within a couple of microseconds (tools/store_lab.hip: halves
         // that arrive within ~1 us of each other cost what a whole line costs)
@@ -574,7 +708,9 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
           __builtin_amdgcn_sched_barrier(0);
         });
         if constexpr (SYNCP == 3 || SYNCP == 5 || SYNCP == 7) gang_meet();
+        mark(7);                                   // DMA issue, twiddles, I2 (wave 0's own)
         if constexpr (SYNCP >= 9) p64v_barrier();
+        mark(8);                                   // barrier in front of the burst (the slowest wave's I2)
         if constexpr (SYNCP == 10) static_for<0, NDMA>([&](auto qc) { dma_one(qc); });
         static_for<0, 8>([&](auto ic) {
           constexpr int g = (decltype(ic)::value + SPLIT) % 8;
@@ -601,7 +737,9 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
           });
           __builtin_amdgcn_sched_barrier(0);
         });
+        mark(9);                                   // store issue (+ the wait for the prefetched rows that trade places)
         if constexpr (SYNCP >= 11) p64v_barrier();
+        mark(10);                                  // barrier behind the burst
         if constexpr (SYNCP == 15) __builtin_amdgcn_s_sleep(4);
         if constexpr (SYNCP == 16) __builtin_amdgcn_s_sleep(16);
         static_for<SPLIT, GP>([&](auto gc) { load_group(rs_next, voff, v_sn, gc); });
@@ -642,7 +780,22 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
     obp = ob;
     if constexpr (SYNCP == 14) p64v_barrier();
     gate_fetch(gpn);     // committed to LDS at the end of the next tile's F1 (after the last tile: a harmless re-read of this tile's bins)
+    if constexpr (MAPX == 3) { cur_t = nxt_t; nxt_t = fut_t; }
+    mark(11);                                      // reload issue + gate fetch issue
   }  // tile loop
+  if constexpr (TSTAMP) {                          // when did this workgroup start / finish (100 MHz)?  a.mem + 256 words: [2 wg], [2 wg + 1]
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid0 == 0) {
+      unsigned long long* tp = reinterpret_cast<unsigned long long*>(const_cast<float*>(a.mem)) + 128 + 2 * blockIdx.x;
+      tp[0] = t_start; tp[1] = __builtin_amdgcn_s_memrealtime();
+      unsigned long long* cp2 = reinterpret_cast<unsigned long long*>(const_cast<float*>(a.mem)) + 4096 + 2 * blockIdx.x;   // shader clocks
+      cp2[0] = c_start; cp2[1] = __builtin_readcyclecounter();
+      if constexpr (TSTAMP == 2) {
+        unsigned long long* pp2 = reinterpret_cast<unsigned long long*>(const_cast<float*>(a.mem)) + 1024 + 12 * blockIdx.x;
+        for (int k = 0; k < 12; ++k) pp2[k] = ph_acc[k];
+      }
+    }
+  }
 }
 
 hipError_t launch_p64v_unused(const RegtileArgs& a, bool in_bf16, bool out_bf16, hipStream_t stream);

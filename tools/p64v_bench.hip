@@ -55,9 +55,9 @@ int main(int argc, char** argv) {
   la.v_sb = (long long)N * D; la.v_sn = D; la.out_sb = (long long)N * D; la.out_sn = D;
   la.tiles_per_row = D / 16; la.n_tiles = B * (D / 16);
 
-  unsigned* cnt_buf; CK(hipMalloc(&cnt_buf, 4096)); CK(hipMemset(cnt_buf, 0, 4096));
+  unsigned* cnt_buf; CK(hipMalloc(&cnt_buf, 65536)); CK(hipMemset(cnt_buf, 0, 65536));
   RegtileArgs ls = la; ls.mem = reinterpret_cast<const float*>(cnt_buf);      // SYNCP variants: a.mem carries the gang counters
-  auto synced = [&](std::function<void()> f) { return std::function<void()>([=] { CK(hipMemsetAsync(cnt_buf, 0, 4096, 0)); f(); }); };
+  auto synced = [&](std::function<void()> f) { return std::function<void()>([=] { CK(hipMemsetAsync(cnt_buf, 0, 65536, 0)); f(); }); };
   // bf16 rows in: the same values rounded to bf16 (device-side conversion)
   uint16_t* vb16; CK(hipMalloc(&vb16, (size_t)B * N * D * 2));
   hipLaunchKernelGGL(to_bf16, dim3(4096), dim3(256), 0, 0, v, vb16, (size_t)B * N * D);
@@ -121,6 +121,43 @@ int main(int argc, char** argv) {
     printf("%-58s %7.4f %7.4f (%+5.1f%%) |", x.name.c_str(), m[0], m[m.size() / 2], 100.0 * (m[m.size() / 2] / base - 1.0));
     for (float t : x.ms) printf(" %.4f", t);
     printf("\n");
+  }
+  // ---- TSTAMP variants: when does every workgroup start and finish (s_memrealtime, 100 MHz)?
+  for (auto& x : vs) {
+    if (!strstr(x.name.c_str(), "TSTAMP")) continue;
+    for (int rep = 0; rep < 3; ++rep) {
+      x.launch(); CK(hipDeviceSynchronize());
+      std::vector<unsigned long long> t(512);
+      CK(hipMemcpy(t.data(), reinterpret_cast<char*>(cnt_buf) + 1024, 4096, hipMemcpyDeviceToHost));
+      unsigned long long t0 = ~0ull; for (int w = 0; w < 256; ++w) t0 = std::min(t0, t[2 * w]);
+      std::vector<double> st, en; for (int w = 0; w < 256; ++w) { st.push_back((t[2 * w] - t0) * 0.01); en.push_back((t[2 * w + 1] - t0) * 0.01); }
+      std::vector<double> es = en; std::sort(es.begin(), es.end()); std::sort(st.begin(), st.end());
+      double xm[8] = {0}; for (int w = 0; w < 256; ++w) xm[w % 8] = std::max(xm[w % 8], en[w]);
+      printf("%-34s starts 0 .. %.1f us; finishes min %.1f p10 %.1f median %.1f p90 %.1f max %.1f us; last finish per XCD:", x.name.c_str(), st[255], es[0], es[25], es[128], es[230], es[255]);
+      for (double v : xm) printf(" %.0f", v);
+      printf("\n");
+      {
+        std::vector<unsigned long long> cy(512);
+        CK(hipMemcpy(cy.data(), reinterpret_cast<char*>(cnt_buf) + 32768, 4096, hipMemcpyDeviceToHost));
+        double lo = 1e9, hi = 0, m = 0;
+        for (int w = 0; w < 256; ++w) { const double mhz = (double)(cy[2 * w + 1] - cy[2 * w]) / ((t[2 * w + 1] - t[2 * w]) * 0.01); lo = std::min(lo, mhz); hi = std::max(hi, mhz); m += mhz / 256; }
+        printf("    shader clocks per microsecond over the kernel (s_memtime / s_memrealtime): mean %.0f MHz, workgroups %.0f .. %.0f\n", m, lo, hi);
+      }
+      if (strstr(x.name.c_str(), "PHASES")) {
+        std::vector<unsigned long long> ph(256 * 12);
+        CK(hipMemcpy(ph.data(), reinterpret_cast<char*>(cnt_buf) + 8192, ph.size() * 8, hipMemcpyDeviceToHost));
+        static const char* pn[12] = {"back edge", "stage 1 of the deferred groups + wait for the LDS-DMA", "read staged groups + their stage 1", "wait for the reloaded groups + their stage 1",
+          "F1 stage 2, twiddles, barrier, real-plane writes", "gate commit (waits for the gate loads)", "deferred stores / loads, E1, middle, E2", "DMA issue, twiddles, I2",
+          "barrier in front of the burst", "store issue (+ trade with the prefetched rows)", "barrier behind the burst", "reload issue + gate fetch issue"};
+        double tot = 0;
+        for (int k = 0; k < 12; ++k) {
+          std::vector<double> v; for (int w = 0; w < 256; ++w) v.push_back(ph[w * 12 + k] * 0.01 / 48.0);
+          std::sort(v.begin(), v.end()); double m = 0; for (double y : v) m += y; m /= 256; tot += m;
+          printf("    %-58s mean %6.2f us per tile (workgroups: min %6.2f median %6.2f max %6.2f)\n", pn[k], m, v[0], v[128], v[255]);
+        }
+        printf("    sum %.2f us per tile\n", tot);
+      }
+    }
   }
   return 0;
 }

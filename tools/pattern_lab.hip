@@ -7,7 +7,7 @@
 //   map 2  dynamic:           a gang takes the next GANG tiles from an atomic counter
 //   map 3  flat:              one workgroup per tile, non-persistent (the dispatcher is the counter)
 //   rot 1  workgroup w starts its row walk at chunk (w / GANG) % chunks-per-tile and wraps (neighbours in different rows at the same time)
-// usage: pattern_lab [reps]
+// usage: pattern_lab [reps] [D] [short]     (D = channels per row, default 768: the row stride in floats; short = only the product's maps)
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/pattern_lab.hip -o tools/pattern_lab
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -91,7 +91,8 @@ int main(int argc, char** argv) {
   const int reps = argc > 1 ? atoi(argv[1]) : 10;
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
   const int cus = prop.multiProcessorCount;
-  const long long B = 256, N = 4096, D = 768, row_bytes = D * 4, rows = B * N;
+  const long long B = 256, N = 4096, D = argc > 2 ? atoll(argv[2]) : 768, row_bytes = D * 4, rows = B * N;
+  const bool brief = argc > 3;
   const size_t bytes = (size_t)rows * row_bytes;
   char *a, *b; CK(hipMalloc(&a, bytes)); CK(hipMalloc(&b, bytes));
   CK(hipMemset(a, 1, bytes)); CK(hipMemset(b, 2, bytes));
@@ -127,6 +128,11 @@ int main(int argc, char** argv) {
     printf("seg %3d  %-14s rot %d  WG/CU %d  T=%d %s %-5s  %.4f ms  %7.1f GB/s\n", seg, mapn[map], rot, per_cu, threads, nt ? "nt" : "  ", moden[mode], ms, nb / ms / 1e6);
     fflush(stdout);
   };
+  if (brief) {     // the row-stride question: does the column walk pile up on a few L2 / memory channels?
+    printf("D = %lld (row stride %lld B = %.2f lines)\n", D, row_bytes, row_bytes / 128.0);
+    for (int seg : {128, 64}) for (int mode : {0, 1, 2}) run(seg, 0, 0, 1, mode, false, 512);
+    return 0;
+  }
   for (int seg : {128, 64}) {
     for (int mode : {0}) {
       for (int map : {0, 2, 4})
