@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(512) spectre_gate_grad_regtile_long(const Gate
       uint32_t voff = (uint32_t)(((long long)n2 * a.v_sn + pa) * ES), doff = (uint32_t)(((long long)n2 * a.dout_sn + pa) * ES);
       if constexpr (GENERAL) { if (!cok) { voff = 0x80000000u; doff = 0x80000000u; } }
       static_for<0, RF>([&](auto ic) {
-        constexpr int q = (decltype(ic)::value / RAF) + RBF * (decltype(ic)::value % RAF);
+        constexpr int q = in_order<RF>(decltype(ic)::value);
         uint32_t vo = voff, dof = doff, vs = (uint32_t)((long long)q * RS * a.v_sn * ES), ds = (uint32_t)((long long)q * RS * a.dout_sn * ES);
         if constexpr (GENERAL) { vo += vs; dof += ds; vs = 0; ds = 0; }   // the range check covers the VGPR offset only
         float x, dy;

@@ -118,7 +118,7 @@ spectre_mix_regtile_mixed(const RegtileArgs a) {
       // vmcnt(0), unpack, next load: ONE request in flight per wave — and does so for RF = 48 and 64 (2.6 ms instead of 1.35 at
       // (300,2560,768); rocprof SQ_INST_LEVEL_VMEM halved, 44 more s_waitcnt in the listing).  The packed words sit in z[].x meanwhile.
       static_for<0, RF>([&](auto ic) {
-        constexpr int q = (decltype(ic)::value / RAF) + RBF * (decltype(ic)::value % RAF);   // order of use in stage 1
+        constexpr int q = in_order<RF>(decltype(ic)::value);   // order of use in stage 1
         uint32_t wv;
         if constexpr (GENERAL) wv = __builtin_amdgcn_raw_buffer_load_b32(rs_in, voff_c + (uint32_t)((long long)q * RS * a.v_sn * ES_IN), 0, 0);
         else wv = *reinterpret_cast<const uint32_t*>(vb + (size_t)q * RS * a.v_sn * ES_IN + voff);
@@ -126,13 +126,13 @@ spectre_mix_regtile_mixed(const RegtileArgs a) {
       });
       __builtin_amdgcn_sched_barrier(0);
       static_for<0, RF>([&](auto ic) {
-        constexpr int q = (decltype(ic)::value / RAF) + RBF * (decltype(ic)::value % RAF);
+        constexpr int q = in_order<RF>(decltype(ic)::value);
         const uint32_t wv = __float_as_uint(z[q].x);
         z[q] = make_float2(__uint_as_float(wv << 16), __uint_as_float(wv & 0xffff0000u));
       });
     } else
     static_for<0, RF>([&](auto ic) {
-      constexpr int q = (decltype(ic)::value / RAF) + RBF * (decltype(ic)::value % RAF);   // order of use in stage 1
+      constexpr int q = in_order<RF>(decltype(ic)::value);   // order of use in stage 1
       if constexpr (GENERAL) {
         const uint32_t off = voff_c + (uint32_t)((long long)q * RS * a.v_sn * ES_IN);
         if constexpr (IN_BF16) {

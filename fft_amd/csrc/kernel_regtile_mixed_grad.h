@@ -56,7 +56,7 @@ spectre_gate_grad_regtile_mixed(const GateGradArgs a) {
       uint32_t voff = (uint32_t)(((long long)u * a.v_sn + p) * ES), doff = (uint32_t)(((long long)u * a.dout_sn + p) * ES);
       if constexpr (GENERAL) { if (kPC * jt + p >= a.d_g) { voff = 0x80000000u; doff = 0x80000000u; } }
       static_for<0, RF>([&](auto ic) {
-        constexpr int q = (decltype(ic)::value / RAF) + RBF * (decltype(ic)::value % RAF);
+        constexpr int q = in_order<RF>(decltype(ic)::value);
         uint32_t vo = voff, dof = doff, vs = (uint32_t)((long long)q * RS * a.v_sn * ES), ds = (uint32_t)((long long)q * RS * a.dout_sn * ES);
         if constexpr (GENERAL) { vo += vs; dof += ds; vs = 0; ds = 0; }   // the range check covers the VGPR offset only
         float x, dy;

@@ -47,10 +47,37 @@ __device__ __forceinline__ void mp_pin(float2 (&z)[NZ]) {
 //  multiplication, the image-freeing barrier moved in front of it or to the top of the tile: 1.87 / 1.89 ms against 1.59, and 1.24 against
 //  1.15 ms without memory traffic; profiles/r03_mixedp_ab.log.  The scattered ds_write_b32 between the multiplications cost more than the
 //  write phase they replace, and the earlier barrier exposes the slowest wave's loads.  Not kept.)
-template <int RF, int RS, int P, bool FIRST = false>
+// STAGED row blocks (round 4): S of the RF row blocks of the NEXT tile — the first S of the order F1 uses them, S even — are requested
+// BEFORE this tile's stores, as LDS-DMA (buffer_load_dwordx4 ... lds, no register needed) into the exchange image, which is idle between
+// E2 and the next E1, and into the LDS behind the gate that a mixed-radix tile leaves free (3000: 96 KiB image + 12 KiB gate of 160).
+// A wave's loads and stores retire through one in-order counter, so a row block reloaded behind its store is only there when that store
+// has been acknowledged (same-box ablation at 3000 with every block deferred or reloaded: loads alone + 0.19 ms, stores alone + 0.03,
+// both + 0.59); staged blocks are older than every store.  One request = 1 KiB = the 8 row classes of the wave x 2 row blocks x 64 bytes:
+// lane l fetches quarter l & 3 of the row of class (l >> 2) & 7 of block pair member l >> 5, and thread (p, u) reads its 8 bytes back
+// out of its OWN wave's slot (no barrier), conflict-free (the wave's 64 reads cover 512 contiguous bytes).  Waves without a row class
+// (u >= RS for all their threads) issue the same requests into a 1-KiB dump, so that every wave counts the same requests.
+template <int RF, int RS, int S> constexpr int mixedp_slot_bytes() { return (S / 2) * 1024; }
+template <int RF, int RS, int S> constexpr int mixedp_row_waves() { return (RS + 7) / 8; }                       // waves that own row classes
+template <int RF, int RS, int S> constexpr int mixedp_image_waves() {                                             // ... whose slots lie in the image
+  return S == 0 ? 0 : (mixed_image_bytes<RF, RS>() / mixedp_slot_bytes<RF, RS, S>() < mixedp_row_waves<RF, RS, S>() ? mixed_image_bytes<RF, RS>() / mixedp_slot_bytes<RF, RS, S>() : mixedp_row_waves<RF, RS, S>());
+}
+template <int RF, int RS, int S> constexpr int mixedp_extra_off() { return (mixed_lds_total<RF, RS>() + 15) & ~15; }   // behind the gate
+template <int RF, int RS, int S> constexpr int mixedp_dump_off() { return mixedp_extra_off<RF, RS, S>() + (mixedp_row_waves<RF, RS, S>() - mixedp_image_waves<RF, RS, S>()) * mixedp_slot_bytes<RF, RS, S>(); }
+// ... and with staged blocks the twiddle bases of every row class live in LDS as well (written once per workgroup): as global loads
+// they are 2 x (RA + RB - 2) of the tile's VMEM requests per thread (34 of ~150 at 60 x 50), they sit in the same in-order counter as the
+// LDS-DMA and the stores, the ones in front of I2 are consumed as soon as they are requested (a memory latency per tile), and their
+// 2 (RA + RB) registers stay live through the transform.  One row of 16-byte-aligned float2 per row class: W^(u j), j = 1 .. RA - 1, then
+// W^(u RA j), j = 1 .. RB - 1.
+template <int RF> constexpr int mixedp_tw_row() { return ((Split<RF>::RA + Split<RF>::RB - 2) + 1) & ~1; }       // float2 per row class
+template <int RF, int RS, int S> constexpr int mixedp_tw_off() { return mixedp_dump_off<RF, RS, S>() + 1024; }
+template <int RF, int RS, int S> constexpr int mixedp_lds_total() { return S == 0 ? mixed_lds_total<RF, RS>() : mixedp_tw_off<RF, RS, S>() + RS * mixedp_tw_row<RF>() * 8; }
+
+template <int RF, int RS, int P, bool FIRST = false, int S = 0>
 __global__ void __launch_bounds__(kPC * (RF > RS ? RF : RS), 1) spectre_mix_regtile_mixedp(const RegtileArgs a) {
   constexpr int D0 = FIRST ? 0 : RF - P;           // the deferred row blocks are [D0, D0 + P) of the order F1 uses them (the last ones: measured
                                                    // 1 % better than the first ones, 1.586 vs 1.605 ms)
+  static_assert(S % 2 == 0 && S >= 0 && (S == 0 || (!FIRST && S <= D0)), "staged row blocks: the first S of F1's order, in pairs; the deferred ones are the last P");
+  static_assert(mixedp_lds_total<RF, RS, S>() <= 160 * 1024, "LDS budget");
   constexpr int N = RF * RS, NZ = mixed_team<RF, RS>(), NT = mixed_threads<RF, RS>();
   static_assert(N % 2 == 0 && P >= 0 && P <= RF, "even n_fft; P deferred row blocks");
   constexpr int RAF = Split<RF>::RA, RBF = Split<RF>::RB;
@@ -99,7 +126,7 @@ __global__ void __launch_bounds__(kPC * (RF > RS ? RF : RS), 1) spectre_mix_regt
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)((long long)nrow * sn * 4), kRsrcFlags);
   };
   // row blocks in the order F1 uses them
-  auto row_q = [](auto ic) { constexpr int i = decltype(ic)::value; return std::integral_constant<int, (i / RAF) + RBF * (i % RAF)>{}; };
+  auto row_q = [](auto ic) { constexpr int i = decltype(ic)::value; return std::integral_constant<int, in_order<RF>(i)>{}; };
   auto load_row = [&](__amdgpu_buffer_rsrc_t rs, uint32_t voff, long long sn, auto qc) -> float2 {
     const rt_u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, voff + (uint32_t)((long long)decltype(qc)::value * RS * sn * 4), 0, 0);
     return make_float2(__uint_as_float(t.x), __uint_as_float(t.y));
@@ -109,6 +136,43 @@ __global__ void __launch_bounds__(kPC * (RF > RS ? RF : RS), 1) spectre_mix_regt
     t.x = __float_as_uint(v.x); t.y = __float_as_uint(v.y);
     __builtin_amdgcn_raw_buffer_store_b64(t, rs, ooff + (uint32_t)((long long)decltype(qc)::value * RS * sn * 4), 0, 0);
   };
+  // ---- staged row blocks: this wave's slot (SGPRs), the lane's request offset and read-back address
+  [[maybe_unused]] const int wv = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+  [[maybe_unused]] const bool wave_rows = wv < mixedp_row_waves<RF, RS, S>();
+  [[maybe_unused]] const int slot_off = !wave_rows ? mixedp_dump_off<RF, RS, S>()
+                                       : wv < mixedp_image_waves<RF, RS, S>() ? wv * mixedp_slot_bytes<RF, RS, S>()
+                                       : mixedp_extra_off<RF, RS, S>() + (wv - mixedp_image_waves<RF, RS, S>()) * mixedp_slot_bytes<RF, RS, S>();
+  [[maybe_unused]] const int slot_step = wave_rows ? 1024 : 0;
+  // lane part of a request's offset, once per burst: (row class, quarter) of this lane, and which member of the block pair it fetches
+  [[maybe_unused]] uint32_t dma_base = 0;
+  [[maybe_unused]] bool dma_second = false;
+  [[maybe_unused]] auto stage_coords = [&](long long sn) {
+    int t = tid0;
+    asm volatile("" : "+v"(t));
+    const int l = t & 63, ud = 8 * (t >> 6) + ((l >> 2) & 7);
+    const uint32_t inside = (uint32_t)(((long long)ud * sn + 4 * (l & 3)) * 4);
+    dma_base = ud < RS ? inside : 0x80000000u;        // (a select, not a branch: beyond every range, like the row offsets of threads without rows)
+    dma_second = (l >> 5) != 0;
+  };
+  [[maybe_unused]] auto stage_pair = [&](__amdgpu_buffer_rsrc_t rs, long long sn, auto jc) {    // row blocks row_q(2j), row_q(2j + 1) of the tile behind rs
+    constexpr int j = decltype(jc)::value;
+    constexpr int qa = in_order<RF>(2 * j), qb = in_order<RF>(2 * j + 1);
+    const uint32_t ca = (uint32_t)((long long)qa * RS * sn * 4), cb = (uint32_t)((long long)qb * RS * sn * 4);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + slot_off + j * slot_step), 16,
+                                             dma_base + (dma_second ? cb : ca), 0, 0, 0);
+  };
+  // read-back: one lane address per tile, the row block is an immediate offset (waves without rows read the image's first bytes: unused)
+  [[maybe_unused]] auto staged_base = [&]() -> const char* {
+    int t = tid0;
+    asm volatile("" : "+v"(t));
+    const int l = t & 63;
+    return smem + (wave_rows ? slot_off : 0) + ((l >> 3) * 4 + ((l & 7) >> 1)) * 16 + (l & 1) * 8;
+  };
+  [[maybe_unused]] auto staged_read = [&](const char* rb, auto ic) -> float2 {                  // this thread's 8 bytes of row block row_q(i)
+    constexpr int i = decltype(ic)::value;
+    return *reinterpret_cast<const float2*>(rb + (i / 2) * 1024 + (i & 1) * 512);
+  };
+
   auto gate_fetch = [&](const float2* gp) {          // raw; all arithmetic happens in gate_commit (nothing computed before the back edge)
     static_for<0, GS>([&](auto ic) {
       const int k = tid + NT * decltype(ic)::value;
@@ -125,8 +189,26 @@ __global__ void __launch_bounds__(kPC * (RF > RS ? RF : RS), 1) spectre_mix_regt
       if (k <= N / 2) glds[k] = make_float2(g.x * inv_n, g.y * inv_n);
     });
   };
+  if constexpr (S > 0) {                             // the twiddle bases of every row class -> LDS, once
+    constexpr int TR = mixedp_tw_row<RF>();
+    float2* twl = reinterpret_cast<float2*>(smem + mixedp_tw_off<RF, RS, S>());
+    for (int i = threadIdx.x; i < RS * TR; i += NT) {
+      const int uu = i / TR, e = i - TR * uu;
+      twl[i] = e < RAF - 1 ? a.tw[uu * (e + 1)] : e < RAF + RBF - 2 ? a.tw[uu * RAF * (e - (RAF - 1) + 1)] : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+  }
   auto load_twiddle_bases = [&](float2 (&wa)[RAF], float2 (&wb)[RBF]) {   // W_N^(u ka), W_N^(u RAF kb)
     const int uu = rows ? u : 0;
+    if constexpr (S > 0) {
+      constexpr int TR = mixedp_tw_row<RF>();
+      const float4* t = reinterpret_cast<const float4*>(smem + mixedp_tw_off<RF, RS, S>()) + uu * (TR / 2);
+      float2 flat[TR];
+      static_for<0, TR / 2>([&](auto ic) { constexpr int i = decltype(ic)::value; const float4 q = t[i]; flat[2 * i] = make_float2(q.x, q.y); flat[2 * i + 1] = make_float2(q.z, q.w); });
+      static_for<1, RAF>([&](auto jc) { constexpr int j = decltype(jc)::value; wa[j] = flat[j - 1]; });
+      static_for<1, RBF>([&](auto jc) { constexpr int j = decltype(jc)::value; wb[j] = flat[RAF - 1 + j - 1]; });
+      return;
+    }
     static_for<1, RAF>([&](auto jc) { constexpr int j = decltype(jc)::value; wa[j] = a.tw[uu * j]; });
     static_for<1, RBF>([&](auto jc) { constexpr int j = decltype(jc)::value; wb[j] = a.tw[uu * RAF * j]; });
   };
@@ -137,7 +219,10 @@ __global__ void __launch_bounds__(kPC * (RF > RS ? RF : RS), 1) spectre_mix_regt
     tile_ptrs(pair_base, vb, ob, gp);
     const __amdgpu_buffer_rsrc_t rs = rsrc(vb, a.v_sn, a.rows_in);
     const uint32_t voff = rows ? (uint32_t)(((long long)u * a.v_sn + 2 * p) * 4) : 0x80000000u;
-    static_for<0, RF>([&](auto ic) { constexpr int q = decltype(row_q(ic))::value; z[q] = load_row(rs, voff, a.v_sn, std::integral_constant<int, q>{}); });
+    if constexpr (S > 0) stage_coords(a.v_sn);
+    static_for<0, S / 2>([&](auto jc) { stage_pair(rs, a.v_sn, jc); });
+    asm volatile("" ::: "memory");
+    static_for<S, RF>([&](auto ic) { constexpr int q = decltype(row_q(ic))::value; z[q] = load_row(rs, voff, a.v_sn, std::integral_constant<int, q>{}); });
     gate_fetch(gp);
   }
 
@@ -162,9 +247,16 @@ __global__ void __launch_bounds__(kPC * (RF > RS ? RF : RS), 1) spectre_mix_regt
 
     // ---- rows u + RS*q, q < RF: F1 over q, W_N^(u k1) ---------------------------------------------------------------------
     float2 wa[RAF], wb[RBF];
-    load_twiddle_bases(wa, wb);
+    if constexpr (S == 0) load_twiddle_bases(wa, wb);
+    // the staged row blocks: requested before the previous tile's stores; hipcc puts the s_waitcnt vmcnt(N) in front of these reads itself
+    // (N = the requests that are certainly younger than the last LDS-DMA: that tile's stores, its reloads, the gate fetch, the twiddle bases)
+    if constexpr (S > 0) {
+      const char* rb = staged_base();
+      static_for<0, S>([&](auto ic) { z[decltype(row_q(ic))::value] = staged_read(rb, ic); });
+    }
     if (rows) {
       fft_ct<RF, false, IdentityMap, NZ>(z);
+      if constexpr (S > 0) { __builtin_amdgcn_sched_barrier(0); load_twiddle_bases(wa, wb); }
       static_for<1, RF>([&](auto kc) {
         constexpr int k1 = decltype(kc)::value, ka = k1 % RAF, kb = k1 / RAF, pos = out_pos<RF>(k1);
         if constexpr (ka > 0) z[pos] = cmul(z[pos], wa[ka]);
@@ -236,6 +328,16 @@ __global__ void __launch_bounds__(kPC * (RF > RS ? RF : RS), 1) spectre_mix_regt
 
     // ---- conj twiddle, I2 over k1, store rows u + RS*n1 (spectre.py:553), reload / trade places -------------------------------
     load_twiddle_bases(wa, wb);
+    if constexpr (S > 0) {
+      // every wave is behind E2's last read: the image is idle, the next tile's first S row blocks may land in it.  The twiddle bases come
+      // out of LDS and are read BEFORE the requests (hipcc orders every LDS read behind a pending LDS-DMA with s_waitcnt vmcnt(0)); the
+      // prefetched row blocks are looked at here (requested a phase and a half ago) so that no wait for them is placed behind the requests.
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      static_for<0, (P > 0 ? P : 1)>([&](auto ic) { mp_pin1(dfr[decltype(ic)::value].x); mp_pin1(dfr[decltype(ic)::value].y); });
+      stage_coords(v_sn);
+      static_for<0, S / 2>([&](auto jc) { stage_pair(rs_next, v_sn, jc); });
+      asm volatile("" ::: "memory");
+    }
     if (rows) {
       static_for<1, RF>([&](auto kc) {
         constexpr int k1 = decltype(kc)::value, ka = k1 % RAF, kb = k1 / RAF;
@@ -266,7 +368,7 @@ __global__ void __launch_bounds__(kPC * (RF > RS ? RF : RS), 1) spectre_mix_regt
     } else {
       static_for<D0, D0 + P>([&](auto ic) { constexpr int q = decltype(row_q(ic))::value; store_row(rs_out, ooff, out_sn, std::integral_constant<int, q>{}, res[q]); });
     }
-    static_for<0, RF>([&](auto ic) {
+    static_for<S, RF>([&](auto ic) {
       constexpr int i = decltype(ic)::value, q = decltype(row_q(ic))::value;
       if constexpr (i < D0 || i >= D0 + P) z[q] = load_row(rs_next, voff, v_sn, std::integral_constant<int, q>{});
     });

@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(512) spectre_mix_regtile_quad(const RegtileArg
       // bf16 rows: every request first, the unpacking afterwards (kernel_regtile_mixed.h: written as one loop hipcc serialises the
       // requests — load, s_waitcnt vmcnt(0), unpack, next load; tools/serial_load_scan.py found 48 / 64 such pairs in the general modes)
       static_for<0, RF>([&](auto ic) {
-        constexpr int q = (decltype(ic)::value / RAF) + RBF * (decltype(ic)::value % RAF);
+        constexpr int q = in_order<RF>(decltype(ic)::value);
         uint32_t wv;
         if constexpr (GENERAL) wv = __builtin_amdgcn_raw_buffer_load_b32(rs_in, voff_c + (uint32_t)((long long)q * RS * a.v_sn * ES_IN), 0, 0);
         else wv = *reinterpret_cast<const uint32_t*>(vb + (size_t)q * RS * a.v_sn * ES_IN + voff);
@@ -97,13 +97,13 @@ __global__ void __launch_bounds__(512) spectre_mix_regtile_quad(const RegtileArg
       });
       __builtin_amdgcn_sched_barrier(0);
       static_for<0, RF>([&](auto ic) {
-        constexpr int q = (decltype(ic)::value / RAF) + RBF * (decltype(ic)::value % RAF);
+        constexpr int q = in_order<RF>(decltype(ic)::value);
         const uint32_t wv = __float_as_uint(z[q].x);
         z[q] = make_float2(__uint_as_float(wv << 16), __uint_as_float(wv & 0xffff0000u));
       });
     } else
     static_for<0, RF>([&](auto ic) {
-      constexpr int q = (decltype(ic)::value / RAF) + RBF * (decltype(ic)::value % RAF);
+      constexpr int q = in_order<RF>(decltype(ic)::value);
       if constexpr (GENERAL) {
         const uint32_t off = voff_c + (uint32_t)((long long)q * RS * a.v_sn * ES_IN);
         if constexpr (IN_BF16) {

@@ -245,8 +245,8 @@ def lint_lds_reads(name, blocks):
 
 def lint_addtid(name, blocks):
     """ds_write_addtid_b32 takes its base from M0, which the asm statement sets itself (hipcc treats M0 as reserved).  Each one must follow
-    an s_mov_b32 m0 inside the same asm statement, and no compiler-generated instruction of the kernel may read or write M0 (if hipcc
-    started to use M0 here — LDS-DMA, s_movrel — it would have to be told about these statements)."""
+    an s_mov_b32 m0 inside the same asm statement, and no compiler-generated instruction of the kernel may READ M0 (hipcc setting it — in front
+    of an LDS-DMA request — is fine: the statements declare M0 clobbered; a compiler-generated read, s_movrel say, would depend on them)."""
     errors, n = [], 0
     for b in blocks:
         prev_inline_m0 = False
@@ -257,7 +257,12 @@ def lint_addtid(name, blocks):
                 if not (x.inline and prev_inline_m0):
                     errors.append(f"{name}: `{x.text}` is not preceded by s_mov_b32 m0 inside its asm statement")
             if mentions_m0 and not x.inline:
-                errors.append(f"{name}: compiler-generated `{x.text}` uses M0 in a kernel whose asm statements overwrite it")
+                # hipcc may SET M0 (it does in front of every LDS-DMA request: the asm statements list M0 as clobbered, so it never assumes
+                # a value survives them); anything else — a read, a read-modify-write — would depend on what an asm statement left there
+                ops = [t.strip().rstrip(",") for t in x.text.split(None, 1)[1].split(",")] if " " in x.text else []
+                sets_m0 = x.op in ("s_mov_b32", "s_add_i32", "s_add_u32", "s_lshl_b32", "s_or_b32", "s_and_b32") and ops and ops[0] == "m0" and "m0" not in ops[1:]
+                if not sets_m0:
+                    errors.append(f"{name}: compiler-generated `{x.text}` uses M0 in a kernel whose asm statements overwrite it")
             if x.inline and x.op == "s_mov_b32" and x.text.split()[1].rstrip(",") == "m0":
                 prev_inline_m0 = True
             elif not (x.inline and x.op in ("s_nop", "ds_write_addtid_b32")):

@@ -160,9 +160,11 @@ def test_lds_check_without_reads_is_an_error(tmp_path):
 
 
 # ---- --check addtid: ds_write_addtid_b32 takes its base from M0, set inside the same asm statement ------------------------------------
-def addtid_listing(own_m0=True, compiler_m0=False):
+def addtid_listing(own_m0=True, compiler_m0=False, compiler_reads_m0=False):
     mov = "\ts_mov_b32 m0, s4\n\ts_nop 0\n" if own_m0 else ""
     other = "\ts_mov_b32 m0, s9\n\tbuffer_load_dword v1, s[0:3], 0 offen lds\n" if compiler_m0 else ""
+    if compiler_reads_m0:
+        other += "\ts_add_i32 m0, m0, s7\n"
     return f"""
 _Z6kernelv:                             ; @_Z6kernelv
 {other}\t;;#ASMSTART
@@ -196,6 +198,13 @@ def test_addtid_write_without_m0_fails(tmp_path):
     assert errors and "not preceded by s_mov_b32 m0" in errors[0]
 
 
-def test_compiler_use_of_m0_next_to_addtid_fails(tmp_path):
-    errors, _ = run_addtid(tmp_path, addtid_listing(compiler_m0=True))
+def test_compiler_setting_m0_for_an_lds_dma_next_to_addtid_passes(tmp_path):
+    """Round 4: the persistent mixed-radix kernel stages row blocks by LDS-DMA; hipcc sets M0 in front of every such request.  The asm
+    statements declare M0 clobbered and set it themselves, so a compiler-generated WRITE is harmless."""
+    errors, notes = run_addtid(tmp_path, addtid_listing(compiler_m0=True))
+    assert not errors, errors
+
+
+def test_compiler_reading_m0_next_to_addtid_fails(tmp_path):
+    errors, _ = run_addtid(tmp_path, addtid_listing(compiler_reads_m0=True))
     assert errors and "uses M0" in errors[0]
