@@ -72,8 +72,14 @@ template <int RF> constexpr int mixedp_tw_row() { return ((Split<RF>::RA + Split
 template <int RF, int RS, int S> constexpr int mixedp_tw_off() { return mixedp_dump_off<RF, RS, S>() + 1024; }
 template <int RF, int RS, int S> constexpr int mixedp_lds_total() { return S == 0 ? mixed_lds_total<RF, RS>() : mixedp_tw_off<RF, RS, S>() + RS * mixedp_tw_row<RF>() * 8; }
 
-template <int RF, int RS, int P, bool FIRST = false, int S = 0>
-__global__ void __launch_bounds__(kPC * (RF > RS ? RF : RS), 1) spectre_mix_regtile_mixedp(const RegtileArgs a) {
+// XP = experiment switches (tools/mixedp_stage_bench.hip; 0 in the library): bit 0 = a workgroup barrier between I2 and the store burst,
+// bit 1 = one behind the burst (in front of the reloads / the gate fetch)
+// Launched with WHOLE waves (mixedp_launch_threads): an LDS-DMA request uses all 64 lanes of a wave — lanes 32-63 fetch the second row
+// block of a pair — and at 60 x 60 the 480 threads of the team would leave wave 7, which owns row classes 56-59, with half its lanes.
+// The threads beyond the team (u >= RF and u >= RS) own neither rows nor bins and only take part in the barriers and the requests.
+template <int RF, int RS> constexpr int mixedp_launch_threads() { return (mixed_threads<RF, RS>() + 63) & ~63; }
+template <int RF, int RS, int P, bool FIRST = false, int S = 0, int XP = 0>
+__global__ void __launch_bounds__((mixedp_launch_threads<RF, RS>()), 1) spectre_mix_regtile_mixedp(const RegtileArgs a) {
   constexpr int D0 = FIRST ? 0 : RF - P;           // the deferred row blocks are [D0, D0 + P) of the order F1 uses them (the last ones: measured
                                                    // 1 % better than the first ones, 1.586 vs 1.605 ms)
   static_assert(S % 2 == 0 && S >= 0 && (S == 0 || (!FIRST && S <= D0)), "staged row blocks: the first S of F1's order, in pairs; the deferred ones are the last P");
@@ -354,6 +360,7 @@ __global__ void __launch_bounds__(kPC * (RF > RS ? RF : RS), 1) spectre_mix_regt
     //  1.56 ms.  Mixing the two directions at a finer grain costs more than the earlier requests gain.)
     float2 res[RF];
     static_for<0, RF>([&](auto nc) { constexpr int n1 = decltype(nc)::value; res[n1] = z[out_pos<RF>(n1)]; });
+    if constexpr ((XP & 1) != 0) { static_for<0, RF>([&](auto nc) { mp_pin1(res[decltype(nc)::value].x); mp_pin1(res[decltype(nc)::value].y); }); rt_lds_barrier(); }
     static_for<0, RF>([&](auto ic) {
       constexpr int i = decltype(ic)::value, q = decltype(row_q(ic))::value;
       if constexpr (i < D0 || i >= D0 + P) store_row(rs_out, ooff, out_sn, std::integral_constant<int, q>{}, res[q]);
@@ -368,6 +375,7 @@ __global__ void __launch_bounds__(kPC * (RF > RS ? RF : RS), 1) spectre_mix_regt
     } else {
       static_for<D0, D0 + P>([&](auto ic) { constexpr int q = decltype(row_q(ic))::value; store_row(rs_out, ooff, out_sn, std::integral_constant<int, q>{}, res[q]); });
     }
+    if constexpr ((XP & 2) != 0) rt_lds_barrier();
     static_for<S, RF>([&](auto ic) {
       constexpr int i = decltype(ic)::value, q = decltype(row_q(ic))::value;
       if constexpr (i < D0 || i >= D0 + P) z[q] = load_row(rs_next, voff, v_sn, std::integral_constant<int, q>{});

@@ -23,20 +23,20 @@ namespace sfft {
       if ((e = mixed_check_lds_layout(reinterpret_cast<const void*>(kern))) != hipSuccess) return e;                    \
       if (dev >= 0 && dev < 16) lds_opt_in[dev] = true;                                                                 \
     }                                                                                                                   \
-    hipLaunchKernelGGL(kern, dim3(a.n_wg), dim3(mixed_threads<RF_, RS_>()), lds, stream, a);                            \
+    hipLaunchKernelGGL(kern, dim3(a.n_wg), dim3(mixedp_launch_threads<RF_, RS_>()), lds, stream, a);                            \
     return hipGetLastError();                                                                                           \
   }
 // Same-box sweep at (256, n, 768), persistent vs one tile per workgroup (tools/mixedp_sweep.py, profiles/r02_mixedp_sweep.log):
 // 3000 1.511 vs 1.649 ms, 2560 1.268 vs 1.386, 2400 1.207 vs 1.343; no gain at 3072 (1.599 both), 3600 (1.961 vs 1.917) and 3840 (1.974 vs
 // 1.958) in round 2 (round 3: see below).
-SFFT_DEFINE_MIXEDP_LAUNCHER(60, 50, 24, 36)
-SFFT_DEFINE_MIXEDP_LAUNCHER(64, 40, 20, 0)
-SFFT_DEFINE_MIXEDP_LAUNCHER(60, 40, 24, 0)
+SFFT_DEFINE_MIXEDP_LAUNCHER(60, 50, 24, 16)
+SFFT_DEFINE_MIXEDP_LAUNCHER(64, 40, 20, 16)
+SFFT_DEFINE_MIXEDP_LAUNCHER(60, 40, 24, 16)
 // Round 3, with the tidied exchanges the persistent kernel also wins at the three lengths round 2 left to kernel_regtile_mixed.h (one box,
 // B = 768000 / n; one tile per workgroup / persistent at P = 12, 16, 20, 24, 28, 32): 3072 = 64 x 48 1.531 / 1.377 1.351 1.297 1.264 1.308
 // 1.739 (spills from 28); 3600 = 60 x 60 1.574 / 1.500 1.493 1.449 1.408 1.357 1.584; 3840 = 64 x 60 1.520 / 1.462 1.459 1.409 1.410
 // 1.350 1.573.
-SFFT_DEFINE_MIXEDP_LAUNCHER(64, 48, 24, 0)
-SFFT_DEFINE_MIXEDP_LAUNCHER(60, 60, 28, 0)
-SFFT_DEFINE_MIXEDP_LAUNCHER(64, 60, 28, 0)
+SFFT_DEFINE_MIXEDP_LAUNCHER(64, 48, 24, 16)
+SFFT_DEFINE_MIXEDP_LAUNCHER(60, 60, 28, 16)
+SFFT_DEFINE_MIXEDP_LAUNCHER(64, 60, 24, 16)
 }  // namespace sfft
