@@ -320,7 +320,7 @@ struct Choice {
   int RF = 0, RS = 0;      // n_fft = RF * RS
   bool wide = false;       // 32-channel tiles: whole 128-byte lines per row (kernel_regtile_wide.h; n_fft <= 1024, fast mode)
   int mode = 0;            // 0 fast, 1 general (row predicates / gate from global), 2 general + memory_fft, 3 row predicates only
-  bool mixedp = false;     // n_fft = 3000 / 2560 / 2400 / 3072 / 3600 / 3840, fp32 in/out, gate in LDS, 8-byte aligned rows: persistent kernel with deferred row blocks (kernel_regtile_mixedp.h)
+  bool mixedp = false;     // n_fft = 3000 / 2560 / 2400 / 3072 / 3600 / 3840, fp32 in/out, gate in LDS, 16-byte aligned input rows, 8-byte aligned output rows: persistent kernel with deferred and LDS-staged row blocks (kernel_regtile_mixedp.h)
   bool pipelined = false;  // n_fft = 4096 fast mode, fp32, 16-byte aligned rows: persistent software-pipelined kernel (kernel_regtile64p.h)
   // stockham
   int P = 0, S = 0, solo = 0;
@@ -408,8 +408,8 @@ int choose(const SpectreMixArgs* a, const Plan* plan, Choice* c) {
     c->wide = !wide_off && !ts->mixed && ts->tile_ch == 16 && n <= wide_max && n <= 2048 && (mode == 0 || mode == 3) && d_g % 32 == 0 && D % 32 == 0 && (!out_bf || in_bf);
     static const bool mixedp_off = [] { const char* e = tuning_env("SPECTRE_MIXEDP"); return e && atoi(e) == 0; }();
     c->mixedp = !mixedp_off && ts->mixed && (n == 3000 || n == 2560 || n == 2400 || n == 3072 || n == 3600 || n == 3840) && (mode == 0 || mode == 3) && a->in_dtype == SPECTRE_F32 && a->out_dtype == SPECTRE_F32 &&
-                reinterpret_cast<uintptr_t>(a->v) % 8 == 0 && reinterpret_cast<uintptr_t>(a->out) % 8 == 0 &&
-                a->v_sn % 2 == 0 && a->v_sb % 2 == 0 && a->out_sn % 2 == 0 && a->out_sb % 2 == 0 &&
+                reinterpret_cast<uintptr_t>(a->v) % 16 == 0 && reinterpret_cast<uintptr_t>(a->out) % 8 == 0 &&      // (input rows: 16-byte LDS-DMA requests, round 4)
+                a->v_sn % 4 == 0 && a->v_sb % 4 == 0 && a->out_sn % 2 == 0 && a->out_sb % 2 == 0 &&
                 a->v_sn * n * 4 < ((int64_t)1 << 31) && a->out_sn * n * 4 < ((int64_t)1 << 31);
     return SPECTRE_OK;
   }

@@ -241,6 +241,30 @@ def test_other_persistent_mixed_lengths_match_oracle(n, B, dN, D, G):
     assert_close(y.cpu().numpy(), spectral_mix_numpy(V.cpu().numpy(), gate.cpu().numpy(), None, n), what=f"n={n} ({B},{n + dN},{D})")
 
 
+@pytest.mark.parametrize("n", [3000, 3600])
+def test_persistent_mixed_lengths_input_views_and_alignment(n):
+    """Round 4: the persistent mixed-radix kernels request 16 row blocks of the next tile as 16-byte LDS-DMA lanes.  A channel-chunk view
+    (row stride 3 * D, 16-byte aligned) goes through them; a view whose first element is only 8-byte aligned takes the one-tile-per-workgroup
+    kernel instead (same results either way); several tiles per workgroup so that staged, deferred and reloaded blocks all occur."""
+    from fft_amd import describe, spectral_mix
+    torch.manual_seed(n)
+    B, D, G = 70, 96, 2
+    big = torch.randn(B, n, 3 * D + 4, device=DEV)
+    gate = torch.randn(B, G, n // 2 + 1, dtype=torch.complex64, device=DEV) * 0.3
+    for off, persistent in ((D, True), (D + 4, True), (D + 2, False)):
+        V = big[:, :, off:off + D]
+        assert (V.data_ptr() % 16 == 0) == persistent
+        assert describe(V, gate, None, n).startswith("regtile-mixed-pipelined") == persistent
+        y = spectral_mix(V, gate, None, n)
+        torch.cuda.synchronize()
+        ref = spectral_mix(V.contiguous(), gate, None, n, algo="stockham")
+        rms = float(ref.square().mean().sqrt())
+        assert float((y - ref).abs().max()) <= 2e-4 * rms
+        for (b, c) in [(0, 0), (B - 1, D - 2), (B // 2, 18)]:
+            want = spectral_mix_numpy(V[b:b + 1, :, c:c + 2].cpu().numpy(), gate[b:b + 1, c // (D // G):c // (D // G) + 1].cpu().numpy(), None, n)
+            assert_close(y[b:b + 1, :, c:c + 2].cpu().numpy(), want, what=f"n={n} view offset {off} column ({b},{c})")
+
+
 def test_n3000_persistent_many_tiles_guard_rows_and_repeatability():
     """Headline width with several tiles per workgroup; rows beyond N_out stay untouched; two launches are bit-identical; agreement with
     the one-tile-per-workgroup kernel it replaces (algo="stockham" is a third implementation) on whole tensors, oracle on columns."""
