@@ -98,6 +98,18 @@ __device__ __forceinline__ void p64_stageA1(float2 (&z)[64]) {      // type A st
   });
 }
 
+template <bool INV, class CB>
+__device__ __forceinline__ void p64_stageA1_cb(float2 (&z)[64], CB cb) {   // ... with a call-back behind every butterfly (SPREAD: one share of the LDS-DMA requests)
+  static_for<0, 8>([&](auto q0c) {
+    constexpr int q0 = decltype(q0c)::value;
+    bfly_plain<8, INV, q0, 8, 64>(z);
+    pin8<q0, 8>(z);
+    __builtin_amdgcn_sched_barrier(0);
+    cb(q0c);
+    __builtin_amdgcn_sched_barrier(0);
+  });
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence + s_barrier, and hipcc implements the
 // fence with s_waitcnt vmcnt(0): every barrier of the exchanges would drain the deferred stores and the prefetches that are meant to
 // travel DURING the exchanges.  Nothing that crosses waves goes through global memory here (a lane reads back only what its own wave
@@ -180,13 +192,23 @@ template <int SPLIT> constexpr int p64_younger_first() { return 4 * (8 - SPLIT) 
 //         per tile — same-box ablation: loads only 1.11 ms, stores only 0.90, neither 0.84).
 // OUT_BF16 = bf16 rows out (round to nearest even, like every other kernel here): a lane stores its 4 channels as 8 bytes.
 // BURST   = the stores of a tile leave back to back behind I2's last butterfly and a workgroup barrier (header comment)
-template <int SPLIT, int PF, bool WITH_MEM = false, bool IN_BF16 = false, bool OUT_BF16 = false, bool BURST = false>
+// SPREAD  = (round 4, fp32 rows, with BURST) every LOAD request and the deferred stores are issued one at a time between butterflies instead
+//         of in bursts: a wave sits in the issue stage of a load until the memory pipeline has taken it (~40 clocks per 1-KiB request with the
+//         chip's read rate saturated: phase times in profiles/r04_p64v_phase_times.log), and a burst of 16 keeps it there while its butterflies
+//         wait.  The LDS-DMA requests go behind the eight twiddle rows, the eight butterflies of I2's first stage and the eight groups of its
+//         last stage (24 shares); the deferred loads behind the eight groups of the middle phase; the deferred stores behind the eight
+//         columns of F1's second stage.  The store burst stays a burst (its two halves have to meet in the L2) and the reloads stay behind it.
+//         Same box, one process (tools/p64v_bench.hip batches 19-23, three boxes): deferred loads spread -2.8 %, LDS-DMA spread -1.7 %,
+//         both -4.8 %, + deferred stores -5.3 %, (SPLIT, PF) = (3, 3) instead of (4, 2) on top: -5.7 ... -7.5 % against the phased order.
+//         (Stores and loads mixed in the middle phase: +4 %; groups prefetched into spare registers instead of reloaded: +0.4 ... +2 %.)
+template <int SPLIT, int PF, bool WITH_MEM = false, bool IN_BF16 = false, bool OUT_BF16 = false, bool BURST = false, bool SPREAD = false>
 __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileArgs a) {
   constexpr int ESI = IN_BF16 ? 2 : 4, ESO = OUT_BF16 ? 2 : 4;   // bytes per input / output element
   constexpr float inv_n = 1.0f / 4096.0f;
   constexpr int GROUP_SLOT = IN_BF16 ? 2 * 1024 : 4 * 1024;     // bytes of one row group in a wave's landing slots
   static_assert(SPLIT >= 1 && SPLIT <= 8 && SPLIT * GROUP_SLOT * 8 <= kP64ImageBytes, "staging lives in the exchange image");
   static_assert(PF >= 0 && SPLIT + PF <= 8, "row groups: SPLIT through LDS, PF deferred / prefetched in registers, the rest behind their stores");
+  static_assert(!SPREAD || (BURST && !IN_BF16 && !WITH_MEM), "SPREAD: fp32 rows, phased order");
   constexpr int GP = 8 - PF;                       // first deferred / prefetched group
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* img = reinterpret_cast<float*>(smem);
@@ -437,6 +459,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
         });
         pin8<ka, 8>(z);
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (SPREAD) { static_for<ka * (4 * PF) / 8, (ka + 1) * (4 * PF) / 8>([&](auto ic) { pf_store(ic); }); __builtin_amdgcn_sched_barrier(0); }
         if constexpr (ka == 0) p64_barrier();      // every wave has emptied its landing slots (and finished E2's reads of the previous
                                                    // tile): the image may be written
         p64_write_col<ka, false>(z, img, p, u);
@@ -451,9 +474,11 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
     __builtin_amdgcn_sched_barrier(0);
     // ---- the quiet part of the tile starts: the deferred results of the previous tile leave, the same row groups of the next tile
     //      are requested into the registers they vacate
-    static_for<0, 4 * PF>([&](auto ic) { pf_store(ic); });
-    if constexpr (BURST) p64_barrier();            // PHASED I/O: every wave has issued its deferred stores before any wave requests the next rows
-    static_for<0, 4 * PF>([&](auto ic) { pf_load(ic); });
+    if constexpr (!SPREAD) {
+      static_for<0, 4 * PF>([&](auto ic) { pf_store(ic); });
+      if constexpr (BURST) p64_barrier();          // PHASED I/O: every wave has issued its deferred stores before any wave requests the next rows
+      static_for<0, 4 * PF>([&](auto ic) { pf_load(ic); });
+    }
     __builtin_amdgcn_sched_barrier(0);
     // ---- E1: position k1 -> image row k1, column (p, u); thread (p, s = u) reads row u, slot n2.  No barrier behind the last read:
     //      the image stays busy until the barrier in front of the middle phase's last stage.
@@ -487,6 +512,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
       });
       static_for<0, 8>([&](auto kac) {
         constexpr int ka = decltype(kac)::value;
+        if constexpr (SPREAD) { static_for<ka * (4 * PF) / 8, (ka + 1) * (4 * PF) / 8>([&](auto ic) { pf_load(ic); }); __builtin_amdgcn_sched_barrier(0); }
         fftA_stage2_group<8, 8, false, ka>(z);
         static_for<0, 8>([&](auto kbc) {
           constexpr int kb = decltype(kbc)::value, j = 8 * ka + kb, k2 = ka + 8 * kb;
@@ -536,7 +562,18 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
     float2 wa[8], wb[8];
     load_twiddles(wa, wb, u);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    static_for<0, SPLIT>([&](auto gc) { dma_group(rs_next, dma_voff(voff, v_sn), v_sn, gc); });
+    // SPREAD: request q = 4 g + m of the burst (fp32 rows: group g, instruction m), issued in 24 shares
+    constexpr int NDMA = 4 * SPLIT, NSHARE = 24;
+    [[maybe_unused]] auto dma_one = [&](auto qc) {
+      constexpr int q = decltype(qc)::value, g = q / 4, m = q % 4;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_next, (__attribute__((address_space(3))) void*)(slot + (4 * g + m) * 1024), 16,
+                                               voff + (uint32_t)((64 * g + 1024 * m) * v_sn * 4), 0, 0, 0);
+    };
+    [[maybe_unused]] auto dma_share = [&](auto sc) {
+      constexpr int sl = decltype(sc)::value;
+      static_for<sl * NDMA / NSHARE, (sl + 1) * NDMA / NSHARE>([&](auto qc) { dma_one(qc); });
+    };
+    if constexpr (!SPREAD) static_for<0, SPLIT>([&](auto gc) { dma_group(rs_next, dma_voff(voff, v_sn), v_sn, gc); });
     asm volatile("" ::: "memory");                 // the vmcnt() at the top of the loop counts on these being older than every store below
 
     // ---- conj twiddle, I2, stores (spectre.py:553) interleaved with the loads that refill the released registers -----------
@@ -544,10 +581,15 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
       constexpr int j = decltype(jc)::value, ja = j % 8, jb = j / 8;     // position j carries k1 = j
       if constexpr (ja > 0) z[j] = cmulc(z[j], wa[ja]);
       if constexpr (jb > 0) z[j] = cmulc(z[j], wb[jb]);
-      if constexpr (ja == 7) { pin8<8 * jb, 1>(z); __builtin_amdgcn_sched_barrier(0); }   // one wb at a time
+      if constexpr (ja == 7) {
+        pin8<8 * jb, 1>(z); __builtin_amdgcn_sched_barrier(0);   // one wb at a time
+        if constexpr (SPREAD) { dma_share(std::integral_constant<int, jb>{}); __builtin_amdgcn_sched_barrier(0); }
+      }
     });
     __builtin_amdgcn_sched_barrier(0);
-    p64_stageA1<true>(z);
+    if constexpr (SPREAD) p64_stageA1_cb<true>(z, [&](auto q0c) { dma_share(std::integral_constant<int, 8 + decltype(q0c)::value>{}); });
+    else p64_stageA1<true>(z);
+    asm volatile("" ::: "memory");
     {
       const uint32_t ooff = (uint32_t)(((long long)(u + 512 * h) * out_sn + 4 * pp) * ESO);
       if constexpr (BURST) {
@@ -557,7 +599,9 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
           pin8<8 * g, 1>(z);
           swap_group(std::integral_constant<int, g>{});
           __builtin_amdgcn_sched_barrier(0);
+          if constexpr (SPREAD) { dma_share(std::integral_constant<int, 16 + decltype(ic)::value>{}); __builtin_amdgcn_sched_barrier(0); }
         });
+        asm volatile("" ::: "memory");                  // (SPREAD: the last LDS-DMA request is older than every store below)
         p64_barrier();                                  // the eight waves start the burst together
         static_for<0, 8>([&](auto ic) {
           constexpr int g = (decltype(ic)::value + SPLIT) % 8;

@@ -15,7 +15,9 @@ hipError_t launch_regtile64p(const RegtileArgs& a, bool in_bf16, bool out_bf16, 
   auto kern = spectre_mix_regtile64p<4, 2>;                                           // fp32: 4 groups by LDS-DMA, 2 deferred, 2 behind their stores
   // round 4: the stores of a tile as one burst behind I2's last butterfly and a workgroup barrier: -4.0 ... -4.6 % for fp32 rows
   // (profiles/r04_burst_ab.log); bf16 rows +-0.3 %, memory_fft +0.5 %: those keep the round-3 order
-  if (burst && !with_mem && !in_bf16) kern = spectre_mix_regtile64p<4, 2, false, false, false, true>;
+  // ... and every load request and the deferred stores spread over the arithmetic, (SPLIT, PF) = (3, 3): another -5.7 ... -7.5 % on three boxes
+  // (tools/p64v_bench.hip batches 19-23, profiles/r04_p64v_ab_19_23_spread.log)
+  if (burst && !with_mem && !in_bf16) kern = spectre_mix_regtile64p<3, 3, false, false, false, true, true>;
   if (with_mem) kern = spectre_mix_regtile64p<4, 1, true>;                            // + memory_fft (spectre.py:548-549)
   // bf16 rows in: a row group is 16 KiB, so up to all eight groups of the next tile fit the image — measured on one box
   // (profiles/r03_p64x_ab_14.log, bf16 -> f32 / bf16 -> bf16): (3,3) 1.476 / 1.329 ms, (4,2) 1.481 / 1.329, (6,2) 1.485 / 1.361,

@@ -127,7 +127,7 @@ __device__ __forceinline__ void p64v_exchange_rest(float2 (&z)[64], float* img, 
 // top of the next tile (completion is in order, so vmcnt(N) with N = that count means "everything up to and including the LDS-DMA has
 // landed").  Steady state: per reloaded group 4 stores + 4 loads, per LDS-staged group 4 stores, the 5 gate loads.  First tile (the
 // prologue): the 4 loads of every register-loaded group and the 5 gate loads.  tools/isa_lint.py checks both against the ISA.
-template <int SPLIT, int PF> constexpr int p64v_younger() { return 8 * (8 - PF - SPLIT) + 4 * SPLIT + 5; }
+template <int SPLIT, int PF, int LATE = 0> constexpr int p64v_younger() { return 8 * (8 - PF - SPLIT - LATE) + 4 * LATE + 4 * SPLIT + 5; }
 template <int SPLIT> constexpr int p64v_younger_first() { return 4 * (8 - SPLIT) + 5; }
 
 // SPLIT = row groups (of 8) of the next tile that travel through LDS.
@@ -141,7 +141,7 @@ template <int SPLIT> constexpr int p64v_younger_first() { return 4 * (8 - SPLIT)
 //         right behind E2 of the previous one, none behind its stores (round 3: the fp32 kernel's late groups cost a memory latency
 //         per tile — same-box ablation: loads only 1.11 ms, stores only 0.90, neither 0.84).
 // OUT_BF16 = bf16 rows out (round to nearest even, like every other kernel here): a lane stores its 4 channels as 8 bytes.
-template <int SPLIT, int PF, bool WITH_MEM = false, bool IN_BF16 = false, bool OUT_BF16 = false, int GANGX = 0, int AUXD = 0, int AUXL = 0, int AUXS = 0, int PRIO = 0, int MAPX = 0, int DSPREAD = 0, int SYNCP = 0, int TSTAMP = 0, int PFL2 = 0, int STAG = 0>
+template <int SPLIT, int PF, bool WITH_MEM = false, bool IN_BF16 = false, bool OUT_BF16 = false, int GANGX = 0, int AUXD = 0, int AUXL = 0, int AUXS = 0, int PRIO = 0, int MAPX = 0, int DSPREAD = 0, int SYNCP = 0, int TSTAMP = 0, int PFL2 = 0, int STAG = 0, int PFSP = 0, int LATE = 0>
 __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) {
   constexpr int ESI = IN_BF16 ? 2 : 4, ESO = OUT_BF16 ? 2 : 4;   // bytes per input / output element
   constexpr float inv_n = 1.0f / 4096.0f;
@@ -248,6 +248,11 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
   float2 z[64];
   float4 dfr[PF > 0 ? 4 * PF : 1];                 // deferred results of the previous tile / prefetched rows of the next one
   static_for<0, 4 * PF>([&](auto ic) { dfr[decltype(ic)::value] = make_float4(0.f, 0.f, 0.f, 0.f); });   // (stored into an empty range before the first tile)
+  // LATE row groups [GP - LATE, GP): PREFETCHED like the deferred ones (spare registers, requested in the quiet middle of the tile) but
+  // stored with the burst: no row group is reloaded behind its store any more when SPLIT + PF + LATE = 8
+  static_assert(LATE >= 0 && SPLIT + PF + LATE <= 8, "row groups");
+  float4 lat[LATE > 0 ? 4 * LATE : 1];
+  static_for<0, (LATE > 0 ? 4 * LATE : 1)>([&](auto ic) { lat[decltype(ic)::value] = make_float4(0.f, 0.f, 0.f, 0.f); });
   char* obp = nullptr;                             // output tile of the deferred results
   float2 gstage[5];      // the next tile's gate bins on their way to LDS (4097 bins / 512 threads, rounded up; + 1 for the last)
 
@@ -433,6 +438,12 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
         dfr[decltype(ic)::value] = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
       }
     };
+    [[maybe_unused]] auto lat_load = [&](auto ic) {
+      constexpr int g = GP - LATE + decltype(ic)::value / 4, m = decltype(ic)::value % 4;
+      static_assert(!IN_BF16 || LATE == 0, "fp32 rows");
+      const pv_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_next, pf_voff + (uint32_t)((64 * g + 1024 * m) * v_sn * 4), 0, AUXL);
+      lat[decltype(ic)::value] = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
+    };
 
     // ---- F1: 64-point forward transform over n1 (register position 8g + e holds row g + 8e), then W_N^(u*k1) ------------
     //      Stage 1 works group by group, in the order the groups arrive: the deferred groups (prefetched a tile ago) first, then the
@@ -445,7 +456,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
         // the tile arrives: completion is in order, so once everything but the requests younger than the last LDS-DMA has retired the
         // staged groups are in the slots (p64v_younger; checked against the ISA by tools/isa_lint.py)
         if (it == 0) asm volatile("s_waitcnt vmcnt(%0) ; lint: first" :: "n"(p64v_younger_first<SPLIT>()) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0) ; lint: steady" :: "n"(p64v_younger<SPLIT, PF>()) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) ; lint: steady" :: "n"(p64v_younger<SPLIT, PF, LATE>()) : "memory");
         mark(1);                                   // stage 1 of the deferred groups, wait for the LDS-DMA
         static_for<0, SPLIT>([&](auto gc) { read_group(gc); });
       }
@@ -472,6 +483,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
         });
         vpin8<ka, 8>(z);
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (PFSP == 2) { static_for<ka * (4 * PF) / 8, (ka + 1) * (4 * PF) / 8>([&](auto ic) { pf_store(ic); }); __builtin_amdgcn_sched_barrier(0); }
         if constexpr (ka == 0) p64v_barrier();      // every wave has emptied its landing slots (and finished E2's reads of the previous
                                                    // tile): the image may be written
         if constexpr (ka == 0 && MAPX == 3) {       // (the barrier waited for lgkmcnt(0): the scalar atomic has returned)
@@ -493,9 +505,11 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
     //      are requested into the registers they vacate
     if constexpr (SYNCP == 2 || SYNCP == 5) gang_meet();
     if constexpr (SYNCP == 13) p64v_barrier();
-    static_for<0, 4 * PF>([&](auto ic) { pf_store(ic); });
-    if constexpr (SYNCP == 12 || SYNCP == 13 || SYNCP >= 15) p64v_barrier();
-    static_for<0, 4 * PF>([&](auto ic) { pf_load(ic); });
+    if constexpr (PFSP < 2) static_for<0, 4 * PF>([&](auto ic) { pf_store(ic); });
+    if constexpr ((SYNCP == 12 || SYNCP == 13 || SYNCP >= 15) && PFSP < 2) p64v_barrier();
+    // PFSP: the deferred loads one at a time between the butterflies of the middle phase (1) / of E1's read phase and the middle (2)
+    if constexpr (PFSP == 0) static_for<0, 4 * PF>([&](auto ic) { pf_load(ic); });
+    if constexpr (PFSP == 0) static_for<0, 4 * LATE>([&](auto ic) { lat_load(ic); });
     // (in the quiet part the touch is a plain dword load into a register that is looked at once, behind E2: an LDS-DMA here would put a
     //  vmcnt(0) in front of the exchange's LDS reads)
     [[maybe_unused]] uint32_t tch[8];
@@ -540,6 +554,9 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
       });
       static_for<0, 8>([&](auto kac) {
         constexpr int ka = decltype(kac)::value;
+        if constexpr (PFSP == 3) { static_for<ka * (4 * PF) / 8, (ka + 1) * (4 * PF) / 8>([&](auto ic) { pf_store(ic); }); }
+        if constexpr (PFSP >= 1) { static_for<ka * (4 * PF) / 8, (ka + 1) * (4 * PF) / 8>([&](auto ic) { pf_load(ic); }); __builtin_amdgcn_sched_barrier(0); }
+        if constexpr (PFSP >= 1 && LATE > 0) { static_for<ka * (4 * LATE) / 8, (ka + 1) * (4 * LATE) / 8>([&](auto ic) { lat_load(ic); }); __builtin_amdgcn_sched_barrier(0); }
         fftA_stage2_group<8, 8, false, ka>(z);
         static_for<0, 8>([&](auto kbc) {
           constexpr int kb = decltype(kbc)::value, j = 8 * ka + kb, k2 = ka + 8 * kb;
@@ -601,7 +618,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_next, (__attribute__((address_space(3))) void*)(slot + (4 * g + m) * 1024), 16,
                                                voff + (uint32_t)((64 * g + 1024 * m) * v_sn * 4), 0, 0, AUXD);
     };
-    constexpr int NDMA = 4 * SPLIT, NSLOT = DSPREAD == 2 ? 16 : 8;
+    constexpr int NDMA = 4 * SPLIT, NSLOT = DSPREAD == 3 ? 24 : DSPREAD == 2 ? 16 : 8;   // (3: ... and over the eight groups of I2's last stage)
     if constexpr (PFL2 == 1) static_for<SPLIT, GP>([&](auto gc) { l2_touch(gc); });
     if constexpr (PFL2 == 2) static_for<SPLIT, GP>([&](auto gc) { const uint32_t t = tch[decltype(gc)::value]; asm volatile("" :: "v"(t)); });
     if constexpr (PFL2 == 3) static_for<0, GP>([&](auto gc) { const uint32_t t = tch[decltype(gc)::value]; asm volatile("" :: "v"(t)); });
@@ -631,7 +648,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
       }
     });
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (DSPREAD == 2) p64v_stageA1_cb<true>(z, [&](auto q0c) {
+    if constexpr (DSPREAD == 2 || DSPREAD == 3) p64v_stageA1_cb<true>(z, [&](auto q0c) {
       constexpr int sl = 8 + decltype(q0c)::value;
       static_for<sl * NDMA / NSLOT, (sl + 1) * NDMA / NSLOT>([&](auto qc) { dma_one(qc); });
     });
@@ -706,6 +723,11 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
           vpin8<8 * g, 1>(z);
           swap_group(std::integral_constant<int, g>{});
           __builtin_amdgcn_sched_barrier(0);
+          if constexpr (DSPREAD == 3) {
+            constexpr int sl = 16 + decltype(ic)::value;
+            static_for<sl * NDMA / NSLOT, (sl + 1) * NDMA / NSLOT>([&](auto qc) { dma_one(qc); });
+            __builtin_amdgcn_sched_barrier(0);
+          }
         });
         if constexpr (SYNCP == 3 || SYNCP == 5 || SYNCP == 7) gang_meet();
         mark(7);                                   // DMA issue, twiddles, I2 (wave 0's own)
@@ -733,6 +755,11 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
               }
             } else {
               store16(rs_out, ooff + (uint32_t)((64 * g + 1024 * m) * out_sn * ESO), res);
+              if constexpr (LATE > 0 && g >= GP - LATE) {           // the prefetched rows of the next tile move in
+                const float4 nx = lat[4 * (g - (GP - LATE)) + m];
+                z[8 * g + 2 * m] = make_float2(nx.x, nx.y);
+                z[8 * g + 2 * m + 1] = make_float2(nx.z, nx.w);
+              }
             }
           });
           __builtin_amdgcn_sched_barrier(0);
@@ -742,7 +769,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
         mark(10);                                  // barrier behind the burst
         if constexpr (SYNCP == 15) __builtin_amdgcn_s_sleep(4);
         if constexpr (SYNCP == 16) __builtin_amdgcn_s_sleep(16);
-        static_for<SPLIT, GP>([&](auto gc) { load_group(rs_next, voff, v_sn, gc); });
+        static_for<SPLIT, GP - LATE>([&](auto gc) { load_group(rs_next, voff, v_sn, gc); });
         __builtin_amdgcn_sched_barrier(0);
       } else {
       if constexpr (SYNCP == 8) p64v_barrier();
