@@ -192,7 +192,7 @@ template <int SPLIT> constexpr int p64_younger_first() { return 4 * (8 - SPLIT) 
 //         per tile — same-box ablation: loads only 1.11 ms, stores only 0.90, neither 0.84).
 // OUT_BF16 = bf16 rows out (round to nearest even, like every other kernel here): a lane stores its 4 channels as 8 bytes.
 // BURST   = the stores of a tile leave back to back behind I2's last butterfly and a workgroup barrier (header comment)
-// SPREAD  = (round 4, fp32 rows, with BURST) every LOAD request and the deferred stores are issued one at a time between butterflies instead
+// SPREAD  = (round 4, with BURST) every LOAD request and the deferred stores are issued one at a time between butterflies instead
 //         of in bursts: a wave sits in the issue stage of a load until the memory pipeline has taken it (~40 clocks per 1-KiB request with the
 //         chip's read rate saturated: phase times in profiles/r04_p64v_phase_times.log), and a burst of 16 keeps it there while its butterflies
 //         wait.  The LDS-DMA requests go behind the eight twiddle rows, the eight butterflies of I2's first stage and the eight groups of its
@@ -201,6 +201,9 @@ template <int SPLIT> constexpr int p64_younger_first() { return 4 * (8 - SPLIT) 
 //         Same box, one process (tools/p64v_bench.hip batches 19-23, three boxes): deferred loads spread -2.8 %, LDS-DMA spread -1.7 %,
 //         both -4.8 %, + deferred stores -5.3 %, (SPLIT, PF) = (3, 3) instead of (4, 2) on top: -5.7 ... -7.5 % against the phased order.
 //         (Stores and loads mixed in the middle phase: +4 %; groups prefetched into spare registers instead of reloaded: +0.4 ... +2 %.)
+//         bf16 rows in (a row group is 16 KiB): (SPLIT, PF) = (5, 3) — nothing is reloaded behind its store — with the phased order and the
+//         three spreads: bf16 -> fp32 1.385 -> 1.312 ms (-5.2 %; (2,3) spread -2.6 %), bf16 -> bf16 1.319 -> 1.187 ms (-10 %) on one box
+//         (profiles/r04_p64v_bf16_spread.log).
 template <int SPLIT, int PF, bool WITH_MEM = false, bool IN_BF16 = false, bool OUT_BF16 = false, bool BURST = false, bool SPREAD = false>
 __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileArgs a) {
   constexpr int ESI = IN_BF16 ? 2 : 4, ESO = OUT_BF16 ? 2 : 4;   // bytes per input / output element
@@ -208,7 +211,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
   constexpr int GROUP_SLOT = IN_BF16 ? 2 * 1024 : 4 * 1024;     // bytes of one row group in a wave's landing slots
   static_assert(SPLIT >= 1 && SPLIT <= 8 && SPLIT * GROUP_SLOT * 8 <= kP64ImageBytes, "staging lives in the exchange image");
   static_assert(PF >= 0 && SPLIT + PF <= 8, "row groups: SPLIT through LDS, PF deferred / prefetched in registers, the rest behind their stores");
-  static_assert(!SPREAD || (BURST && !IN_BF16 && !WITH_MEM), "SPREAD: fp32 rows, phased order");
+  static_assert(!SPREAD || (BURST && !WITH_MEM), "SPREAD: phased order, no memory_fft");
   constexpr int GP = 8 - PF;                       // first deferred / prefetched group
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* img = reinterpret_cast<float*>(smem);
@@ -563,11 +566,19 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
     load_twiddles(wa, wb, u);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // SPREAD: request q = 4 g + m of the burst (fp32 rows: group g, instruction m), issued in 24 shares
-    constexpr int NDMA = 4 * SPLIT, NSHARE = 24;
+    constexpr int NDMA = (IN_BF16 ? 2 : 4) * SPLIT, NSHARE = 24;   // (bf16 rows: two requests per group, dma_group)
+    [[maybe_unused]] const uint32_t dvo = dma_voff(voff, v_sn);
     [[maybe_unused]] auto dma_one = [&](auto qc) {
-      constexpr int q = decltype(qc)::value, g = q / 4, m = q % 4;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_next, (__attribute__((address_space(3))) void*)(slot + (4 * g + m) * 1024), 16,
-                                               voff + (uint32_t)((64 * g + 1024 * m) * v_sn * 4), 0, 0, 0);
+      constexpr int q = decltype(qc)::value;
+      if constexpr (IN_BF16) {
+        constexpr int g = q / 2, mh = q % 2;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_next, (__attribute__((address_space(3))) void*)(slot + (2 * g + mh) * 1024), 16,
+                                                 dvo + (uint32_t)((64 * g + 2048 * mh) * v_sn * ESI), 0, 0, 0);
+      } else {
+        constexpr int g = q / 4, m = q % 4;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_next, (__attribute__((address_space(3))) void*)(slot + (4 * g + m) * 1024), 16,
+                                                 voff + (uint32_t)((64 * g + 1024 * m) * v_sn * 4), 0, 0, 0);
+      }
     };
     [[maybe_unused]] auto dma_share = [&](auto sc) {
       constexpr int sl = decltype(sc)::value;

@@ -5,7 +5,7 @@
 namespace sfft {
 hipError_t launch_regtile64p(const RegtileArgs& a, bool in_bf16, bool out_bf16, bool burst, hipStream_t stream) {
   const bool with_mem = a.mem != nullptr;
-  static std::atomic<bool> lds_opt_in[16][6];   // [device]: > 64 KiB of dynamic LDS needs a one-time opt-in (idempotent; the flag only saves the call)
+  static std::atomic<bool> lds_opt_in[16][7];   // [device]: > 64 KiB of dynamic LDS needs a one-time opt-in (idempotent; the flag only saves the call)
   // <SPLIT, PF>: SPLIT row groups of the next tile travel through LDS (LDS-DMA, requested before the stores), PF row groups have their
   // stores / loads moved out of the store/load burst to the end of F1 (16 registers each); the other 8 - SPLIT - PF groups are reloaded
   // behind their own stores.  Interleaved A/B on one box (profiles/r02_p64_ab_waits.log): (4,1) 1.591 ms, (4,2) 1.563, (4,3) 1.548,
@@ -27,8 +27,12 @@ hipError_t launch_regtile64p(const RegtileArgs& a, bool in_bf16, bool out_bf16, 
   // bf16 rows in / fp32 rows out (BASELINE config 2 read literally): phased I/O, pairs instead of gangs of four, 2 groups through LDS and
   // 3 deferred: -7.1 ... -7.6 % against the round-3 form (tools/p64v_bench.hip ... bf16, profiles/r04_p64v_bf16_in_ab.log)
   if (burst && in_bf16 && !out_bf16) kern = spectre_mix_regtile64p<2, 3, false, true, false, true>;
+  // ... third session of round 4: with every load request and the deferred stores spread over the arithmetic, five groups through LDS and
+  // three deferred (nothing reloaded behind its store): bf16 -> fp32 -5.2 %, bf16 -> bf16 (phased order, gangs of four) -10 %
+  if (burst && !with_mem && in_bf16 && !out_bf16) kern = spectre_mix_regtile64p<5, 3, false, true, false, true, true>;
+  if (burst && !with_mem && in_bf16 && out_bf16) kern = spectre_mix_regtile64p<5, 3, false, true, true, true, true>;
 
-  const int variant = in_bf16 ? (out_bf16 ? 3 : burst ? 5 : 2) : with_mem ? 1 : burst ? 4 : 0;
+  const int variant = in_bf16 ? (out_bf16 ? (burst && !with_mem ? 6 : 3) : burst && !with_mem ? 5 : 2) : with_mem ? 1 : burst ? 4 : 0;
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev < 0 || dev >= 16 || !lds_opt_in[dev][variant]) {

@@ -141,7 +141,7 @@ template <int SPLIT> constexpr int p64v_younger_first() { return 4 * (8 - SPLIT)
 //         right behind E2 of the previous one, none behind its stores (round 3: the fp32 kernel's late groups cost a memory latency
 //         per tile — same-box ablation: loads only 1.11 ms, stores only 0.90, neither 0.84).
 // OUT_BF16 = bf16 rows out (round to nearest even, like every other kernel here): a lane stores its 4 channels as 8 bytes.
-template <int SPLIT, int PF, bool WITH_MEM = false, bool IN_BF16 = false, bool OUT_BF16 = false, int GANGX = 0, int AUXD = 0, int AUXL = 0, int AUXS = 0, int PRIO = 0, int MAPX = 0, int DSPREAD = 0, int SYNCP = 0, int TSTAMP = 0, int PFL2 = 0, int STAG = 0, int PFSP = 0, int LATE = 0>
+template <int SPLIT, int PF, bool WITH_MEM = false, bool IN_BF16 = false, bool OUT_BF16 = false, int GANGX = 0, int AUXD = 0, int AUXL = 0, int AUXS = 0, int PRIO = 0, int MAPX = 0, int DSPREAD = 0, int SYNCP = 0, int TSTAMP = 0, int PFL2 = 0, int STAG = 0, int PFSP = 0, int LATE = 0, int RLF = 0>
 __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) {
   constexpr int ESI = IN_BF16 ? 2 : 4, ESO = OUT_BF16 ? 2 : 4;   // bytes per input / output element
   constexpr float inv_n = 1.0f / 4096.0f;
@@ -389,8 +389,13 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
     const __amdgpu_buffer_rsrc_t rs = rsrc_in(vb, a.v_sn);
     static_for<0, SPLIT>([&](auto gc) { dma_group(rs, dma_voff(voff, a.v_sn), a.v_sn, gc); });
     asm volatile("" ::: "memory");
-    static_for<SPLIT, 8>([&](auto gc) { load_group(rs, voff, a.v_sn, gc); });
-    gate_fetch(gp);
+    // RLF: the row groups that used to be reloaded behind the stores, and the gate bins, are requested at the START of their own tile, between
+    // the butterflies of the deferred groups (which are already there) — not at the end of the previous one behind its store burst
+    if constexpr (RLF) static_for<GP, 8>([&](auto gc) { load_group(rs, voff, a.v_sn, gc); });
+    else {
+      static_for<SPLIT, 8>([&](auto gc) { load_group(rs, voff, a.v_sn, gc); });
+      gate_fetch(gp);
+    }
   }
 
   for (int it = 0; MAPX == 3 || it < a.tpw; ++it) {
@@ -459,6 +464,15 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
         else asm volatile("s_waitcnt vmcnt(%0) ; lint: steady" :: "n"(p64v_younger<SPLIT, PF, LATE>()) : "memory");
         mark(1);                                   // stage 1 of the deferred groups, wait for the LDS-DMA
         static_for<0, SPLIT>([&](auto gc) { read_group(gc); });
+      }
+      if constexpr (RLF != 0 && i < PF) {
+        constexpr int R = GP - SPLIT;                                        // groups that are neither staged nor deferred
+        const __amdgpu_buffer_rsrc_t rs_cur = rsrc_in(vb, v_sn);
+        static_for<0, R>([&](auto rc) {
+          if constexpr (decltype(rc)::value % PF == i) load_group(rs_cur, pf_voff, v_sn, std::integral_constant<int, SPLIT + decltype(rc)::value>{});
+        });
+        if constexpr (i == PF - 1) gate_fetch(gp);
+        __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr (i == PF + SPLIT && TSTAMP == 2) { vpin8<8 * ((PF + SPLIT - 1) < PF ? GP + PF + SPLIT - 1 : SPLIT - 1), 1>(z); mark(2); }   // staged groups read + stage 1
       swap_group(std::integral_constant<int, g>{});
@@ -612,13 +626,20 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // DSPREAD: 0 = all 4 * SPLIT LDS-DMA requests in one burst; 1 = spread over the conj-twiddle multiplications (one share per 8 positions);
     // 2 = spread over the twiddle multiplications and the eight butterflies of I2's first stage
+    [[maybe_unused]] const uint32_t dvo = dma_voff(voff, v_sn);
     auto dma_one = [&](auto qc) {
-      constexpr int q = decltype(qc)::value, g = q / 4, m = q % 4;
-      static_assert(!IN_BF16 || DSPREAD == 0, "fp32 rows only");
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_next, (__attribute__((address_space(3))) void*)(slot + (4 * g + m) * 1024), 16,
-                                               voff + (uint32_t)((64 * g + 1024 * m) * v_sn * 4), 0, 0, AUXD);
+      constexpr int q = decltype(qc)::value;
+      if constexpr (IN_BF16) {                       // two requests per group (dma_group)
+        constexpr int g = q / 2, mh = q % 2;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_next, (__attribute__((address_space(3))) void*)(slot + (2 * g + mh) * 1024), 16,
+                                                 dvo + (uint32_t)((64 * g + 2048 * mh) * v_sn * ESI), 0, 0, AUXD);
+      } else {
+        constexpr int g = q / 4, m = q % 4;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_next, (__attribute__((address_space(3))) void*)(slot + (4 * g + m) * 1024), 16,
+                                                 voff + (uint32_t)((64 * g + 1024 * m) * v_sn * 4), 0, 0, AUXD);
+      }
     };
-    constexpr int NDMA = 4 * SPLIT, NSLOT = DSPREAD == 3 ? 24 : DSPREAD == 2 ? 16 : 8;   // (3: ... and over the eight groups of I2's last stage)
+    constexpr int NDMA = (IN_BF16 ? 2 : 4) * SPLIT, NSLOT = DSPREAD == 3 ? 24 : DSPREAD == 2 ? 16 : 8;   // (3: ... and over the eight groups of I2's last stage)
     if constexpr (PFL2 == 1) static_for<SPLIT, GP>([&](auto gc) { l2_touch(gc); });
     if constexpr (PFL2 == 2) static_for<SPLIT, GP>([&](auto gc) { const uint32_t t = tch[decltype(gc)::value]; asm volatile("" :: "v"(t)); });
     if constexpr (PFL2 == 3) static_for<0, GP>([&](auto gc) { const uint32_t t = tch[decltype(gc)::value]; asm volatile("" :: "v"(t)); });
@@ -769,7 +790,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
         mark(10);                                  // barrier behind the burst
         if constexpr (SYNCP == 15) __builtin_amdgcn_s_sleep(4);
         if constexpr (SYNCP == 16) __builtin_amdgcn_s_sleep(16);
-        static_for<SPLIT, GP - LATE>([&](auto gc) { load_group(rs_next, voff, v_sn, gc); });
+        if constexpr (RLF == 0) static_for<SPLIT, GP - LATE>([&](auto gc) { load_group(rs_next, voff, v_sn, gc); });
         __builtin_amdgcn_sched_barrier(0);
       } else {
       if constexpr (SYNCP == 8) p64v_barrier();
@@ -806,7 +827,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
       }
     obp = ob;
     if constexpr (SYNCP == 14) p64v_barrier();
-    gate_fetch(gpn);     // committed to LDS at the end of the next tile's F1 (after the last tile: a harmless re-read of this tile's bins)
+    if constexpr (RLF == 0) gate_fetch(gpn);     // committed to LDS at the end of the next tile's F1 (after the last tile: a harmless re-read of this tile's bins)
     if constexpr (MAPX == 3) { cur_t = nxt_t; nxt_t = fut_t; }
     mark(11);                                      // reload issue + gate fetch issue
   }  // tile loop
