@@ -203,7 +203,8 @@ template <int SPLIT> constexpr int p64_younger_first() { return 4 * (8 - SPLIT) 
 //         (Stores and loads mixed in the middle phase: +4 %; groups prefetched into spare registers instead of reloaded: +0.4 ... +2 %.)
 //         bf16 rows in (a row group is 16 KiB): (SPLIT, PF) = (5, 3) — nothing is reloaded behind its store — with the phased order and the
 //         three spreads: bf16 -> fp32 1.385 -> 1.312 ms (-5.2 %; (2,3) spread -2.6 %), bf16 -> bf16 1.319 -> 1.187 ms (-10 %) on one box
-//         (profiles/r04_p64v_bf16_spread.log).
+//         (profiles/r04_p64v_bf16_spread.log).  fp32 rows + memory_fft, (4, 1): phased order -7.7 %, + the three spreads -11.5 % (2.025 -> 1.793 ms,
+//         profiles/r04_p64v_mem_spread.log).
 template <int SPLIT, int PF, bool WITH_MEM = false, bool IN_BF16 = false, bool OUT_BF16 = false, bool BURST = false, bool SPREAD = false>
 __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileArgs a) {
   constexpr int ESI = IN_BF16 ? 2 : 4, ESO = OUT_BF16 ? 2 : 4;   // bytes per input / output element
@@ -211,7 +212,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
   constexpr int GROUP_SLOT = IN_BF16 ? 2 * 1024 : 4 * 1024;     // bytes of one row group in a wave's landing slots
   static_assert(SPLIT >= 1 && SPLIT <= 8 && SPLIT * GROUP_SLOT * 8 <= kP64ImageBytes, "staging lives in the exchange image");
   static_assert(PF >= 0 && SPLIT + PF <= 8, "row groups: SPLIT through LDS, PF deferred / prefetched in registers, the rest behind their stores");
-  static_assert(!SPREAD || (BURST && !WITH_MEM), "SPREAD: phased order, no memory_fft");
+  static_assert(!SPREAD || BURST, "SPREAD: with the phased order");
   constexpr int GP = 8 - PF;                       // first deferred / prefetched group
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* img = reinterpret_cast<float*>(smem);

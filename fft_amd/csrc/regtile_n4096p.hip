@@ -5,7 +5,7 @@
 namespace sfft {
 hipError_t launch_regtile64p(const RegtileArgs& a, bool in_bf16, bool out_bf16, bool burst, hipStream_t stream) {
   const bool with_mem = a.mem != nullptr;
-  static std::atomic<bool> lds_opt_in[16][7];   // [device]: > 64 KiB of dynamic LDS needs a one-time opt-in (idempotent; the flag only saves the call)
+  static std::atomic<bool> lds_opt_in[16][8];   // [device]: > 64 KiB of dynamic LDS needs a one-time opt-in (idempotent; the flag only saves the call)
   // <SPLIT, PF>: SPLIT row groups of the next tile travel through LDS (LDS-DMA, requested before the stores), PF row groups have their
   // stores / loads moved out of the store/load burst to the end of F1 (16 registers each); the other 8 - SPLIT - PF groups are reloaded
   // behind their own stores.  Interleaved A/B on one box (profiles/r02_p64_ab_waits.log): (4,1) 1.591 ms, (4,2) 1.563, (4,3) 1.548,
@@ -19,6 +19,7 @@ hipError_t launch_regtile64p(const RegtileArgs& a, bool in_bf16, bool out_bf16, 
   // (tools/p64v_bench.hip batches 19-23, profiles/r04_p64v_ab_19_23_spread.log)
   if (burst && !with_mem && !in_bf16) kern = spectre_mix_regtile64p<3, 3, false, false, false, true, true>;
   if (with_mem) kern = spectre_mix_regtile64p<4, 1, true>;                            // + memory_fft (spectre.py:548-549)
+  if (with_mem && burst && !in_bf16) kern = spectre_mix_regtile64p<4, 1, true, false, false, true, true>;   // ... phased order + spread requests: -11.5 %
   // bf16 rows in: a row group is 16 KiB, so up to all eight groups of the next tile fit the image — measured on one box
   // (profiles/r03_p64x_ab_14.log, bf16 -> f32 / bf16 -> bf16): (3,3) 1.476 / 1.329 ms, (4,2) 1.481 / 1.329, (6,2) 1.485 / 1.361,
   // (7,1) 1.509 / 1.383, (6,0) 1.528 / 1.369, (8,0) 1.566 / 1.435: requesting everything early does NOT pay, the deferred stores do
@@ -32,7 +33,7 @@ hipError_t launch_regtile64p(const RegtileArgs& a, bool in_bf16, bool out_bf16, 
   if (burst && !with_mem && in_bf16 && !out_bf16) kern = spectre_mix_regtile64p<5, 3, false, true, false, true, true>;
   if (burst && !with_mem && in_bf16 && out_bf16) kern = spectre_mix_regtile64p<5, 3, false, true, true, true, true>;
 
-  const int variant = in_bf16 ? (out_bf16 ? (burst && !with_mem ? 6 : 3) : burst && !with_mem ? 5 : 2) : with_mem ? 1 : burst ? 4 : 0;
+  const int variant = in_bf16 ? (out_bf16 ? (burst && !with_mem ? 6 : 3) : burst && !with_mem ? 5 : 2) : with_mem ? (burst ? 7 : 1) : burst ? 4 : 0;
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev < 0 || dev >= 16 || !lds_opt_in[dev][variant]) {

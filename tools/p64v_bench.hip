@@ -63,11 +63,18 @@ int main(int argc, char** argv) {
   hipLaunchKernelGGL(to_bf16, dim3(4096), dim3(256), 0, 0, v, vb16, (size_t)B * N * D);
   CK(hipDeviceSynchronize());
   RegtileArgs lb = la; lb.v = vb16;
+  const bool memv = argc > 3 && !strcmp(argv[3], "mem");        // fp32 rows + memory_fft
+  float* memb = nullptr;
+  if (memv) { CK(hipMalloc(&memb, (size_t)F * D * 8)); CK(hipMemcpy(memb, gate, (size_t)F * D * 8, hipMemcpyDeviceToDevice)); }
+  RegtileArgs lm = la; lm.mem = memb;
   const bool bfo = argc > 3 && !strcmp(argv[3], "bf16out");      // bf16 rows in AND out
   const bool bf = (argc > 3 && !strcmp(argv[3], "bf16")) || bfo;
   std::vector<Variant> vs;
   auto add = [&](const char* name, std::function<void()> f) { if (strstr(name, filter)) vs.push_back({name, f, {}}); };
-  if (!bf) {
+  if (memv) {
+    add("LIBRARY <4,1> + memory_fft", mk(spectre_mix_regtile64p<4, 1, true>, lm, 2, kP64LdsTotal));
+#include "p64v_variants_mem.inc"
+  } else if (!bf) {
     add("LIBRARY <4,2>", mk(spectre_mix_regtile64p<4, 2>, la, 2, kP64LdsTotal));
     add("copy    <4,2> (must equal the library)", mk(spectre_mix_p64v<4, 2>, la, 2));
 #include "p64v_variants.inc"
@@ -81,9 +88,10 @@ int main(int argc, char** argv) {
 
   // ---- correctness against the library kernel
   {
-    RegtileArgs r = bf ? lb : la; r.out = out_ref;
+    RegtileArgs r = memv ? lm : bf ? lb : la; r.out = out_ref;
     CK(hipMemset(out_ref, 0xff, (size_t)B * N * D * 4));
-    if (bfo) mk(spectre_mix_regtile64p<3, 3, false, true, true>, r, 4, kP64LdsTotal)();
+    if (memv) mk(spectre_mix_regtile64p<4, 1, true>, r, 2, kP64LdsTotal)();
+    else if (bfo) mk(spectre_mix_regtile64p<3, 3, false, true, true>, r, 4, kP64LdsTotal)();
     else if (bf) mk(spectre_mix_regtile64p<3, 3, false, true>, r, 4, kP64LdsTotal)(); else mk(spectre_mix_regtile64p<4, 2>, r, 2, kP64LdsTotal)();
     CK(hipDeviceSynchronize());
     std::vector<float> ho((size_t)N * D), hr((size_t)N * D);
