@@ -44,6 +44,8 @@ template <int RF, int RS, int XV = SFFT_EXCHANGE_B128(RF, RS)> constexpr int gat
 }
 template <int RF, int RS> constexpr int gate_grad_lds_total() { return gate_grad_image_bytes<RF, RS>() + (RF * RS / 2 + 1) * 8; }
 
+constexpr bool kGateGradSpread = false;  // round 4: the 64-load burst behind the partner exchange moved into the product phase, one more pair per
+                                         // product: 2.66 -> 2.75 ms (f32), 2.19 -> 2.26 (bf16) on one box — the product phase is request-bound already; not shipped
 // Workgroup barrier that orders LDS traffic only: __syncthreads() is a fence + s_barrier and hipcc implements the fence with
 // s_waitcnt vmcnt(0), which would wait for the next tile's rows requested just before it (kernel_regtile64p.h has the long story).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -178,7 +180,8 @@ __global__ void __launch_bounds__(kPC * RS) spectre_gate_grad_regtile(const Gate
         });
       });
     });
-    static_for<0, NS>([&](auto tc) {
+    // (kGateGradSpread: these 64 loads per thread one pair at a time behind the products below instead of back to back here — measured slower)
+    if constexpr (!kGateGradSpread) static_for<0, NS>([&](auto tc) {
       static_for<0, RAS>([&](auto kac) {
         static_for<RBS / 2, RBS>([&](auto kbc) {
           constexpr int j = decltype(tc)::value * RS + RBS * decltype(kac)::value + decltype(kbc)::value;
@@ -216,6 +219,7 @@ __global__ void __launch_bounds__(kPC * RS) spectre_gate_grad_regtile(const Gate
             acc[k1 + RF * k2] = cur;
           }
           load_row(jt + a.S, std::integral_constant<int, j>{}, v_sn, d_sn, p, u, more);       // z[j] is dead
+          if constexpr (kGateGradSpread) load_row(jt + a.S, std::integral_constant<int, j + RBS / 2>{}, v_sn, d_sn, p, u, more);   // ... and so is its upper-half twin
         });
       });
       if constexpr (t == 0) {                         // Nyquist: k1 = 0, k2 = RS/2 (ka = 0, kb = RBS/2): Re(A) Im(A)
