@@ -118,8 +118,10 @@ __device__ __forceinline__ void p64_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 // workgroups that walk through adjacent tiles in step (launch: n_wg is a multiple of it): the 2 that share a 128-byte line of fp32 rows,
 // the 4 that share a line of bf16 rows.  bf16 rows in / fp32 rows out with the round-4 phased I/O: 2 — the pair that matters is the one
-// whose half-line STORES meet (gang 4: 1.466 ms, gang 2: 1.435 on one box; profiles/r04_p64v_bf16_in_ab.log)
-constexpr int p64_gang(bool in_bf16, bool out_bf16, bool burst) { return (in_bf16 && out_bf16) || (in_bf16 && !burst) || (out_bf16 && !in_bf16) ? 4 : 2; }
+// whose half-line STORES meet (gang 4: 1.466 ms, gang 2: 1.435 on one box; profiles/r04_p64v_bf16_in_ab.log) — until the requests were spread
+// over the arithmetic: with (5, 3) + SPREAD the gang of four is ahead again (1.352 against 1.374 ms, profiles/r04_p64v_bf16_spread.log), so
+// every bf16 variant walks in fours
+constexpr int p64_gang(bool in_bf16, bool out_bf16, bool burst) { (void)burst; return in_bf16 || out_bf16 ? 4 : 2; }
 
 // One exchange = position j of thread (p, u) -> image row j, column (p, u); thread (p, u) then reads row u, slots 0..63.  One float
 // plane at a time (the tile is 256 KiB, the image 136 KiB).  The scattered dword writes are ds_write2st64_b32 (the LDS takes a store's

@@ -496,7 +496,7 @@ int launch(const SpectreMixArgs* a, const Plan* plan, const Choice& c, bool conj
       // round 4: store burst behind a workgroup barrier + phased I/O (fp32 rows out).  SPECTRE_P64_BURST=0: the round-3 order (tuning aid)
       static const bool burst_off = [] { const char* e2 = tuning_env("SPECTRE_P64_BURST"); return e2 && atoi(e2) == 0; }();
       const bool burst = !burst_off && !a->mem;
-      const int gang = ((ib && ob) || (ib && !burst) || (ob && !ib)) ? 4 : 2;   // = p64_gang() of kernel_regtile64p.h: workgroups that walk in step
+      const int gang = (ib || ob) ? 4 : 2;   // = p64_gang() of kernel_regtile64p.h: workgroups that walk in step
       const int slots = std::max(gang, ncu / gang * gang);
       k.tpw = forced > 0 ? forced : std::max(1, (k.n_tiles + slots - 1) / slots);
       k.n_wg = gang * ((k.n_tiles + gang * k.tpw - 1) / (gang * k.tpw));
