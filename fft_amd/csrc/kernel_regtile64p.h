@@ -154,8 +154,11 @@ __device__ __forceinline__ void p64_write_col(float2 (&z)[64], float* img, int p
 //   barrier | read re | barrier | write im | barrier | read im [| barrier].
 // The chunk order of the reads (slots 0-3, 8-11, ..., then 4-7, 12-15, ...) is the order in which the next stage's first butterflies
 // consume them.  LAST_BARRIER = false leaves the image busy: the caller puts the barrier in front of its next write.
-template <bool LAST_BARRIER>
-__device__ __forceinline__ void p64_exchange_rest(float2 (&z)[64], float* img, int p, int u) {
+// CB: called behind each of the three barriers (SPREAD: a share of the deferred loads — a wave that has just passed a barrier of an exchange
+// waits for the LDS anyway, so the time a request spends in the issue stage there is free)
+struct P64NoCb { template <class T> __device__ __forceinline__ void operator()(T) const {} };
+template <bool LAST_BARRIER, class CB = P64NoCb>
+__device__ __forceinline__ void p64_exchange_rest(float2 (&z)[64], float* img, int p, int u, CB cb = CB{}) {
   constexpr int RW = 8 * 68, PS = 68;
   const float* rd = img + u * RW + p * PS;
   auto read_plane = [&](auto is_im) {
@@ -167,10 +170,13 @@ __device__ __forceinline__ void p64_exchange_rest(float2 (&z)[64], float* img, i
     });
   };
   p64_barrier();
+  cb(std::integral_constant<int, 0>{});
   read_plane(std::false_type{});
   p64_barrier();
+  cb(std::integral_constant<int, 1>{});
   static_for<0, 8>([&](auto cc) { p64_write_col<decltype(cc)::value, true>(z, img, p, u); });
   p64_barrier();
+  cb(std::integral_constant<int, 2>{});
   read_plane(std::true_type{});
   if constexpr (LAST_BARRIER) p64_barrier();       // image free again
 }
@@ -198,7 +204,8 @@ template <int SPLIT> constexpr int p64_younger_first() { return 4 * (8 - SPLIT) 
 //         of in bursts: a wave sits in the issue stage of a load until the memory pipeline has taken it (~40 clocks per 1-KiB request with the
 //         chip's read rate saturated: phase times in profiles/r04_p64v_phase_times.log), and a burst of 16 keeps it there while its butterflies
 //         wait.  The LDS-DMA requests go behind the eight twiddle rows, the eight butterflies of I2's first stage and the eight groups of its
-//         last stage (24 shares); the deferred loads behind the eight groups of the middle phase; the deferred stores behind the eight
+//         last stage (24 shares); the deferred loads behind the three barriers of E1 (half of them: -1.5 ... -2.9 % on three boxes; ALL of
+//         them there +1 %, the gaps of E1 and E2 -0.7 %) and the eight groups of the middle phase; the deferred stores behind the eight
 //         columns of F1's second stage.  The store burst stays a burst (its two halves have to meet in the L2) and the reloads stay behind it.
 //         Same box, one process (tools/p64v_bench.hip batches 19-23, three boxes): deferred loads spread -2.8 %, LDS-DMA spread -1.7 %,
 //         both -4.8 %, + deferred stores -5.3 %, (SPLIT, PF) = (3, 3) instead of (4, 2) on top: -5.7 ... -7.5 % against the phased order.
@@ -488,7 +495,11 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
     __builtin_amdgcn_sched_barrier(0);
     // ---- E1: position k1 -> image row k1, column (p, u); thread (p, s = u) reads row u, slot n2.  No barrier behind the last read:
     //      the image stays busy until the barrier in front of the middle phase's last stage.
-    p64_exchange_rest<false>(z, img, p, u);
+    if constexpr (SPREAD) p64_exchange_rest<false>(z, img, p, u, [&](auto kc) {       // half of the deferred loads in E1's three gaps ...
+      constexpr int k = decltype(kc)::value, H = (4 * PF) / 2;
+      static_for<k * H / 3, (k + 1) * H / 3>([&](auto ic) { pf_load(ic); });
+    });
+    else p64_exchange_rest<false>(z, img, p, u);
 
     // ---- middle: F2 -> gate -> I1 (kernel_regtile.h; bin of register (ka, kb): k = k1 + 64 k2, k2 = ka + 8 kb) -------------
     {
@@ -518,7 +529,11 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
       });
       static_for<0, 8>([&](auto kac) {
         constexpr int ka = decltype(kac)::value;
-        if constexpr (SPREAD) { static_for<ka * (4 * PF) / 8, (ka + 1) * (4 * PF) / 8>([&](auto ic) { pf_load(ic); }); __builtin_amdgcn_sched_barrier(0); }
+        if constexpr (SPREAD) {                      // ... the other half behind the eight groups of the middle phase
+          constexpr int H = (4 * PF) / 2, R = 4 * PF - H;
+          static_for<H + ka * R / 8, H + (ka + 1) * R / 8>([&](auto ic) { pf_load(ic); });
+          __builtin_amdgcn_sched_barrier(0);
+        }
         fftA_stage2_group<8, 8, false, ka>(z);
         static_for<0, 8>([&](auto kbc) {
           constexpr int kb = decltype(kbc)::value, j = 8 * ka + kb, k2 = ka + 8 * kb;

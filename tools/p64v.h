@@ -102,8 +102,9 @@ __device__ __forceinline__ void p64v_write_col(float2 (&z)[64], float* img, int 
 //   barrier | read re | barrier | write im | barrier | read im [| barrier].
 // The chunk order of the reads (slots 0-3, 8-11, ..., then 4-7, 12-15, ...) is the order in which the next stage's first butterflies
 // consume them.  LAST_BARRIER = false leaves the image busy: the caller puts the barrier in front of its next write.
-template <bool LAST_BARRIER>
-__device__ __forceinline__ void p64v_exchange_rest(float2 (&z)[64], float* img, int p, int u) {
+struct P64vNoCb { template <class T> __device__ __forceinline__ void operator()(T) const {} };
+template <bool LAST_BARRIER, class CB = P64vNoCb>
+__device__ __forceinline__ void p64v_exchange_rest(float2 (&z)[64], float* img, int p, int u, CB cb = CB{}) {
   constexpr int RW = 8 * 68, PS = 68;
   const float* rd = img + u * RW + p * PS;
   auto read_plane = [&](auto is_im) {
@@ -115,10 +116,13 @@ __device__ __forceinline__ void p64v_exchange_rest(float2 (&z)[64], float* img, 
     });
   };
   p64v_barrier();
+  cb(std::integral_constant<int, 0>{});
   read_plane(std::false_type{});
   p64v_barrier();
+  cb(std::integral_constant<int, 1>{});
   static_for<0, 8>([&](auto cc) { p64v_write_col<decltype(cc)::value, true>(z, img, p, u); });
   p64v_barrier();
+  cb(std::integral_constant<int, 2>{});
   read_plane(std::true_type{});
   if constexpr (LAST_BARRIER) p64v_barrier();       // image free again
 }
@@ -479,7 +483,9 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
       bfly_plain<8, false, 8 * g, 1, 64>(z);       // over e -> ka at position 8g + ka (W_64^(g ka) is applied by the column butterflies below)
       vpin8<8 * g, 1>(z);
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (PFSP == 6 && i >= PF) { static_for<i * (4 * PF) / 16, (i + 1) * (4 * PF) / 16>([&](auto ic2) { pf_store(ic2); }); __builtin_amdgcn_sched_barrier(0); }
     });
+    if constexpr (PFSP == 6) static_for<0, PF * (4 * PF) / 16>([&](auto ic2) { pf_store(ic2); });   // (the shares of the first PF slots: behind the wait for the LDS-DMA they would be counted as younger)
     if constexpr (TSTAMP == 2) { vpin8<8 * (GP - 1), 1>(z); mark(3); }   // wait for the reloaded groups + their stage 1
     {
       float2 wa[8], wb[8];
@@ -497,7 +503,8 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
         });
         vpin8<ka, 8>(z);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (PFSP == 2) { static_for<ka * (4 * PF) / 8, (ka + 1) * (4 * PF) / 8>([&](auto ic) { pf_store(ic); }); __builtin_amdgcn_sched_barrier(0); }
+        if constexpr (PFSP == 2 || PFSP == 4 || PFSP == 5 || PFSP == 7 || PFSP == 8) { static_for<ka * (4 * PF) / 8, (ka + 1) * (4 * PF) / 8>([&](auto ic) { pf_store(ic); }); __builtin_amdgcn_sched_barrier(0); }
+        if constexpr (PFSP == 6) { static_for<(8 + ka) * (4 * PF) / 16, (9 + ka) * (4 * PF) / 16>([&](auto ic) { pf_store(ic); }); __builtin_amdgcn_sched_barrier(0); }
         if constexpr (ka == 0) p64v_barrier();      // every wave has emptied its landing slots (and finished E2's reads of the previous
                                                    // tile): the image may be written
         if constexpr (ka == 0 && MAPX == 3) {       // (the barrier waited for lgkmcnt(0): the scalar atomic has returned)
@@ -538,7 +545,30 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
     __builtin_amdgcn_sched_barrier(0);
     // ---- E1: position k1 -> image row k1, column (p, u); thread (p, s = u) reads row u, slot n2.  No barrier behind the last read:
     //      the image stays busy until the barrier in front of the middle phase's last stage.
-    p64v_exchange_rest<false>(z, img, p, u);
+    [[maybe_unused]] auto pf_load_slot = [&](auto sc) {       // PFSP 5 / 6: the deferred loads over 14 slots — E1's three gaps, the middle's eight groups, E2's three gaps
+      constexpr int sl = decltype(sc)::value, L = 4 * PF;
+      static_for<sl * L / 14, (sl + 1) * L / 14>([&](auto ic) { pf_load(ic); });
+    };
+    if constexpr (PFSP == 5 || PFSP == 6) p64v_exchange_rest<false>(z, img, p, u, [&](auto kc) { pf_load_slot(kc); });
+    else if constexpr (PFSP == 7) p64v_exchange_rest<false>(z, img, p, u, [&](auto kc) {           // all deferred loads in E1's three gaps
+      constexpr int k = decltype(kc)::value, L = 4 * PF;
+      static_for<k * L / 3, (k + 1) * L / 3>([&](auto ic) { pf_load(ic); });
+    });
+    else if constexpr (PFSP == 8) p64v_exchange_rest<false>(z, img, p, u, [&](auto kc) {           // ... in the six gaps of E1 and E2
+      constexpr int k = decltype(kc)::value, L = 4 * PF;
+      static_for<k * L / 6, (k + 1) * L / 6>([&](auto ic) { pf_load(ic); });
+    });
+    else if constexpr (PFSP == 9) p64v_exchange_rest<false>(z, img, p, u, [&](auto kc) {           // deferred STORES in E1's first gap, loads in the other five
+      constexpr int k = decltype(kc)::value, L = 4 * PF;
+      if constexpr (k == 0) static_for<0, L>([&](auto ic) { pf_store(ic); });
+      else static_for<(k - 1) * L / 5, k * L / 5>([&](auto ic) { pf_load(ic); });
+    });
+    else
+    if constexpr (PFSP == 4) p64v_exchange_rest<false>(z, img, p, u, [&](auto kc) {
+      constexpr int k = decltype(kc)::value, H = (4 * PF) / 2;
+      static_for<k * H / 3, (k + 1) * H / 3>([&](auto ic) { pf_load(ic); });
+    });
+    else p64v_exchange_rest<false>(z, img, p, u);
 
     // ---- middle: F2 -> gate -> I1 (kernel_regtile.h; bin of register (ka, kb): k = k1 + 64 k2, k2 = ka + 8 kb) -------------
     {
@@ -569,7 +599,9 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
       static_for<0, 8>([&](auto kac) {
         constexpr int ka = decltype(kac)::value;
         if constexpr (PFSP == 3) { static_for<ka * (4 * PF) / 8, (ka + 1) * (4 * PF) / 8>([&](auto ic) { pf_store(ic); }); }
-        if constexpr (PFSP >= 1) { static_for<ka * (4 * PF) / 8, (ka + 1) * (4 * PF) / 8>([&](auto ic) { pf_load(ic); }); __builtin_amdgcn_sched_barrier(0); }
+        if constexpr (PFSP >= 1 && PFSP < 4) { static_for<ka * (4 * PF) / 8, (ka + 1) * (4 * PF) / 8>([&](auto ic) { pf_load(ic); }); __builtin_amdgcn_sched_barrier(0); }
+        if constexpr (PFSP == 5 || PFSP == 6) { pf_load_slot(std::integral_constant<int, 3 + ka>{}); __builtin_amdgcn_sched_barrier(0); }
+        if constexpr (PFSP == 4) { constexpr int H = (4 * PF) / 2, R = 4 * PF - H; static_for<H + ka * R / 8, H + (ka + 1) * R / 8>([&](auto ic) { pf_load(ic); }); __builtin_amdgcn_sched_barrier(0); }
         if constexpr (PFSP >= 1 && LATE > 0) { static_for<ka * (4 * LATE) / 8, (ka + 1) * (4 * LATE) / 8>([&](auto ic) { lat_load(ic); }); __builtin_amdgcn_sched_barrier(0); }
         fftA_stage2_group<8, 8, false, ka>(z);
         static_for<0, 8>([&](auto kbc) {
@@ -611,7 +643,16 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
 
     // ---- E2: position n2 -> image row n2, column (p, k1 = u); thread (p, u) reads row u, slot k1.  The barrier behind the last read
     //      frees the image for the LDS-DMA below.
-    p64v_exchange_rest<true>(z, img, p, u);
+    if constexpr (PFSP == 5 || PFSP == 6) p64v_exchange_rest<true>(z, img, p, u, [&](auto kc) { pf_load_slot(std::integral_constant<int, 11 + decltype(kc)::value>{}); });
+    else if constexpr (PFSP == 8) p64v_exchange_rest<true>(z, img, p, u, [&](auto kc) {
+      constexpr int k = 3 + decltype(kc)::value, L = 4 * PF;
+      static_for<k * L / 6, (k + 1) * L / 6>([&](auto ic) { pf_load(ic); });
+    });
+    else if constexpr (PFSP == 9) p64v_exchange_rest<true>(z, img, p, u, [&](auto kc) {
+      constexpr int k = 3 + decltype(kc)::value, L = 4 * PF;
+      static_for<(k - 1) * L / 5, k * L / 5>([&](auto ic) { pf_load(ic); });
+    });
+    else p64v_exchange_rest<true>(z, img, p, u);
     mark(6);                                       // deferred stores / loads issue, E1, middle, E2
     if constexpr (SYNCP == 1 || SYNCP == 6) gang_meet();
 
