@@ -72,8 +72,8 @@ template <int RF> constexpr int mixedp_tw_row() { return ((Split<RF>::RA + Split
 template <int RF, int RS, int S> constexpr int mixedp_tw_off() { return mixedp_dump_off<RF, RS, S>() + 1024; }
 template <int RF, int RS, int S> constexpr int mixedp_lds_total() { return S == 0 ? mixed_lds_total<RF, RS>() : mixedp_tw_off<RF, RS, S>() + RS * mixedp_tw_row<RF>() * 8; }
 
-// XP = experiment switches (tools/mixedp_stage_bench.hip; 0 in the library): bit 0 = a workgroup barrier between I2 and the store burst,
-// bit 1 = one behind the burst (in front of the reloads / the gate fetch)
+// XP = experiment switches (tools/mixedp_stage_bench.hip): bit 0 = a workgroup barrier between I2 and the store burst, bit 1 = one behind
+// the burst (in front of the reloads / the gate fetch), bits 2 / 3 = the deferred loads in the gaps of E1 / of E1 and E2
 // Launched with WHOLE waves (mixedp_launch_threads): an LDS-DMA request uses all 64 lanes of a wave — lanes 32-63 fetch the second row
 // block of a pair — and at 60 x 60 the 480 threads of the team would leave wave 7, which owns row classes 56-59, with half its lanes.
 // The threads beyond the team (u >= RF and u >= RS) own neither rows nor bins and only take part in the barriers and the requests.
@@ -273,8 +273,23 @@ __global__ void __launch_bounds__((mixedp_launch_threads<RF, RS>()), 1) spectre_
     __builtin_amdgcn_sched_barrier(0);
     // ---- the quiet part of the tile starts: the deferred results of the previous tile leave, the same row blocks of the next tile
     //      are requested into the registers they vacate
-    static_for<D0, D0 + P>([&](auto ic) { store_row(rs_prev, ooff, out_sn, row_q(ic), dfr[decltype(ic)::value - D0]); });
-    static_for<D0, D0 + P>([&](auto ic) { dfr[decltype(ic)::value - D0] = load_row(rs_next, voff, v_sn, row_q(ic)); });
+    if constexpr ((XP & 16) == 0) static_for<D0, D0 + P>([&](auto ic) { store_row(rs_prev, ooff, out_sn, row_q(ic), dfr[decltype(ic)::value - D0]); });
+    // XP bits 2 / 3 (tools/mixedp_stage_bench.hip): the deferred loads behind the barriers of E1 (5 gaps) / of E1 and E2 (9 gaps) instead of here
+    // (kernel_regtile64p.h SPREAD: a wave that has just passed a barrier of an exchange waits for the LDS anyway)
+    constexpr int NGAP = (XP & 8) != 0 ? 9 : (XP & 4) != 0 ? 5 : 0;
+    constexpr bool GAP_ST = (XP & 16) != 0;          // bit 4: the deferred STORES over E1's five gaps, the loads over E2's four
+    [[maybe_unused]] auto gap_loads = [&](auto kc) {
+      if constexpr (GAP_ST) {
+        constexpr int k = decltype(kc)::value;
+        if constexpr (k < 5) static_for<D0 + k * P / 5, D0 + (k + 1) * P / 5>([&](auto ic) { store_row(rs_prev, ooff, out_sn, row_q(ic), dfr[decltype(ic)::value - D0]); });
+        else static_for<D0 + (k - 5) * P / 4, D0 + (k - 4) * P / 4>([&](auto ic) { dfr[decltype(ic)::value - D0] = load_row(rs_next, voff, v_sn, row_q(ic)); });
+      } else
+      if constexpr (NGAP > 0 && decltype(kc)::value < NGAP) {
+        constexpr int k = decltype(kc)::value;
+        static_for<D0 + k * P / NGAP, D0 + (k + 1) * P / NGAP>([&](auto ic) { dfr[decltype(ic)::value - D0] = load_row(rs_next, voff, v_sn, row_q(ic)); });
+      }
+    };
+    if constexpr (NGAP == 0 && !GAP_ST) static_for<D0, D0 + P>([&](auto ic) { dfr[decltype(ic)::value - D0] = load_row(rs_next, voff, v_sn, row_q(ic)); });
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- E1 (kernel_regtile_mixed.h); the first barrier also separates it from the previous tile's E2 reads ---------------
@@ -285,16 +300,21 @@ __global__ void __launch_bounds__((mixedp_launch_threads<RF, RS>()), 1) spectre_
     const MixedM0 m0 = mixed_m0(img, tid);
     auto wr = [&](auto offc, float v) { mixed_write_addtid<decltype(offc)::value * 4>(v, m0); };
     rt_lds_barrier();
+    gap_loads(std::integral_constant<int, 0>{});
     if (rows) static_for<0, RF>([&](auto kc) { constexpr int k1 = decltype(kc)::value; wr(std::integral_constant<int, k1 * ROW1>{}, z[out_pos<RF>(k1)].x); });
     rt_lds_barrier();
+    gap_loads(std::integral_constant<int, 1>{});
     if (bins) static_for<0, RS>([&](auto nc) { constexpr int n2 = decltype(nc)::value; z[n2].x = mp_lds_read<n2 * kPC * 4>(r1); });
     rt_lds_barrier();
     mp_pin<0, RS, false>(z);
+    gap_loads(std::integral_constant<int, 2>{});
     if (rows) static_for<0, RF>([&](auto kc) { constexpr int k1 = decltype(kc)::value; wr(std::integral_constant<int, k1 * ROW1>{}, z[out_pos<RF>(k1)].y); });
     rt_lds_barrier();
+    gap_loads(std::integral_constant<int, 3>{});
     if (bins) static_for<0, RS>([&](auto nc) { constexpr int n2 = decltype(nc)::value; z[n2].y = mp_lds_read<n2 * kPC * 4>(r1); });
     rt_lds_barrier();
     mp_pin<0, RS, true>(z);
+    gap_loads(std::integral_constant<int, 4>{});
 
     // ---- bins k = u + RF*k2: F2 over n2, gate, I1 over k2 ------------------------------------------------------------------
     using BinMap = OutPosMap<RS>;
@@ -323,14 +343,18 @@ __global__ void __launch_bounds__((mixedp_launch_threads<RF, RS>()), 1) spectre_
     // ---- E2 ---------------------------------------------------------------------------------------------------------------
     if (bins) static_for<0, RS>([&](auto nc) { constexpr int n2 = decltype(nc)::value; wr(std::integral_constant<int, n2 * ROW2>{}, z[BinMap::at(out_pos<RS>(n2))].x); });
     rt_lds_barrier();
+    gap_loads(std::integral_constant<int, 5>{});
     if (rows) static_for<0, RF>([&](auto kc) { constexpr int k1 = decltype(kc)::value; z[k1].x = mp_lds_read<k1 * kPC * 4>(r2); });
     rt_lds_barrier();
     mp_pin<0, RF, false>(z);
+    gap_loads(std::integral_constant<int, 6>{});
     if (bins) static_for<0, RS>([&](auto nc) { constexpr int n2 = decltype(nc)::value; wr(std::integral_constant<int, n2 * ROW2>{}, z[BinMap::at(out_pos<RS>(n2))].y); });
     rt_lds_barrier();
+    gap_loads(std::integral_constant<int, 7>{});
     if (rows) static_for<0, RF>([&](auto kc) { constexpr int k1 = decltype(kc)::value; z[k1].y = mp_lds_read<k1 * kPC * 4>(r2); });
     rt_lds_barrier();
     mp_pin<0, RF, true>(z);
+    gap_loads(std::integral_constant<int, 8>{});
 
     // ---- conj twiddle, I2 over k1, store rows u + RS*n1 (spectre.py:553), reload / trade places -------------------------------
     load_twiddle_bases(wa, wb);

@@ -558,6 +558,16 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
       constexpr int k = decltype(kc)::value, L = 4 * PF;
       static_for<k * L / 6, (k + 1) * L / 6>([&](auto ic) { pf_load(ic); });
     });
+    else if constexpr (PFSP == 10) p64v_exchange_rest<false>(z, img, p, u, [&](auto kc) {          // all deferred STORES in E1's first gap; loads: a quarter in each of the other two, half over the middle
+      constexpr int k = decltype(kc)::value, L = 4 * PF, H = L / 2;
+      if constexpr (k == 0) static_for<0, L>([&](auto ic) { pf_store(ic); });
+      else static_for<(k - 1) * H / 2, k * H / 2>([&](auto ic) { pf_load(ic); });
+    });
+    else if constexpr (PFSP == 11) p64v_exchange_rest<false>(z, img, p, u, [&](auto kc) {          // a third of the stores, then a sixth of the loads, in each gap; half of the loads over the middle
+      constexpr int k = decltype(kc)::value, L = 4 * PF, H = L / 2;
+      static_for<k * L / 3, (k + 1) * L / 3>([&](auto ic) { pf_store(ic); });
+      if constexpr (k > 0) static_for<(k - 1) * H / 2, k * H / 2>([&](auto ic) { pf_load(ic); });
+    });
     else if constexpr (PFSP == 9) p64v_exchange_rest<false>(z, img, p, u, [&](auto kc) {           // deferred STORES in E1's first gap, loads in the other five
       constexpr int k = decltype(kc)::value, L = 4 * PF;
       if constexpr (k == 0) static_for<0, L>([&](auto ic) { pf_store(ic); });
@@ -601,7 +611,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
         if constexpr (PFSP == 3) { static_for<ka * (4 * PF) / 8, (ka + 1) * (4 * PF) / 8>([&](auto ic) { pf_store(ic); }); }
         if constexpr (PFSP >= 1 && PFSP < 4) { static_for<ka * (4 * PF) / 8, (ka + 1) * (4 * PF) / 8>([&](auto ic) { pf_load(ic); }); __builtin_amdgcn_sched_barrier(0); }
         if constexpr (PFSP == 5 || PFSP == 6) { pf_load_slot(std::integral_constant<int, 3 + ka>{}); __builtin_amdgcn_sched_barrier(0); }
-        if constexpr (PFSP == 4) { constexpr int H = (4 * PF) / 2, R = 4 * PF - H; static_for<H + ka * R / 8, H + (ka + 1) * R / 8>([&](auto ic) { pf_load(ic); }); __builtin_amdgcn_sched_barrier(0); }
+        if constexpr (PFSP == 4 || PFSP == 10 || PFSP == 11) { constexpr int H = (4 * PF) / 2, R = 4 * PF - H; static_for<H + ka * R / 8, H + (ka + 1) * R / 8>([&](auto ic) { pf_load(ic); }); __builtin_amdgcn_sched_barrier(0); }
         if constexpr (PFSP >= 1 && LATE > 0) { static_for<ka * (4 * LATE) / 8, (ka + 1) * (4 * LATE) / 8>([&](auto ic) { lat_load(ic); }); __builtin_amdgcn_sched_barrier(0); }
         fftA_stage2_group<8, 8, false, ka>(z);
         static_for<0, 8>([&](auto kbc) {
