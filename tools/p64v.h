@@ -20,6 +20,7 @@ constexpr int kV64LdsTotal = kV64TwOff + 64 * 14 * 8;
 static_assert(kV64LdsTotal <= 160 * 1024, "LDS budget");
 
 typedef unsigned int pv_u32x4 __attribute__((ext_vector_type(4)));
+typedef float pv_f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kV64RsrcFlags = 0x00020000;        // raw buffer, 32-bit data format (gfx90a / gfx942 / gfx950 dword 3)
 
 __device__ __forceinline__ void vlane16_swap(float& x, float& y) {   // x of the odd 16-lane rows <-> y of the even rows
@@ -131,7 +132,7 @@ __device__ __forceinline__ void p64v_exchange_rest(float2 (&z)[64], float* img, 
 // top of the next tile (completion is in order, so vmcnt(N) with N = that count means "everything up to and including the LDS-DMA has
 // landed").  Steady state: per reloaded group 4 stores + 4 loads, per LDS-staged group 4 stores, the 5 gate loads.  First tile (the
 // prologue): the 4 loads of every register-loaded group and the 5 gate loads.  tools/isa_lint.py checks both against the ISA.
-template <int SPLIT, int PF, int LATE = 0> constexpr int p64v_younger() { return 8 * (8 - PF - SPLIT - LATE) + 4 * LATE + 4 * SPLIT + 5; }
+template <int SPLIT, int PF, int LATE = 0, int PARK = 0> constexpr int p64v_younger() { return 8 * (8 - PF - SPLIT - LATE) + 4 * LATE + 4 * SPLIT + 5 - 4 * PARK; }
 template <int SPLIT> constexpr int p64v_younger_first() { return 4 * (8 - SPLIT) + 5; }
 
 // SPLIT = row groups (of 8) of the next tile that travel through LDS.
@@ -145,7 +146,7 @@ template <int SPLIT> constexpr int p64v_younger_first() { return 4 * (8 - SPLIT)
 //         right behind E2 of the previous one, none behind its stores (round 3: the fp32 kernel's late groups cost a memory latency
 //         per tile — same-box ablation: loads only 1.11 ms, stores only 0.90, neither 0.84).
 // OUT_BF16 = bf16 rows out (round to nearest even, like every other kernel here): a lane stores its 4 channels as 8 bytes.
-template <int SPLIT, int PF, bool WITH_MEM = false, bool IN_BF16 = false, bool OUT_BF16 = false, int GANGX = 0, int AUXD = 0, int AUXL = 0, int AUXS = 0, int PRIO = 0, int MAPX = 0, int DSPREAD = 0, int SYNCP = 0, int TSTAMP = 0, int PFL2 = 0, int STAG = 0, int PFSP = 0, int LATE = 0, int RLF = 0>
+template <int SPLIT, int PF, bool WITH_MEM = false, bool IN_BF16 = false, bool OUT_BF16 = false, int GANGX = 0, int AUXD = 0, int AUXL = 0, int AUXS = 0, int PRIO = 0, int MAPX = 0, int DSPREAD = 0, int SYNCP = 0, int TSTAMP = 0, int PFL2 = 0, int STAG = 0, int PFSP = 0, int LATE = 0, int RLF = 0, int PARK = 0>
 __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) {
   constexpr int ESI = IN_BF16 ? 2 : 4, ESO = OUT_BF16 ? 2 : 4;   // bytes per input / output element
   constexpr float inv_n = 1.0f / 4096.0f;
@@ -464,10 +465,24 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
       if constexpr (i == PF) {
         // the tile arrives: completion is in order, so once everything but the requests younger than the last LDS-DMA has retired the
         // staged groups are in the slots (p64v_younger; checked against the ISA by tools/isa_lint.py)
-        if (it == 0) asm volatile("s_waitcnt vmcnt(%0) ; lint: first" :: "n"(p64v_younger_first<SPLIT>()) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0) ; lint: steady" :: "n"(p64v_younger<SPLIT, PF, LATE>()) : "memory");
+        if (it == 0) asm volatile("s_waitcnt vmcnt(%0) ; lint: first" :: "n"(p64v_younger_first<SPLIT>() + 4 * PARK) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) ; lint: steady" :: "n"(p64v_younger<SPLIT, PF, LATE, PARK>()) : "memory");
         mark(1);                                   // stage 1 of the deferred groups, wait for the LDS-DMA
         static_for<0, SPLIT>([&](auto gc) { read_group(gc); });
+      }
+      if constexpr (PARK != 0 && i < PF) {
+        // PARK: the results of the first reloaded group of the PREVIOUS tile were parked in the image behind the landing slots (own-wave area,
+        // untracked asm LDS accesses: hipcc orders tracked ones behind the pending LDS-DMA with vmcnt(0)); they leave now, before the wait below
+        static_for<0, 4>([&](auto mc) {
+          constexpr int m = decltype(mc)::value;
+          if constexpr (m % PF == i || (PF > 4)) {
+            pv_f32x4 rv;
+            const uint32_t pa = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(smem + 8 * SPLIT * GROUP_SLOT + (__builtin_amdgcn_readfirstlane(tid0 >> 6) * 4 + m) * 1024 + lane * 16);
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(rv) : "v"(pa) : "memory");
+            store16(rsrc_out(obp, out_sn, it > 0), pf_ooff + (uint32_t)((64 * SPLIT + 1024 * m) * out_sn * ESO), make_float4(rv.x, rv.y, rv.z, rv.w));
+          }
+        });
+        __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr (RLF != 0 && i < PF) {
         constexpr int R = GP - SPLIT;                                        // groups that are neither staged nor deferred
@@ -795,6 +810,16 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
           vpin8<8 * g, 1>(z);
           swap_group(std::integral_constant<int, g>{});
           __builtin_amdgcn_sched_barrier(0);
+          if constexpr (PARK != 0 && decltype(ic)::value == 0) {        // g = SPLIT: results -> LDS, its registers take the next tile's rows NOW (loads, in front of the burst)
+            static_for<0, 4>([&](auto mc) {
+              constexpr int m = decltype(mc)::value;
+              pv_f32x4 res; res.x = z[8 * g + 2 * m].x; res.y = z[8 * g + 2 * m].y; res.z = z[8 * g + 2 * m + 1].x; res.w = z[8 * g + 2 * m + 1].y;
+              const uint32_t pa = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(smem + 8 * SPLIT * GROUP_SLOT + (__builtin_amdgcn_readfirstlane(tid0 >> 6) * 4 + m) * 1024 + lane * 16);
+              asm volatile("ds_write_b128 %0, %1" :: "v"(pa), "v"(res) : "memory");
+            });
+            load_group(rs_next, voff, v_sn, std::integral_constant<int, SPLIT>{});
+            __builtin_amdgcn_sched_barrier(0);
+          }
           if constexpr (DSPREAD == 3) {
             constexpr int sl = 16 + decltype(ic)::value;
             static_for<sl * NDMA / NSLOT, (sl + 1) * NDMA / NSLOT>([&](auto qc) { dma_one(qc); });
@@ -825,6 +850,8 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
               } else {
                 store16(rs_out, ooff + (uint32_t)((64 * g + 1024 * m) * out_sn * ESO), res);
               }
+            } else if constexpr (PARK != 0 && g == SPLIT) {
+              // parked (and its registers already hold the next tile's rows): nothing to store here
             } else {
               store16(rs_out, ooff + (uint32_t)((64 * g + 1024 * m) * out_sn * ESO), res);
               if constexpr (LATE > 0 && g >= GP - LATE) {           // the prefetched rows of the next tile move in
@@ -841,7 +868,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
         mark(10);                                  // barrier behind the burst
         if constexpr (SYNCP == 15) __builtin_amdgcn_s_sleep(4);
         if constexpr (SYNCP == 16) __builtin_amdgcn_s_sleep(16);
-        if constexpr (RLF == 0) static_for<SPLIT, GP - LATE>([&](auto gc) { load_group(rs_next, voff, v_sn, gc); });
+        if constexpr (RLF == 0) static_for<SPLIT + (PARK != 0 ? 1 : 0), GP - LATE>([&](auto gc) { load_group(rs_next, voff, v_sn, gc); });
         __builtin_amdgcn_sched_barrier(0);
       } else {
       if constexpr (SYNCP == 8) p64v_barrier();
@@ -882,6 +909,17 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
     if constexpr (MAPX == 3) { cur_t = nxt_t; nxt_t = fut_t; }
     mark(11);                                      // reload issue + gate fetch issue
   }  // tile loop
+  if constexpr (PARK != 0) {                       // the last tile's parked group
+    coords();
+    const uint32_t ooff_l = (uint32_t)(((long long)(u + 512 * h) * a.out_sn + 4 * pp) * ESO);
+    static_for<0, 4>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      pv_f32x4 rv;
+      const uint32_t pa = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(smem + 8 * SPLIT * GROUP_SLOT + (__builtin_amdgcn_readfirstlane(tid0 >> 6) * 4 + m) * 1024 + lane * 16);
+      asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(rv) : "v"(pa) : "memory");
+      store16(rsrc_out(obp, a.out_sn, true), ooff_l + (uint32_t)((64 * SPLIT + 1024 * m) * a.out_sn * ESO), make_float4(rv.x, rv.y, rv.z, rv.w));
+    });
+  }
   if constexpr (TSTAMP) {                          // when did this workgroup start / finish (100 MHz)?  a.mem + 256 words: [2 wg], [2 wg + 1]
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (tid0 == 0) {
