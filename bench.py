@@ -11,7 +11,11 @@ configuration is BASELINE.json's B=2048 batch shard); there is no collective in 
 barrier + MAX-over-ranks timing reduction the contract asks for.
 
 Prints ONE JSON line on rank 0 with
-  value        whole-job tokens/s (B_total * N * K / wall time of the K timed steps, max over ranks)
+  value        whole-job tokens/s = B_total * N * K / (last rank's finish - first rank's start) of the K timed steps: every rank
+               stamps the node's monotonic clock behind the opening barrier + synchronize and behind its closing synchronize (in front
+               of the closing barrier), so the job time is MAX over ranks of the end minus MIN over ranks of the start — the
+               max-over-ranks wall time without the latency of the closing barrier itself (`timing` in the line says so;
+               `wall_incl_closing_barrier_s` is the older definition)
   roofline     dominant kernel vs the HBM roofline: algorithmic bytes per launch / average launch duration,
                the duration measured live with HIP events on the launch stream over the timed region
   cpu_baseline the oracle's torch.fft restatement of the same statements timed on this box's host cores
@@ -95,7 +99,8 @@ def main():
     ap.add_argument("--print-launch", action="store_true", help="print the multi-process launch command for --gpus N and exit")
     a = ap.parse_args()
 
-    # --gpus N without a launcher around us: become the launcher (one rank per GPU, RCCL rendezvous on 127.0.0.1)
+    # --gpus N without a launcher around us: become the launcher (one rank per GPU; rendezvous on 127.0.0.1: gloo control plane first,
+    # then an RCCL group that has to prove itself — fft_amd/rendezvous.py)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         cmd = launch_command(a.gpus, [x for x in sys.argv[1:] if x != "--print-launch"])
         if a.print_launch:
@@ -151,9 +156,12 @@ def main():
         torch.cuda.synchronize()
 
     # The contract's protocol WITHOUT the power-state prewarm, from the idle state the process starts in (the protocol of rounds 1-2, ADVICE
-    # r03): W warm-up + K timed steps.  Informational (`cold_start`): round-over-round comparisons must use like for like.
+    # r03): W warm-up + K timed steps.  Informational (`cold_start`): round-over-round comparisons must use like for like.  Every world
+    # size runs it (rank 0 reports its own), and its launches COUNT as prewarm launches, so that the number of launches in front of the
+    # timed region is the same for every N and every round (`launches_before_timed_region`).
     cold = None
-    if a.prewarm > 0 and world == 1:
+    launched = 0
+    if a.prewarm >= a.warmup + a.steps:
         for _ in range(a.warmup):
             step()
         torch.cuda.synchronize()
@@ -164,21 +172,38 @@ def main():
         c1.record()
         torch.cuda.synchronize()
         cold = c0.elapsed_time(c1) / a.steps
-    for _ in range(max(0, a.prewarm)):                        # power-state ramp (untimed; the contract's warmup steps follow)
+        launched = a.warmup + a.steps
+    for _ in range(max(0, a.prewarm - launched)):             # power-state ramp (untimed; the contract's warmup steps follow)
         step()
+    launched = max(launched, a.prewarm)
     for _ in range(a.warmup):
         step()
-    barrier()
+    launched += a.warmup
+    clock = lambda: time.clock_gettime(time.CLOCK_MONOTONIC)  # one clock for every process of the node
+    barrier()                                                 # the contract's opening barrier + synchronize
+    if world > 1:
+        # ... and a common start: the ranks leave a gloo barrier up to a millisecond apart (TCP on the loopback), which on a 26-ms timed
+        # region would read as scaling loss.  They agree on a start time a few milliseconds ahead (the MAX all-reduce is itself a barrier)
+        # and spin until the node's monotonic clock reaches it.
+        (t_go,) = rdv.max_over_ranks([clock() + 0.004])
+        while clock() < t_go:
+            pass
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
+    t_start = clock()
     ev0.record()                                              # same stream the kernels are launched on
     for _ in range(a.steps):
         step()
     ev1.record()
-    barrier()
-    wall = time.perf_counter() - t0
-    kern_ms = ev0.elapsed_time(ev1) / a.steps                 # average launch duration over the timed region
-    wall, kern_ms = rdv.max_over_ranks([wall, kern_ms])
+    torch.cuda.synchronize()
+    t_end = clock()
+    rdv.barrier()                                             # the contract's closing barrier (the synchronize is in front of the stamp)
+    wall_old = clock() - t_start
+    kern_ms_own = ev0.elapsed_time(ev1) / a.steps             # average launch duration over the timed region, this rank
+    last_end, neg_first_start, wall_old, kern_ms = rdv.max_over_ranks([t_end, -t_start, wall_old, kern_ms_own])
+    wall = last_end + neg_first_start                         # whole job: first rank's start -> last rank's finish
+    per_rank = rdv.gather_over_ranks({"rank": rank, "kernel_ms": kern_ms_own, "wall_s": t_end - t_start,
+                                      "start_after_first_us": (t_start + neg_first_start) * 1e6,
+                                      "end_before_last_us": (last_end - t_end) * 1e6})
 
     # other storage dtypes of the same workload, same run (informational; `value` above is the --io default).
     # BASELINE.json configs[2] words the headline shape as "bf16 in / fp32 compute": both readings are reported.
@@ -243,6 +268,16 @@ def main():
                 fm = copy_probe(Vv, ov, -1, mode="copy", warmup=3, iters=max(5, a.steps // 2))
                 variants[name].update({"pattern_copy_GBps": cb / pm / 1e6, "pattern_copy_ms": pm, "frac_of_pattern_copy": pm / ms * (byt / cb),
                                        "flat_copy_GBps": cb / fm / 1e6})
+            # mixed storage (bf16 rows in, fp32 rows out: BASELINE configs[2] read literally) has no copy of its own shape; its ceiling is its
+            # two request streams issued alone, each in the kernel's own segment width on the variant's own tensors: 32-byte loads of the
+            # bf16 rows (gangs of four per line) + 64-byte stores of the fp32 rows (pairs) — VERDICT r04 item 3
+            if tin != tout and Vv.is_contiguous() and N % 4096 == 0 and (B * N * D * Vv.element_size()) % (256 * 1024) == 0:
+                ldm = min(copy_probe(Vv, Vv, 16 * Vv.element_size(), mode="load", wgs_per_cu=w, warmup=3, iters=max(5, a.steps // 2)) for w in (1, 2, 4))
+                stm = min(copy_probe(ov, ov, 16 * ov.element_size(), mode="store", wgs_per_cu=w, warmup=3, iters=max(5, a.steps // 2)) for w in (1, 2, 4))
+                variants[name].update({"pattern_load_only_ms": ldm, "pattern_store_only_ms": stm, "pattern_requests_ms": ldm + stm,
+                                       "frac_of_pattern_requests": (ldm + stm) / ms,
+                                       "pattern_note": f"{16 * Vv.element_size()}-byte load-only pass over V + {16 * ov.element_size()}-byte store-only pass over out, "
+                                                       "issued one after the other; > 1 = the kernel overlaps its two directions"})
             del Vv, ov
         # Where the driver places an allocation is worth +-5 % to this kernel and +-10 % to a copy (LABNOTES.md section 5, round 3, item 7;
         # tools/placement_time.py): allocations fall into two classes, one of which takes stores ~19 % faster.  The headline above uses the
@@ -276,7 +311,7 @@ def main():
             # of all Nc rows for the whole-line tiles of n_fft <= 1024 (kernel_regtile_wide.h), 64-byte halves in pairs otherwise
             if (Bc * Nc * Dc * 4) % (256 * 1024) == 0:
                 sgc = 128 if "wide" in variants[name]["kernel"] else 64
-                if (sgc * Nc) % (128 * 1024) == 0:
+                if True:                                                  # (tiles that are not whole 128-KiB chunks — C4: 64 B x 3000 rows — run the probe's masked form)
                     pm = min(copy_probe(Vc, oc, sgc, tile_rows=Nc, mode="copy", wgs_per_cu=w, warmup=3, iters=max(5, a.steps // 2)) for w in (1, 2, 4))
                     variants[name].update({"pattern_copy_ms": pm, "pattern_copy_GBps": 2.0 * Bc * Nc * Dc * 4 / pm / 1e6,
                                            "frac_of_pattern_copy": pm / ms * (byt / (2.0 * Bc * Nc * Dc * 4)), "pattern_segment_bytes": sgc})
@@ -341,11 +376,19 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": alg, "kernel_ms": kern_ms},
             "prewarm_steps": max(0, a.prewarm),
+            "launches_before_timed_region": launched,
+            "timing": "value = tokens / (MAX over ranks of the finish stamp - MIN over ranks of the start stamp); stamps = the node's "
+                      "CLOCK_MONOTONIC behind barrier + synchronize (start) and behind the closing synchronize, in front of the closing "
+                      "barrier (finish); roofline.kernel_ms = MAX over ranks of the HIP-event average of the K launches",
+            "wall_s": wall,
+            "wall_incl_closing_barrier_s": wall_old,
+            "per_rank": sorted(per_rank, key=lambda r: r["rank"]),
             **rdv.describe(),
         }
         if cold is not None:
             res["cold_start"] = {"kernel_ms": cold, "tokens_per_s": B * N / (cold * 1e-3), "roofline_frac": alg / (cold * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                 "protocol": f"{a.warmup} warm-up + {a.steps} timed launches from the idle state, before the prewarm (rounds 1-2 protocol)"}
+                                 "protocol": f"{a.warmup} warm-up + {a.steps} timed launches from the idle state (rounds 1-2 protocol); they count as "
+                                             f"the first {a.warmup + a.steps} of the {a.prewarm} prewarm launches"}
         if ceilings:
             res["roofline"].update(ceilings)
             res["roofline"]["frac_of_pattern_copy"] = achieved / ceilings["pattern_copy_GBps"]

@@ -35,6 +35,9 @@ struct ProbeArgs {
 
 constexpr int kProbeThreads = 512, kProbeInFlight = 16;   // 16 x 16 bytes per lane in flight = 128 KiB per workgroup
 
+// RAGGED = a tile is not a whole number of 128-KiB chunks (C4: 64 bytes x 3000 rows): the last chunk's accesses beyond the tile's rows are
+// masked off per lane.  The whole-chunk shapes keep the unpredicated instantiation (their numbers are compared across rounds).
+template <bool RAGGED>
 __global__ void __launch_bounds__(kProbeThreads) spectre_probe_copy_kernel(const ProbeArgs a) {
   const int tid = threadIdx.x;
   const int wg = xcd_contiguous(blockIdx.x, gridDim.x);
@@ -47,13 +50,30 @@ __global__ void __launch_bounds__(kProbeThreads) spectre_probe_copy_kernel(const
   const long long lane_off = a.seg > 0 ? (long long)(tid / lps) * a.row_bytes + (tid % lps) * 16 : (long long)tid * 16;
   const long long step = a.seg > 0 ? (long long)(kProbeThreads / lps) * a.row_bytes : (long long)kProbeThreads * 16;   // bytes between instructions
   const long long tile_bytes = a.seg > 0 ? (long long)a.seg * a.tile_rows : 256 * 1024;
-  const int chunks = (int)(tile_bytes / (kProbeThreads * 16 * kProbeInFlight));                                         // 128-KiB chunks per tile
+  const int chunks = (int)((tile_bytes + kProbeThreads * 16 * kProbeInFlight - 1) / (kProbeThreads * 16 * kProbeInFlight));   // 128-KiB chunks per tile
+  [[maybe_unused]] const int rpi = lps > 0 ? kProbeThreads / lps : 1, row0 = lps > 0 ? tid / lps : 0;                    // rows per instruction, this lane's row in it
   for (int it = 0; it < a.tpw; ++it) {
     const int t = base_tile + a.gang * it;
     if (t >= a.n_tiles) break;
     const long long base = a.seg > 0 ? (long long)(t / a.cols) * a.tile_rows * a.row_bytes + (long long)(t % a.cols) * a.seg : (long long)t * tile_bytes;
     for (int c = 0; c < chunks; ++c) {
       const long long off = base + lane_off + (long long)c * kProbeInFlight * step;
+      if constexpr (RAGGED) {
+        const int r0 = c * kProbeInFlight * rpi + row0;
+        if (a.mode != 2) {
+#pragma unroll
+          for (int q = 0; q < kProbeInFlight; ++q) if (r0 + q * rpi < a.tile_rows) v[q] = *reinterpret_cast<const probe_f32x4*>(a.src + off + q * step);
+        }
+        if (a.mode != 1) {
+#pragma unroll
+          for (int q = 0; q < kProbeInFlight; ++q) if (r0 + q * rpi < a.tile_rows) *reinterpret_cast<probe_f32x4*>(a.dst + off + q * step) = v[q];
+        } else {
+#pragma unroll
+          for (int q = 0; q < kProbeInFlight; ++q)
+            if (v[q].x == 1.2345e-30f) *reinterpret_cast<probe_f32x4*>(a.dst + off + q * step) = v[q];
+        }
+        continue;
+      }
       if (a.mode != 2) {
 #pragma unroll
         for (int q = 0; q < kProbeInFlight; ++q) v[q] = *reinterpret_cast<const probe_f32x4*>(a.src + off + q * step);
@@ -99,7 +119,8 @@ int probe_copy(const SpectreProbeArgs* p, int warmup, int iters, float* ms_per_l
       return hipSuccess;
     };
     hipEvent_t e0, e1;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipSetDevice(prev); return SPECTRE_E_HIP; }
+    if (hipEventCreate(&e0) != hipSuccess) { (void)hipSetDevice(prev); return SPECTRE_E_HIP; }
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); (void)hipSetDevice(prev); return SPECTRE_E_HIP; }
     hipError_t e = hipSuccess;
     for (int i = 0; i < warmup && e == hipSuccess; ++i) e = go();
     if (e == hipSuccess) e = hipEventRecord(e0, stream);
@@ -118,7 +139,7 @@ int probe_copy(const SpectreProbeArgs* p, int warmup, int iters, float* ms_per_l
   }
   if (seg != 0 && (seg < 16 || (seg & (seg - 1)) || seg > 1024 || p->row_bytes % seg || p->tile_rows < 1 || p->rows % p->tile_rows)) {
     *why = "seg_bytes must be 0 or a power of two in 16..1024 that divides row_bytes; tile_rows must divide rows"; return SPECTRE_E_INVALID; }
-  if (seg != 0 && ((long long)seg * p->tile_rows) % (kProbeThreads * 16 * kProbeInFlight)) { *why = "a tile must be whole 128-KiB chunks"; return SPECTRE_E_INVALID; }
+  const bool ragged = seg != 0 && ((long long)seg * p->tile_rows) % (kProbeThreads * 16 * kProbeInFlight) != 0;   // (C4: 3000 rows; masked last chunk)
   if (seg == 0 && (p->rows * p->row_bytes) % (256 * 1024)) { *why = "dense copy: the buffer must be whole 256-KiB chunks"; return SPECTRE_E_INVALID; }
   if (p->mode < 0 || p->mode > 2) { *why = "mode must be 0 (copy), 1 (load) or 2 (store)"; return SPECTRE_E_INVALID; }
   *why = "HIP runtime call failed";
@@ -140,10 +161,15 @@ int probe_copy(const SpectreProbeArgs* p, int warmup, int iters, float* ms_per_l
   const int n_wg = a.gang * ((a.n_tiles + a.gang * a.tpw - 1) / (a.gang * a.tpw));
   hipStream_t stream = reinterpret_cast<hipStream_t>(p->stream);
   hipEvent_t e0, e1;
-  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipSetDevice(prev); return SPECTRE_E_HIP; }
-  for (int i = 0; i < warmup; ++i) hipLaunchKernelGGL(spectre_probe_copy_kernel, dim3(n_wg), dim3(kProbeThreads), 0, stream, a);
+  if (hipEventCreate(&e0) != hipSuccess) { (void)hipSetDevice(prev); return SPECTRE_E_HIP; }
+  if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); (void)hipSetDevice(prev); return SPECTRE_E_HIP; }
+  auto go = [&] {
+    if (ragged) hipLaunchKernelGGL(spectre_probe_copy_kernel<true>, dim3(n_wg), dim3(kProbeThreads), 0, stream, a);
+    else hipLaunchKernelGGL(spectre_probe_copy_kernel<false>, dim3(n_wg), dim3(kProbeThreads), 0, stream, a);
+  };
+  for (int i = 0; i < warmup; ++i) go();
   hipError_t e = hipEventRecord(e0, stream);
-  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(spectre_probe_copy_kernel, dim3(n_wg), dim3(kProbeThreads), 0, stream, a);
+  for (int i = 0; i < iters; ++i) go();
   if (e == hipSuccess) e = hipEventRecord(e1, stream);
   if (e == hipSuccess) e = hipEventSynchronize(e1);
   float ms = 0.f;

@@ -493,9 +493,9 @@ int launch(const SpectreMixArgs* a, const Plan* plan, const Choice& c, bool conj
     } else if (c.pipelined) {   // one workgroup per CU walks through tpw tiles; pairs of workgroups stay on adjacent tiles
       const int ncu = cu_count(a->device);
       static const int forced = [] { const char* e = tuning_env("SPECTRE_P64_TPW"); return e ? atoi(e) : 0; }();
-      // round 4: store burst behind a workgroup barrier + phased I/O (fp32 rows out).  SPECTRE_P64_BURST=0: the round-3 order (tuning aid)
+      // round 4: store burst behind a workgroup barrier + phased I/O + requests spread over the arithmetic — every variant (fp32 rows,
+      // bf16 rows in and / or out, memory_fft).  SPECTRE_P64_BURST=0: the round-3 order (tuning aid)
       static const bool burst_off = [] { const char* e2 = tuning_env("SPECTRE_P64_BURST"); return e2 && atoi(e2) == 0; }();
-      const bool burst = !burst_off && !a->mem;
       const int gang = (ib || ob) ? 4 : 2;   // = p64_gang() of kernel_regtile64p.h: workgroups that walk in step
       const int slots = std::max(gang, ncu / gang * gang);
       k.tpw = forced > 0 ? forced : std::max(1, (k.n_tiles + slots - 1) / slots);

@@ -7,7 +7,8 @@ an 8-GPU node cannot be lost to the transport:
   1. the process group is ALWAYS formed over gloo first (TCP on 127.0.0.1: no GPU, no RCCL involved) and the census is gathered there:
      `ranks_seen` = one record per rank (rank, local rank, device ordinal, device UUID, pid);
   2. if RCCL is wanted (`prefer="nccl"`), a HIP device is present and every rank drives a DISTINCT device, an RCCL group is created next
-     to it and proved with one barrier and one MAX all-reduce of a device tensor, inside a time box; the ranks then AGREE over gloo whether
+     to it and proved with one barrier and one MAX all-reduce of a device tensor, inside a time box (ours: the RCCL watchdog is disarmed
+     for the proof, so a hung collective cannot abort the process before the fallback); the ranks then AGREE over gloo whether
      it worked everywhere.  Any exception, any time-out on any rank, or two ranks on one device (RCCL refuses that: "duplicate GPU")
      -> every rank uses gloo for the barrier / MAX and `fallback_reason` says why;
   3. `barrier()` and `max_over_ranks()` use whichever transport was agreed on; `backend` names it ("nccl" | "gloo" | "none" for one rank).
@@ -57,6 +58,16 @@ class Rendezvous:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return [float(x) for x in t.cpu()]
 
+    def gather_over_ranks(self, obj) -> list:
+        """[obj of rank 0, obj of rank 1, ...] on every rank — always over the gloo control plane (small Python objects: per-rank timings
+        for the attribution fields of the bench line), whatever transport the barrier uses."""
+        if self.backend == "none":
+            return [obj]
+        import torch.distributed as dist
+        got = [None] * self.world
+        dist.all_gather_object(got, obj)             # the DEFAULT group = gloo (rendezvous() forms it first; the RCCL group sits beside it)
+        return got
+
     def describe(self) -> dict:
         return {"rendezvous": self.backend, "ranks_seen": self.ranks_seen, "distinct_devices": len({(r["device"], r["uuid"]) for r in self.ranks_seen}),
                 "oversubscribed": self.oversubscribed, "rendezvous_fallback": self.fallback_reason}
@@ -90,7 +101,14 @@ def _prove_nccl(device, timeout_s: float):
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(device)                   # (the current device is per thread, and rendezvous() calls this from a worker thread)
-    group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=timeout_s))
+    # The time box is OURS (the caller joins this thread for timeout_s and then agrees with the other ranks over gloo).  ProcessGroupNCCL's
+    # own watchdog must not get there first: with the default TORCH_NCCL_ASYNC_ERROR_HANDLING a collective that exceeds the GROUP's timeout
+    # makes the watchdog abort the whole PROCESS (SIGABRT) — before the "agree and fall back" step could run.  So: no
+    # process-level handling (read when the group is constructed), no heartbeat monitor, and a group timeout far beyond the box.
+    os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
+    os.environ.setdefault("TORCH_NCCL_ENABLE_MONITORING", "0")
+    os.environ.setdefault("TORCH_NCCL_DUMP_ON_TIMEOUT", "0")
+    group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=max(1800.0, 20.0 * timeout_s)))
     dist.barrier(group=group, device_ids=[device.index])
     t = torch.tensor([float(dist.get_rank())], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)

@@ -202,13 +202,16 @@ class SpectreHead(nn.Module):
         self.dropout = nn.Dropout(dropout_p) if dropout_p > 0 else nn.Identity()
 
     # ---- host logic: everything up to the filter the kernel consumes (spectre.py:502-503, :511-536) --
-    def spectral_gate(self, x: torch.Tensor, pos_phase: Optional[torch.Tensor] = None, *, v_out: Optional[torch.Tensor] = None
-                      ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    def spectral_gate(self, x: torch.Tensor, pos_phase: Optional[torch.Tensor] = None, *, v_out: Optional[torch.Tensor] = None,
+                      with_value: bool = True) -> Tuple[Optional[torch.Tensor], torch.Tensor, torch.Tensor]:
         """Returns (V (B,N,d), gate (B,G,F_half) complex64, q_pool (B,d)).  `v_out` (inference only): a (B,N,d) view the value
-        projection is written into — e.g. this head's channel slice of a multi-head buffer — instead of a fresh tensor."""
+        projection is written into — e.g. this head's channel slice of a multi-head buffer — instead of a fresh tensor.
+        `with_value=False`: the caller projects the values itself (the multi-head layer does it for all heads at once); V is None."""
         Bsz, N, d = x.shape
         assert d == self.d
-        if v_out is not None:
+        if not with_value:
+            V = None
+        elif v_out is not None:
             if torch.is_grad_enabled() and (x.requires_grad or self.W_v.weight.requires_grad):
                 raise RuntimeError("spectral_gate(v_out=...) writes the value projection in place and records no graph: inference only")
             V = torch.matmul(x, self.W_v.weight.t(), out=v_out)          # W_v has no bias (spectre.py:428)
@@ -264,6 +267,36 @@ class SpectreHead(nn.Module):
 # --------------------------------------------------------------------------------------------------
 # multi-head wrapper
 # --------------------------------------------------------------------------------------------------
+class _MultiHeadValueFn(torch.autograd.Function):
+    """Value projections of all heads (spectre.py:503 inside the per-head loop of :712-719) written straight into the channel
+    slices of ONE (B, N, D) tensor: V[..., h] = x[..., h] @ W_v^h.T — H GEMMs with strided operands, no concatenation pass
+    over the activations in either direction (dx is assembled the same way)."""
+
+    @staticmethod
+    def forward(ctx, x, *weights):
+        hd = weights[0].shape[0]
+        V = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+        for i, w in enumerate(weights):
+            torch.matmul(x[..., i * hd:(i + 1) * hd], w.t(), out=V[..., i * hd:(i + 1) * hd])      # W_v has no bias (spectre.py:428)
+        ctx.save_for_backward(x, *weights)
+        return V
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dV):
+        x, *weights = ctx.saved_tensors
+        hd = weights[0].shape[0]
+        dx = torch.empty(x.shape, dtype=x.dtype, device=x.device) if ctx.needs_input_grad[0] else None
+        dws = []
+        for i, w in enumerate(weights):
+            sl = slice(i * hd, (i + 1) * hd)
+            dVi = dV[..., sl]
+            if dx is not None:
+                torch.matmul(dVi, w, out=dx[..., sl])
+            dws.append(dVi.reshape(-1, hd).t() @ x[..., sl].reshape(-1, hd) if ctx.needs_input_grad[1 + i] else None)
+        return (dx, *dws)
+
+
 class _WaveletRefinementParams(nn.Module):
     """Holds the parameters of the reference's `WaveletRefinement` (spectre.py:819-832) so that its state_dict loads;
     the refinement itself is out of scope (stochastic per batch element) and is only accepted
@@ -310,15 +343,40 @@ class SpectreMultiHead(nn.Module):
         self.out_proj = nn.Linear(embed_dim, embed_dim, bias=False)
         self.wavelet_refinement = _WaveletRefinementParams(embed_dim, wavelet_on_rate)
 
-    def forward(self, x: torch.Tensor, pos_phase: Optional[torch.Tensor] = None, memory_fft: Optional[torch.Tensor] = None):
+    fused_autograd = True          # under autograd: one value-projection node + ONE spectral-mix node for all heads (False: the reference's loop)
+
+    def _forward_per_head(self, x, pos_phase, memory_fft):
+        """The reference's own structure (spectre.py:712-719): per-head modules, concatenated.  Kept for autocast and as the
+        comparison path of the tests."""
         chunks = torch.chunk(x, self.num_heads, dim=-1)
         mems = torch.chunk(memory_fft, self.num_heads, dim=-1) if memory_fft is not None else [None] * self.num_heads
+        mixed = torch.cat([h(c, pos_phase, memory_fft=m) for h, c, m in zip(self.heads, chunks, mems)], dim=-1)
+        return self.out_proj(mixed)
+
+    def forward(self, x: torch.Tensor, pos_phase: Optional[torch.Tensor] = None, memory_fft: Optional[torch.Tensor] = None):
+        chunks = torch.chunk(x, self.num_heads, dim=-1)
         needs_graph = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())
                                                    or (pos_phase is not None and pos_phase.requires_grad)
                                                    or (memory_fft is not None and memory_fft.requires_grad))
-        if needs_graph or any(not isinstance(h.dropout, nn.Identity) for h in self.heads):
-            mixed = torch.cat([h(c, pos_phase, memory_fft=m) for h, c, m in zip(self.heads, chunks, mems)], dim=-1)
+        p_drop = self.heads[0].dropout.p if isinstance(self.heads[0].dropout, nn.Dropout) else 0.0
+        if needs_graph:
+            if not self.fused_autograd or torch.is_autocast_enabled():
+                return self._forward_per_head(x, pos_phase, memory_fft)
+            # Training (row N3 under autograd): the per-head loop + torch.cat of the reference moves the whole activation once more in
+            # each direction — as many bytes as the mix itself.  Here: one node projects every head's values into its channel slice of
+            # one (B, N, D) tensor, the heads' gates are stacked to (B, H*G, F), and ONE spectral-mix node covers all heads (its
+            # backward = one dV launch + one dgate launch over H*G groups).  Dropout (same p in every head, spectre.py:689) acts on
+            # the fused tensor: the same distribution as per-head masks, drawn in one call.
+            V = _MultiHeadValueFn.apply(x, *[h.W_v.weight for h in self.heads])
+            gate_all = torch.cat([h.spectral_gate(c, pos_phase, with_value=False)[1].to(torch.complex64)
+                                  for h, c in zip(self.heads, chunks)], dim=1)
+            mem = None if memory_fft is None else memory_fft.to(torch.complex64)
+            mixed = _SpectralMixFn.apply(V, gate_all, mem, self.heads[0].n_fft)
+            if p_drop > 0.0 and self.training:
+                mixed = F.dropout(mixed, p_drop, True)
             return self.out_proj(mixed)
+        if p_drop > 0.0 and self.training:
+            return self._forward_per_head(x, pos_phase, memory_fft)
         # One launch for all heads (row N3): every head's value projection lands in its channel slice of one (B, N, D) tensor,
         # the heads' gates are stacked to (B, H*G, F) — channel c of the full tensor belongs to gate row c // d_g exactly as in
         # the per-head calls — and memory_fft is used un-chunked.  Replaces the reference's per-head loop + torch.cat (:712-719).

@@ -205,8 +205,10 @@ def case_decode(name, d, n_fft, G, seed, L, T, *, with_mem=False):
     print(f"{name:28s} decode L={L} T={T} d={d} n_fft={n_fft}  {os.path.getsize(path) / 1e3:.0f} kB")
 
 
-def case_multihead(name, B, N, E, H, n_fft, G, seed, *, with_mem=False, with_phase=False):
-    """SpectreMultiHead.forward (spectre.py:660-726) with the stochastic wavelet refinement switched off: row N3."""
+def case_multihead(name, B, N, E, H, n_fft, G, seed, *, with_mem=False, with_phase=False, with_grad=False):
+    """SpectreMultiHead.forward (spectre.py:660-726) with the stochastic wavelet refinement switched off: row N3.
+    with_grad: also what the reference's autograd returns for a fixed upstream gradient `dout` — d/dx and d/d(every parameter that
+    takes part): the training half of row N3 (one fused mix launch under autograd must reproduce them)."""
     torch.manual_seed(seed)
     mh = ref.SpectreMultiHead(E, H, n_fft, pooling_type="mean", num_groups=G, wavelet_on_rate=0.0).eval()
     g = torch.Generator().manual_seed(seed + 5000)
@@ -222,11 +224,21 @@ def case_multihead(name, B, N, E, H, n_fft, G, seed, *, with_mem=False, with_pha
         d_out["pos_phase"] = pp.numpy()
     with torch.no_grad():
         d_out["out"] = mh(x, pos_phase=pp, memory_fft=mem).numpy()
+    if with_grad:
+        xg = x.clone().requires_grad_(True)
+        out = mh(xg, pos_phase=pp, memory_fft=mem)
+        dout = torch.randn(out.shape, generator=g)
+        (out * dout).sum().backward()
+        d_out["dout"] = dout.numpy()
+        d_out["grad_x"] = xg.grad.numpy()
+        for k, prm in mh.named_parameters():
+            if prm.grad is not None:
+                d_out["grad/" + k] = prm.grad.numpy()
     for k, v in mh.state_dict().items():
         d_out["sd/" + k] = v.numpy()
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **d_out)
-    print(f"{name:28s} multihead x{tuple(x.shape)} H={H}  {os.path.getsize(path) / 1e3:.0f} kB")
+    print(f"{name:28s} multihead x{tuple(x.shape)} H={H}{' + gradients' if with_grad else ''}  {os.path.getsize(path) / 1e3:.0f} kB")
 
 
 def g_random(scale=0.3, zero_frac=0.18):
@@ -303,6 +315,8 @@ def main():
     # G11 — the multi-head wrapper (wavelet refinement off)
     case_multihead("g11_multihead_h2", 2, 64, 32, 2, 64, 2, 40)
     case_multihead("g11_multihead_h4_mem_phase", 2, 48, 64, 4, 64, 2, 41, with_mem=True, with_phase=True)
+    case_multihead("g11_multihead_h3_grad", 2, 256, 96, 3, 256, 2, 42, with_grad=True)
+    case_multihead("g11_multihead_h2_grad_mem_phase", 2, 50, 64, 2, 64, 4, 43, with_mem=True, with_phase=True, with_grad=True)
     # G8 — bf16 input values; oracle = reference on x_bf16.float(); bf16 rounding of the result stored
     case_fixed_gate("g8_bf16_n1024", 1, 1024, 16, 1024, 4, 22, g_random(), bf16=True)
     case_fixed_gate("g8_bf16_n4096", 1, 4096, 16, 4096, 4, 23, g_random(), bf16=True)

@@ -77,3 +77,32 @@ def test_rccl_branch_of_the_rendezvous_runs_on_hardware(tmp_path):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mp.spawn(_rccl_world1, args=(port, str(tmp_path)), nprocs=1, join=True)
     assert json.load(open(tmp_path / "ok.json"))["got"] == [1.25, 7.5]
+
+
+def test_eight_ranks_on_one_gpu():
+    """The launcher, the port handling, the census and the timing protocol at the REAL world size: eight ranks of
+    `python bench.py --gpus 8` on the one GPU of the test box, a small per-rank shape.  The line must carry one attribution record per
+    rank (`per_rank`: kernel_ms, wall_s, start / finish offsets) so that a scaling loss on the 8-GPU node can be pinned on a rank, on the
+    barrier or on the launcher."""
+    args = ["--steps", "6", "--warmup", "2", "--prewarm", "10", "--shape", "16,4096,768", "--no-cpu-baseline"]
+    out, line = _run({"SPECTRE_BENCH_OVERSUBSCRIBE": "1"}, ["--gpus", "8", *args], timeout=900)
+    assert out.returncode == 0 and line is not None, out.stderr[-3000:]
+    assert line["n_gpus"] == 8 and line["rendezvous"] == "gloo" and line["oversubscribed"] and line["distinct_devices"] == 1
+    assert [r["rank"] for r in line["ranks_seen"]] == list(range(8)) and len({r["pid"] for r in line["ranks_seen"]}) == 8
+    assert line["config"]["global_batch"] == 128 and "batch-shard x8" in line["config"]["parallelism"]
+    pr = line["per_rank"]
+    assert [r["rank"] for r in pr] == list(range(8))
+    assert all(r["kernel_ms"] > 0 and r["wall_s"] > 0 and r["start_after_first_us"] >= 0 and r["end_before_last_us"] >= 0 for r in pr)
+    assert min(r["start_after_first_us"] for r in pr) == 0 and min(r["end_before_last_us"] for r in pr) == 0
+    # the agreed start: every rank leaves the spin within a fraction of a millisecond of the first one
+    assert max(r["start_after_first_us"] for r in pr) < 2000, pr
+    # whole-job time = first start -> last finish: never shorter than the slowest rank's own wall time, never longer than the old
+    # definition (which also contains the closing barrier)
+    assert line["wall_s"] >= max(r["wall_s"] for r in pr) - 1e-6
+    assert line["wall_s"] <= line["wall_incl_closing_barrier_s"] + 1e-3
+    assert abs(line["value"] - 8 * 16 * 4096 * 6 / line["wall_s"]) <= 1e-6 * line["value"]
+    assert abs(line["roofline"]["kernel_ms"] - max(r["kernel_ms"] for r in pr)) <= 1e-6
+    assert line["launches_before_timed_region"] == 12
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "bench_w8_oversubscribed.json"), "w") as f:
+        json.dump(line, f)

@@ -65,7 +65,8 @@ def _worker(rank, world, port, scenario, tmp):
         return
     rdv.barrier()
     wall, kern = rdv.max_over_ranks([0.5 + rank, 10.0 - rank])      # bench.py reduces [wall, kernel_ms] this way
-    rec = dict(rdv.describe(), wall=wall, kern=kern, world=rdv.world, rank=rdv.rank)
+    gathered = rdv.gather_over_ranks({"rank": rank, "kernel_ms": 1.0 + rank})   # bench.py's per-rank attribution records (always over gloo)
+    rec = dict(rdv.describe(), wall=wall, kern=kern, world=rdv.world, rank=rdv.rank, gathered=gathered)
     with open(os.path.join(tmp, f"r{rank}.json"), "w") as f:
         json.dump(rec, f)
     if scenario == "hang":
@@ -83,7 +84,7 @@ def test_single_rank_needs_no_process_group():
     sys.path.insert(0, ROOT)
     from fft_amd.rendezvous import rendezvous
     rdv = rendezvous(1, 0, 0, device=None)
-    assert rdv.backend == "none" and rdv.max_over_ranks([1.5, 2.5]) == [1.5, 2.5]
+    assert rdv.backend == "none" and rdv.max_over_ranks([1.5, 2.5]) == [1.5, 2.5] and rdv.gather_over_ranks({"a": 1}) == [{"a": 1}]
     rdv.barrier()
     d = rdv.describe()
     assert d["rendezvous"] == "none" and len(d["ranks_seen"]) == 1 and d["rendezvous_fallback"] is None
@@ -98,6 +99,7 @@ def test_world2_without_devices_uses_gloo(tmp_path):
         assert [x["rank"] for x in rec["ranks_seen"]] == [0, 1]
         assert len({x["pid"] for x in rec["ranks_seen"]}) == 2               # two processes, both seen by both
         assert "no HIP device" in rec["rendezvous_fallback"]
+        assert rec["gathered"] == [{"rank": 0, "kernel_ms": 1.0}, {"rank": 1, "kernel_ms": 2.0}]   # every rank's record, in rank order, on every rank
     assert recs[0]["ranks_seen"] == recs[1]["ranks_seen"]
 
 
@@ -132,3 +134,29 @@ def test_gloo_on_request_does_not_touch_rccl(tmp_path):
     recs = _run(tmp_path, "gloo_requested")
     for rec in recs:
         assert rec["rendezvous"] == "gloo" and rec["rendezvous_fallback"] is None and rec["kern"] == 10.0
+
+
+def test_the_rccl_proof_disarms_the_process_killing_watchdog(monkeypatch):
+    """the time box on the RCCL proof is the caller's (thread join + agreement over gloo).  ProcessGroupNCCL's own watchdog
+    would abort the PROCESS first if the group carried the box's time-out and the default error handling — so the proof must create the
+    group with handling off and a time-out far beyond the box.  (No GPU here: the group constructor and the collectives are stand-ins.)"""
+    sys.path.insert(0, ROOT)
+    import datetime
+    import torch
+    import torch.distributed as dist
+    from fft_amd import rendezvous as rz
+    seen = {}
+    for k in ("TORCH_NCCL_ASYNC_ERROR_HANDLING", "TORCH_NCCL_ENABLE_MONITORING"):
+        monkeypatch.delenv(k, raising=False)
+
+    def fake_new_group(backend=None, timeout=None):
+        seen.update(backend=backend, timeout=timeout, handling=os.environ.get("TORCH_NCCL_ASYNC_ERROR_HANDLING"),
+                    monitoring=os.environ.get("TORCH_NCCL_ENABLE_MONITORING"))
+        raise RuntimeError("stop here")
+
+    monkeypatch.setattr(dist, "new_group", fake_new_group)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
+    with pytest.raises(RuntimeError, match="stop here"):
+        rz._prove_nccl(_fake_device(0), 90.0)
+    assert seen["backend"] == "nccl" and seen["handling"] == "0" and seen["monitoring"] == "0"
+    assert seen["timeout"] >= datetime.timedelta(seconds=20 * 90.0)

@@ -223,9 +223,37 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
     cur_t = __builtin_amdgcn_readfirstlane((int)tick_lds[0]); nxt_t = __builtin_amdgcn_readfirstlane((int)tick_lds[1]);
     __syncthreads();
   }
-  const int pair_base = MAPX == 3 ? xcd_base + cur_t : MAPX == 2 ? ((bx / 16) * 8 + bx % 8) * 2 + (bx / 8) % 2 : MAPX ? wg_lin : (wg_lin / GANG) * a.tpw * GANG + (wg_lin % GANG);
+  // MAPX = 4 (round 5): DYNAMIC tickets per PAIR.  One ticket = the two adjacent tiles (2 T, 2 T + 1) of the XCD's eighth of the tensor = both
+  // halves of every line; the pair's LEADER (even workgroup) draws it from the XCD's counter with a scalar atomic two tiles ahead and publishes
+  // it in the pair's mailbox (a.mem + 10240 words, 8 tagged slots per pair: (sequence + 1) << 16 | ticket; scalar atomic swap, same L2), the
+  // FOLLOWER reads the slot with a scalar load behind E1 and looks at it at the barrier of the middle phase (half a tile of slack).  The chip-wide
+  // window is then 8 x 16 adjacent tile pairs instead of 128 regions 96 tiles apart, and the two halves of a line stay with two workgroups in step.
+  [[maybe_unused]] const int member4 = wg_lin & 1;
+  [[maybe_unused]] unsigned* mbox4 = reinterpret_cast<unsigned*>(const_cast<float*>(a.mem)) + 10240 + 8 * (wg_lin >> 1);   // (behind the TSTAMP areas)
+  [[maybe_unused]] const int per_xcd4 = MAPX == 5 ? a.n_tiles / 2 : a.n_tiles / 16;   // MAPX = 5: ONE counter for the chip (a.mem must then be device-coherent for scalar atomics: uncached memory)
+  [[maybe_unused]] const int base4 = MAPX == 5 ? 0 : xcd_base;
+  if constexpr (MAPX == 5) tick_cnt = reinterpret_cast<unsigned*>(const_cast<float*>(a.mem));
+  if constexpr (MAPX == 4 || MAPX == 5) {
+    if (tid0 == 0) {
+      unsigned t0, t1;
+      if (member4 == 0) {
+        t0 = atomicAdd(tick_cnt, 1u); t1 = atomicAdd(tick_cnt, 1u);
+        __hip_atomic_store(mbox4 + 0, (1u << 16) | t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mbox4 + 1, (2u << 16) | t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        t0 = t1 = 0xffffu;
+        for (int i = 0; i < (1 << 20); ++i) { const unsigned w = __hip_atomic_load(mbox4 + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if ((w >> 16) == 1u) { t0 = w & 0xffffu; break; } __builtin_amdgcn_s_sleep(4); }
+        for (int i = 0; i < (1 << 20); ++i) { const unsigned w = __hip_atomic_load(mbox4 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if ((w >> 16) == 2u) { t1 = w & 0xffffu; break; } __builtin_amdgcn_s_sleep(4); }
+      }
+      tick_lds[0] = t0; tick_lds[1] = t1;
+    }
+    __syncthreads();
+    cur_t = __builtin_amdgcn_readfirstlane((int)tick_lds[0]); nxt_t = __builtin_amdgcn_readfirstlane((int)tick_lds[1]);
+    __syncthreads();
+  }
+  const int pair_base = (MAPX == 4 || MAPX == 5) ? base4 + 2 * cur_t + member4 : MAPX == 3 ? xcd_base + cur_t : MAPX == 2 ? ((bx / 16) * 8 + bx % 8) * 2 + (bx / 8) % 2 : MAPX ? wg_lin : (wg_lin / GANG) * a.tpw * GANG + (wg_lin % GANG);
   const int TS = MAPX ? a.n_wg : GANG;
-  if (MAPX == 3 ? cur_t >= per_xcd : pair_base >= a.n_tiles) return;
+  if ((MAPX == 4 || MAPX == 5) ? cur_t >= per_xcd4 : MAPX == 3 ? cur_t >= per_xcd : pair_base >= a.n_tiles) return;
   // SYNCP: wave 0 announces the workgroup (one atomic add, no return value: older than every request the hand-counted waits look at) and
   // polls the gang's counter with SCALAR loads (lgkmcnt, not the in-order vmcnt the stores sit in); the other waves wait at a barrier.
   // Performance only: the spin is bounded, and a gang whose partner never shows up stops waiting after the first time-out.
@@ -403,10 +431,10 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
     }
   }
 
-  for (int it = 0; MAPX == 3 || it < a.tpw; ++it) {
-    const int tile = MAPX == 3 ? xcd_base + cur_t : pair_base + TS * it;
-    if (MAPX == 3 ? cur_t >= per_xcd : tile >= a.n_tiles) break;                  // workgroup-uniform
-    const bool more = MAPX == 3 ? nxt_t < per_xcd : (it + 1 < a.tpw) && (tile + TS < a.n_tiles);
+  for (int it = 0; MAPX == 3 || MAPX == 4 || MAPX == 5 || it < a.tpw; ++it) {
+    const int tile = (MAPX == 4 || MAPX == 5) ? base4 + 2 * cur_t + member4 : MAPX == 3 ? xcd_base + cur_t : pair_base + TS * it;
+    if ((MAPX == 4 || MAPX == 5) ? cur_t >= per_xcd4 : MAPX == 3 ? cur_t >= per_xcd : tile >= a.n_tiles) break;                  // workgroup-uniform
+    const bool more = (MAPX == 4 || MAPX == 5) ? nxt_t < per_xcd4 : MAPX == 3 ? nxt_t < per_xcd : (it + 1 < a.tpw) && (tile + TS < a.n_tiles);
     coords();
     if constexpr (TSTAMP == 2) { if (it == 0) ph_last = __builtin_amdgcn_s_memrealtime(); }
     mark(0);                                       // (gate fetch of the previous iteration .. here)
@@ -414,12 +442,16 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
     if constexpr (MAPX == 3) {                     // the ticket of the tile after next: requested now, in the LDS word behind F1's barrier
       if (__builtin_amdgcn_readfirstlane(tid0 >> 6) == 0) asm volatile("s_atomic_add %0, %1, 0x0 glc" : "+s"(fut) : "s"(tick_cnt) : "memory");
     }
+    [[maybe_unused]] unsigned* slot4 = mbox4 + ((it + 2) & 7);
+    if constexpr (MAPX == 4 || MAPX == 5) {        // the leader draws the pair's ticket of the tile after next
+      if (__builtin_amdgcn_readfirstlane(tid0 >> 6) == 0 && member4 == 0) asm volatile("s_atomic_add %0, %1, 0x0 glc" : "+s"(fut) : "s"(tick_cnt) : "memory");
+    }
     long long v_sn = a.v_sn, out_sn = a.out_sn;
     asm volatile("" : "+s"(v_sn), "+s"(out_sn));
     const char* vb; char* ob; const float2* gp;
     tile_ptrs(tile, vb, ob, gp);
     const char* vbn = vb; char* obn = ob; const float2* gpn = gp;
-    if (more) tile_ptrs(MAPX == 3 ? xcd_base + nxt_t : tile + TS, vbn, obn, gpn);
+    if (more) tile_ptrs((MAPX == 4 || MAPX == 5) ? base4 + 2 * nxt_t + member4 : MAPX == 3 ? xcd_base + nxt_t : tile + TS, vbn, obn, gpn);
     const __amdgpu_buffer_rsrc_t rs_next = rsrc_in(vbn, v_sn, more), rs_out = rsrc_out(ob, out_sn);
     // PFL2: touch the half lines of the row groups that will be RELOADED behind this tile's stores (one dword per row, LDS-DMA into a dump
     // word area: no register, tracked by vmcnt like every other request) so that the reloads find their lines in the L2.  Wave w covers the
@@ -525,6 +557,14 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
         if constexpr (ka == 0 && MAPX == 3) {       // (the barrier waited for lgkmcnt(0): the scalar atomic has returned)
           if (__builtin_amdgcn_readfirstlane(tid0 >> 6) == 0) { asm volatile("" : "+s"(fut)); if (lane == 0) tick_lds[0] = fut; }
         }
+        if constexpr (ka == 0 && (MAPX == 4 || MAPX == 5)) {       // leader: publish the ticket (fire and forget) and hand it to the other waves
+          if (__builtin_amdgcn_readfirstlane(tid0 >> 6) == 0 && member4 == 0) {
+            asm volatile("" : "+s"(fut));
+            unsigned pub = ((unsigned)(it + 3) << 16) | (fut & 0xffffu);
+            asm volatile("s_atomic_swap %0, %1, 0x0" :: "s"(pub), "s"(slot4) : "memory");
+            if (lane == 0) tick_lds[0] = fut;
+          }
+        }
         p64v_write_col<ka, false>(z, img, p, u);
         __builtin_amdgcn_sched_barrier(0);
       });
@@ -595,6 +635,10 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
     });
     else p64v_exchange_rest<false>(z, img, p, u);
 
+    [[maybe_unused]] unsigned got4 = 0;
+    if constexpr (MAPX == 4 || MAPX == 5) {        // follower: ask for the pair's ticket of the tile after next (published by the leader at ITS F1 barrier)
+      if (__builtin_amdgcn_readfirstlane(tid0 >> 6) == 0 && member4 != 0) asm volatile("s_load_dword %0, %1, 0x0 glc" : "=s"(got4) : "s"(slot4) : "memory");
+    }
     // ---- middle: F2 -> gate -> I1 (kernel_regtile.h; bin of register (ka, kb): k = k1 + 64 k2, k2 = ka + 8 kb) -------------
     {
       const int k1 = u;
@@ -655,6 +699,17 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
       });
       // type B stage 2: radix-8 over ka (positions 8 ka + n_lo) -> natural order, position n2 = n_lo + 8 n_hi.  Every wave has long
       // finished E1's reads; behind this barrier the image is written again, column by column like in F1.
+      if constexpr (MAPX == 4 || MAPX == 5) {      // follower: the slot must carry this sequence number; a leader that is behind is waited for (bounded)
+        if (__builtin_amdgcn_readfirstlane(tid0 >> 6) == 0 && member4 != 0) {
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(got4) :: "memory");
+          for (int i = 0; i < (1 << 16) && (got4 >> 16) != (unsigned)(it + 3); ++i) {
+            __builtin_amdgcn_s_sleep(8);
+            asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(got4) : "s"(slot4) : "memory");
+          }
+          const unsigned tk = (got4 >> 16) == (unsigned)(it + 3) ? (got4 & 0xffffu) : 0xffffu;   // (time-out: this workgroup stops)
+          if (lane == 0) tick_lds[0] = tk;
+        }
+      }
       p64v_barrier();
       static_for<0, 8>([&](auto nc) {
         constexpr int nlo = decltype(nc)::value;
@@ -688,7 +743,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
     float2 wa[8], wb[8];
     load_twiddles(wa, wb, u);
     [[maybe_unused]] int fut_t = 0;
-    if constexpr (MAPX == 3) fut_t = __builtin_amdgcn_readfirstlane((int)tick_lds[0]);
+    if constexpr (MAPX >= 3) fut_t = __builtin_amdgcn_readfirstlane((int)tick_lds[0]);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // DSPREAD: 0 = all 4 * SPLIT LDS-DMA requests in one burst; 1 = spread over the conj-twiddle multiplications (one share per 8 positions);
     // 2 = spread over the twiddle multiplications and the eight butterflies of I2's first stage
@@ -906,7 +961,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
     obp = ob;
     if constexpr (SYNCP == 14) p64v_barrier();
     if constexpr (RLF == 0) gate_fetch(gpn);     // committed to LDS at the end of the next tile's F1 (after the last tile: a harmless re-read of this tile's bins)
-    if constexpr (MAPX == 3) { cur_t = nxt_t; nxt_t = fut_t; }
+    if constexpr (MAPX >= 3) { cur_t = nxt_t; nxt_t = fut_t; }
     mark(11);                                      // reload issue + gate fetch issue
   }  // tile loop
   if constexpr (PARK != 0) {                       // the last tile's parked group
