@@ -57,6 +57,8 @@ struct RegtileArgs {
   int conj_gate;        // 1: filter with conj(gate) — the adjoint w.r.t. v (dV = mix(dOut, conj(gate)))
   int rows_in, rows_out;   // kernel_regtile64p.h: input rows that exist (min(N_in, n_fft); the rest is rfft's zero padding) and output rows
                            // that are written (spectre.py:553) = the extents of its buffer resources
+  unsigned* tickets;       // kernel_regtile64p.h TICKETS: this launch's slice of the plan's ticket ring (uncached device memory, zeroed on
+                           // the launch's stream): counter | gang mailboxes | one claim bit per tile.  nullptr: static tile map
 };
 
 constexpr int kPC = 8;                       // pair-columns per tile: 16 channels, 64-byte fp32 row segments

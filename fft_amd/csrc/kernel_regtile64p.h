@@ -66,6 +66,18 @@ constexpr int kP64TwOff = (regtile_lds_total<64, 64, 1>() + 15) & ~15;
 constexpr int kP64LdsTotal = kP64TwOff + 64 * 14 * 8;
 static_assert(kP64LdsTotal <= 160 * 1024, "LDS budget");
 
+// TICKETS (round 5): the launch's slice of the plan's ticket ring (RegtileArgs::tickets; UNCACHED device memory — the counter is driven
+// by scalar atomics, which carry no scope bits: only memory the L2 does not keep is coherent between XCDs for them), in 32-bit words:
+//   [0]                      the chip-wide ticket counter
+//   [kP64TkBox + 8 g ...]    mailbox of gang g: 8 slots, (tag << 24) | ticket, tag = sequence % 255 + 1 (never 0 = the reset state)
+//   [kP64TkClaim ...]        one claim bit per TILE (tile index = GANG * ticket + member)
+// and two LDS words behind everything else (the next-but-one tile on its way from wave 0 to the other waves).
+constexpr int kP64TkBox = 16, kP64TkClaim = 2048, kP64TkSliceWords = 16384;
+constexpr unsigned kP64TkEnd = 0xffffffu;         // "no more tickets" in a mailbox slot
+constexpr int kP64LdsTotalT = kP64LdsTotal + 16;
+static_assert(kP64LdsTotalT <= 160 * 1024, "LDS budget");
+constexpr int p64_ticket_capacity() { return (kP64TkSliceWords - kP64TkClaim) * 32; }      // tiles one slice can keep claim bits for
+
 typedef unsigned int p64_u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kP64RsrcFlags = 0x00020000;        // raw buffer, 32-bit data format (gfx90a / gfx942 / gfx950 dword 3)
 
@@ -214,7 +226,22 @@ template <int SPLIT> constexpr int p64_younger_first() { return 4 * (8 - SPLIT) 
 //         three spreads: bf16 -> fp32 1.385 -> 1.312 ms (-5.2 %; (2,3) spread -2.6 %), bf16 -> bf16 1.319 -> 1.187 ms (-10 %) on one box
 //         (profiles/r04_p64v_bf16_spread.log).  fp32 rows + memory_fft, (4, 1): phased order -7.7 %, + the three spreads -11.5 % (2.025 -> 1.793 ms,
 //         profiles/r04_p64v_mem_spread.log).
-template <int SPLIT, int PF, bool WITH_MEM = false, bool IN_BF16 = false, bool OUT_BF16 = false, bool BURST = false, bool SPREAD = false>
+// TICKETS = (round 5) DYNAMIC tile order.  With the static map every gang owns its own region of the tensor, so at any time the chip has
+//         all 256 batch elements open (2 x 3.2 GB); a pure copy in this tile shape runs 40 % faster (64-byte tiles; 32-byte tiles 43 %, 128-byte
+//         tiles 10 %) when the gangs instead take adjacent tiles from ONE counter in address order — the chip-wide window is then a few
+//         batch elements (tools/window_lab.hip, profiles/r05_window_lab_tile_maps.log) — provided the workgroups that share a line keep
+//         walking in step: one ticket per GANG (= GANG adjacent tiles = every piece of a row's 128-byte line), not per workgroup (that
+//         was round 4's attempt: +0.6 ... +17 %).  The gang's LEADER (member 0) draws the ticket two tiles ahead with a scalar atomic
+//         (lgkmcnt: no place in the in-order vmcnt the hand-counted waits look at), publishes it in the gang's mailbox and every member
+//         claims its own tile of the ticket by setting the tile's claim bit (atomic or, scalar as well); the requests are issued at the
+//         barriers the tile has anyway (each waits for lgkmcnt(0)), one step of the little state machine per barrier, so nothing waits
+//         for a round trip.  Correctness never depends on the members of a gang being resident together: a tile is processed by whoever
+//         set its claim bit (exactly one workgroup can), a follower whose leader does not publish in time stops following, and every
+//         workgroup that runs out of tickets SWEEPS the claim bits for tiles nobody has claimed and processes them one at a time.
+//         A ticket whose tile this member did not get (claimed by a sweeper, or beyond the last tile) is a PHANTOM tile: the same
+//         instruction stream over empty buffer ranges, so that the gang stays in step.  Harness, same box, one process: -3.3 % with one
+//         counter per XCD (profiles/r05_p64v_ab_31_pair_tickets.log).
+template <int SPLIT, int PF, bool WITH_MEM = false, bool IN_BF16 = false, bool OUT_BF16 = false, bool BURST = false, bool SPREAD = false, bool TICKETS = false>
 __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileArgs a) {
   constexpr int ESI = IN_BF16 ? 2 : 4, ESO = OUT_BF16 ? 2 : 4;   // bytes per input / output element
   constexpr float inv_n = 1.0f / 4096.0f;
@@ -262,7 +289,19 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
   constexpr int GANG = p64_gang(IN_BF16, OUT_BF16, BURST);
   const int wg_lin = xcd_contiguous(blockIdx.x, a.n_wg);
   const int pair_base = (wg_lin / GANG) * a.tpw * GANG + (wg_lin % GANG);
-  if (pair_base >= a.n_tiles) return;
+  if constexpr (!TICKETS) { if (pair_base >= a.n_tiles) return; }
+  // ---- TICKETS: tiles are GANG * ticket + member; a tile variable holds a tile index, -1 (phantom) or -2 (no more tickets)
+  [[maybe_unused]] const int tk_member = wg_lin % GANG;
+  [[maybe_unused]] unsigned* const tk_cnt = a.tickets;
+  [[maybe_unused]] unsigned* const tk_box = a.tickets + kP64TkBox + 8 * (wg_lin / GANG);
+  [[maybe_unused]] unsigned* const tk_claim = a.tickets + kP64TkClaim;
+  [[maybe_unused]] volatile int* const tk_lds = reinterpret_cast<volatile int*>(smem + kP64LdsTotal);
+  [[maybe_unused]] const unsigned tk_total = (unsigned)((a.n_tiles + GANG - 1) / GANG);
+  [[maybe_unused]] const bool tk_w0 = __builtin_amdgcn_readfirstlane(tid0 >> 6) == 0;
+  [[maybe_unused]] auto tk_tag = [](int seq) -> unsigned { return (unsigned)(seq % 255) + 1u; };
+  [[maybe_unused]] int cur_tile = -2, nxt_tile = -2;
+  [[maybe_unused]] int tk_seq = 2;                 // sequence number (within the gang's stream) of the ticket being acquired
+  [[maybe_unused]] bool tk_follow = true;          // false: the leader stopped publishing in time (or the stream ended): go and sweep
 
   float2 z[64];
   float4 dfr[PF > 0 ? 4 * PF : 1];                 // deferred results of the previous tile / prefetched rows of the next one
@@ -395,36 +434,121 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
     });
   };
 
+  static_assert(!TICKETS || (SPREAD && BURST), "TICKETS: built on the phased order with spread requests");
+  // TICKETS: round 0 follows the gang's tickets; every later round processes ONE tile that nobody has claimed (the sweep).  Static map: one round.
+  for (int round = 0;; ++round) {
+  if constexpr (TICKETS) {
+    if (round == 0) {
+      // the first two tickets of the gang, synchronously (nothing is in flight yet): the leader draws and publishes, the others read
+      if (tid0 == 0) {
+        for (int sq = 0; sq < 2; ++sq) {
+          unsigned t = kP64TkEnd;
+          if (tk_member == 0) {
+            t = __hip_atomic_fetch_add(tk_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t >= tk_total) t = kP64TkEnd;
+            __hip_atomic_store(tk_box + sq, (tk_tag(sq) << 24) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } else {
+            for (int i = 0; i < (1 << 18); ++i) {      // (bounded: a leader that is not resident yet must not hang this workgroup)
+              const unsigned w = __hip_atomic_load(tk_box + sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if ((w >> 24) == tk_tag(sq)) { t = w & 0xffffffu; break; }
+              __builtin_amdgcn_s_sleep(8);
+            }
+          }
+          int tl = -2;
+          if (t != kP64TkEnd) {
+            const unsigned ti = t * GANG + tk_member;
+            tl = -1;
+            if (ti < (unsigned)a.n_tiles && !(__hip_atomic_fetch_or(tk_claim + (ti >> 5), 1u << (ti & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (1u << (ti & 31)))) tl = (int)ti;
+          }
+          tk_lds[sq] = tl;
+        }
+      }
+      __syncthreads();
+      cur_tile = __builtin_amdgcn_readfirstlane(tk_lds[0]); nxt_tile = __builtin_amdgcn_readfirstlane(tk_lds[1]);   // (uniform: SGPRs)
+      __syncthreads();
+      tk_follow = nxt_tile != -2;
+      if (cur_tile == -2) nxt_tile = -2;
+    } else {
+      // sweep: the lowest tile whose claim bit is still clear (every thread looks at its share of the bit words; LDS minimum)
+      asm volatile("s_waitcnt vmcnt(0) ; lint: drain" ::: "memory");
+      __syncthreads();
+      if (tid0 == 0) tk_lds[0] = 0x7fffffff;
+      __syncthreads();
+      const int n_words = (a.n_tiles + 31) >> 5;
+      const int sw = (int)((long long)wg_lin * n_words / a.n_wg);   // every workgroup starts looking somewhere else (fewer collisions when many sweep)
+      for (int w = tid0; w < n_words; w += 512) {
+        unsigned fr = ~__hip_atomic_load(tk_claim + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (32 * w + 32 > a.n_tiles) fr &= (1u << (a.n_tiles - 32 * w)) - 1u;
+        if (fr) atomicMin(const_cast<int*>(tk_lds), 32 * (w >= sw ? w - sw : w - sw + n_words) + (int)__builtin_ctz(fr));
+      }
+      __syncthreads();
+      const int key = __builtin_amdgcn_readfirstlane(tk_lds[0]);
+      __syncthreads();
+      if (key == 0x7fffffff) break;                  // every tile has an owner: done
+      const int cand = 32 * (((key >> 5) + sw) % n_words) + (key & 31);
+      if (tid0 == 0) tk_lds[1] = (__hip_atomic_fetch_or(tk_claim + (cand >> 5), 1u << (cand & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (cand & 31)) & 1u;
+      __syncthreads();
+      const int lost = __builtin_amdgcn_readfirstlane(tk_lds[1]);
+      __syncthreads();
+      if (lost) continue;                            // somebody else took it in the meantime: look again
+      cur_tile = cand; nxt_tile = -2;
+    }
+    if (cur_tile == -2) continue;                    // (round 0 without a single ticket: straight to the sweep)
+  }
+  [[maybe_unused]] bool prev_live = false;         // TICKETS: the previous tile of this round was a real one (its deferred results are stored)
   // ---- prologue: request tile 0 the same way every later tile is requested --------------------------------------------
   {
     const char* vb; char* ob; const float2* gp;
-    tile_ptrs(pair_base, vb, ob, gp);
+    tile_ptrs(TICKETS ? (cur_tile >= 0 ? cur_tile : 0) : pair_base, vb, ob, gp);
     const uint32_t voff = (uint32_t)(((long long)(u + 512 * h) * a.v_sn + 4 * pp) * ESI);
-    const __amdgpu_buffer_rsrc_t rs = rsrc_in(vb, a.v_sn);
+    const __amdgpu_buffer_rsrc_t rs = rsrc_in(vb, a.v_sn, TICKETS ? cur_tile >= 0 : true);
     static_for<0, SPLIT>([&](auto gc) { dma_group(rs, dma_voff(voff, a.v_sn), a.v_sn, gc); });
     asm volatile("" ::: "memory");
     static_for<SPLIT, 8>([&](auto gc) { load_group(rs, voff, a.v_sn, gc); });
     gate_fetch(gp);
   }
 
-  for (int it = 0; it < a.tpw; ++it) {
-    const int tile = pair_base + GANG * it;
-    if (tile >= a.n_tiles) break;                  // workgroup-uniform
-    const bool more = (it + 1 < a.tpw) && (tile + GANG < a.n_tiles);
+  for (int it = 0; TICKETS || it < a.tpw; ++it) {
+    const int tile = TICKETS ? (cur_tile >= 0 ? cur_tile : 0) : pair_base + GANG * it;
+    if (TICKETS ? cur_tile == -2 : tile >= a.n_tiles) break;                  // workgroup-uniform
+    const bool more = TICKETS ? nxt_tile >= 0 : (it + 1 < a.tpw) && (tile + GANG < a.n_tiles);
+    [[maybe_unused]] const bool cur_live = TICKETS ? cur_tile >= 0 : true;     // false: a phantom tile (empty ranges: loads return 0, stores are dropped)
     coords();
+    // ---- TICKETS: the tile after next.  Wave 0 moves a small state machine one step at each of the barriers the tile has anyway (they wait
+    //      for lgkmcnt(0), which is what a scalar request returns through):
+    //        leader:   H0 draw (s_atomic_add) | H1 publish (s_atomic_swap into the mailbox) + claim (s_atomic_or) | H2 result -> LDS
+    //        follower: H3 read the mailbox (s_load_dword glc) | H4 check the tag (a late leader is waited for, bounded) + claim | H5 result -> LDS
+    [[maybe_unused]] unsigned tk_a = 1, tk_b = 0, tk_bit = 0;
+    [[maybe_unused]] int tk_tile = -2;
+    [[maybe_unused]] unsigned* const tk_slot = tk_box + (tk_seq & 7);
+    [[maybe_unused]] const bool tk_lead = tk_w0 && tk_member == 0 && round == 0 && tk_follow, tk_foll = tk_w0 && tk_member != 0 && round == 0 && tk_follow;
+    [[maybe_unused]] auto tk_claim_issue = [&](unsigned t) {      // t < tk_total: ask for this member's tile of ticket t
+      const unsigned ti = t * GANG + tk_member;
+      tk_tile = -1;
+      if (ti < (unsigned)a.n_tiles) {
+        tk_tile = (int)ti; tk_bit = 1u << (ti & 31); tk_b = tk_bit;
+        unsigned* wp = tk_claim + (ti >> 5);
+        asm volatile("s_atomic_or %0, %1, 0x0 glc" : "+s"(tk_b) : "s"(wp) : "memory");
+      }
+    };
+    [[maybe_unused]] auto tk_claim_result = [&]() {                 // (behind a wait for lgkmcnt(0)) -> the LDS word the other waves read
+      if (tk_tile >= 0) { asm volatile("" : "+s"(tk_b)); if (tk_b & tk_bit) tk_tile = -1; }
+      if (lane == 0) tk_lds[0] = tk_tile;
+    };
+    if constexpr (TICKETS) { if (tk_lead) asm volatile("s_atomic_add %0, %1, 0x0 glc" : "+s"(tk_a) : "s"(tk_cnt) : "memory"); }   // H0
     long long v_sn = a.v_sn, out_sn = a.out_sn;
     asm volatile("" : "+s"(v_sn), "+s"(out_sn));
     const char* vb; char* ob; const float2* gp;
     tile_ptrs(tile, vb, ob, gp);
     const char* vbn = vb; char* obn = ob; const float2* gpn = gp;
-    if (more) tile_ptrs(tile + GANG, vbn, obn, gpn);
-    const __amdgpu_buffer_rsrc_t rs_next = rsrc_in(vbn, v_sn, more), rs_out = rsrc_out(ob, out_sn);
+    if (more) tile_ptrs(TICKETS ? nxt_tile : tile + GANG, vbn, obn, gpn);
+    const __amdgpu_buffer_rsrc_t rs_next = rsrc_in(vbn, v_sn, more), rs_out = rsrc_out(ob, out_sn, cur_live);
 
     [[maybe_unused]] const uint32_t pf_ooff = (uint32_t)(((long long)(u + 512 * h) * out_sn + 4 * pp) * ESO);
     [[maybe_unused]] const uint32_t pf_voff = (uint32_t)(((long long)(u + 512 * h) * v_sn + 4 * pp) * ESI);
     [[maybe_unused]] auto pf_store = [&](auto ic) {
       constexpr int g = GP + decltype(ic)::value / 4, m = decltype(ic)::value % 4;
-      store16(rsrc_out(obp, out_sn, it > 0), pf_ooff + (uint32_t)((64 * g + 1024 * m) * out_sn * ESO), dfr[decltype(ic)::value]);
+      store16(rsrc_out(obp, out_sn, TICKETS ? prev_live : it > 0), pf_ooff + (uint32_t)((64 * g + 1024 * m) * out_sn * ESO), dfr[decltype(ic)::value]);
     };
     [[maybe_unused]] auto pf_load = [&](auto ic) {
       constexpr int g = GP + decltype(ic)::value / 4, m = decltype(ic)::value % 4;
@@ -475,6 +599,15 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
         if constexpr (SPREAD) { static_for<ka * (4 * PF) / 8, (ka + 1) * (4 * PF) / 8>([&](auto ic) { pf_store(ic); }); __builtin_amdgcn_sched_barrier(0); }
         if constexpr (ka == 0) p64_barrier();      // every wave has emptied its landing slots (and finished E2's reads of the previous
                                                    // tile): the image may be written
+        if constexpr (ka == 0 && TICKETS) {          // H1 (the barrier waited for lgkmcnt(0): the ticket is here)
+          if (tk_lead) {
+            asm volatile("" : "+s"(tk_a));
+            const unsigned t = tk_a < tk_total ? tk_a : kP64TkEnd;
+            const unsigned pub = (tk_tag(tk_seq) << 24) | t;
+            asm volatile("s_atomic_swap %0, %1, 0x0" :: "s"(pub), "s"(tk_slot) : "memory");      // (no return value: fire and forget)
+            if (t != kP64TkEnd) tk_claim_issue(t);
+          }
+        }
         p64_write_col<ka, false>(z, img, p, u);
         __builtin_amdgcn_sched_barrier(0);
       });
@@ -497,9 +630,11 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
     //      the image stays busy until the barrier in front of the middle phase's last stage.
     if constexpr (SPREAD) p64_exchange_rest<false>(z, img, p, u, [&](auto kc) {       // half of the deferred loads in E1's three gaps ...
       constexpr int k = decltype(kc)::value, H = (4 * PF) / 2;
+      if constexpr (TICKETS && k == 0) { if (tk_lead) tk_claim_result(); }             // H2
       static_for<k * H / 3, (k + 1) * H / 3>([&](auto ic) { pf_load(ic); });
     });
     else p64_exchange_rest<false>(z, img, p, u);
+    if constexpr (TICKETS) { if (tk_foll) asm volatile("s_load_dword %0, %1, 0x0 glc" : "=s"(tk_a) : "s"(tk_slot) : "memory"); }   // H3
 
     // ---- middle: F2 -> gate -> I1 (kernel_regtile.h; bin of register (ka, kb): k = k1 + 64 k2, k2 = ka + 8 kb) -------------
     {
@@ -561,6 +696,17 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
       });
       // type B stage 2: radix-8 over ka (positions 8 ka + n_lo) -> natural order, position n2 = n_lo + 8 n_hi.  Every wave has long
       // finished E1's reads; behind this barrier the image is written again, column by column like in F1.
+      if constexpr (TICKETS) {                       // H4: the slot must carry this sequence number; a leader that is behind is waited for
+        if (tk_foll) {
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(tk_a) :: "memory");
+          for (int i = 0; i < (1 << 16) && (tk_a >> 24) != tk_tag(tk_seq); ++i) {
+            __builtin_amdgcn_s_sleep(8);
+            asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(tk_a) : "s"(tk_slot) : "memory");
+          }
+          if ((tk_a >> 24) == tk_tag(tk_seq) && (tk_a & 0xffffffu) != kP64TkEnd) tk_claim_issue(tk_a & 0xffffffu);
+          // (no ticket in time, or the end of the stream: tk_tile stays -2 and this workgroup goes on to the sweep)
+        }
+      }
       p64_barrier();
       static_for<0, 8>([&](auto nc) {
         constexpr int nlo = decltype(nc)::value;
@@ -574,7 +720,8 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
 
     // ---- E2: position n2 -> image row n2, column (p, k1 = u); thread (p, u) reads row u, slot k1.  The barrier behind the last read
     //      frees the image for the LDS-DMA below.
-    p64_exchange_rest<true>(z, img, p, u);
+    if constexpr (TICKETS) p64_exchange_rest<true>(z, img, p, u, [&](auto kc) { if constexpr (decltype(kc)::value == 0) { if (tk_foll) tk_claim_result(); } });   // H5
+    else p64_exchange_rest<true>(z, img, p, u);
 
     // ---- the image is idle until the next F1: let the first row groups of the next tile land in it, and fetch its gate -----
     const uint32_t voff = (uint32_t)(((long long)(u + 512 * h) * v_sn + 4 * pp) * ESI);
@@ -582,6 +729,8 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
     //  s_waitcnt vmcnt(0) — the whole HBM round trip of the requests below, at the start of every burst)
     float2 wa[8], wb[8];
     load_twiddles(wa, wb, u);
+    [[maybe_unused]] int fut_tile = -2;
+    if constexpr (TICKETS) { if (round == 0 && tk_follow) fut_tile = __builtin_amdgcn_readfirstlane(tk_lds[0]); }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // SPREAD: request q = 4 g + m of the burst (fp32 rows: group g, instruction m), issued in 24 shares
     constexpr int NDMA = (IN_BF16 ? 2 : 4) * SPLIT, NSHARE = 24;   // (bf16 rows: two requests per group, dma_group)
@@ -694,7 +843,13 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
       }
     obp = ob;
     gate_fetch(gpn);     // committed to LDS at the end of the next tile's F1 (after the last tile: a harmless re-read of this tile's bins)
+    if constexpr (TICKETS) {
+      prev_live = cur_live; cur_tile = nxt_tile; nxt_tile = fut_tile; ++tk_seq;
+      if (fut_tile == -2) tk_follow = false;         // the stream has ended (or the leader fell silent): no more requests
+    }
   }  // tile loop
+  if constexpr (!TICKETS) break;
+  }  // rounds
 }
 
 hipError_t launch_regtile64p(const RegtileArgs& a, bool in_bf16, bool out_bf16, bool burst, hipStream_t stream);

@@ -5,7 +5,7 @@
 namespace sfft {
 hipError_t launch_regtile64p(const RegtileArgs& a, bool in_bf16, bool out_bf16, bool burst, hipStream_t stream) {
   const bool with_mem = a.mem != nullptr;
-  static std::atomic<bool> lds_opt_in[16][8];   // [device]: > 64 KiB of dynamic LDS needs a one-time opt-in (idempotent; the flag only saves the call)
+  static std::atomic<bool> lds_opt_in[16][16];   // [device]: > 64 KiB of dynamic LDS needs a one-time opt-in (idempotent; the flag only saves the call)
   // <SPLIT, PF>: SPLIT row groups of the next tile travel through LDS (LDS-DMA, requested before the stores), PF row groups have their
   // stores / loads moved out of the store/load burst to the end of F1 (16 registers each); the other 8 - SPLIT - PF groups are reloaded
   // behind their own stores.  Interleaved A/B on one box (profiles/r02_p64_ab_waits.log): (4,1) 1.591 ms, (4,2) 1.563, (4,3) 1.548,
@@ -33,15 +33,23 @@ hipError_t launch_regtile64p(const RegtileArgs& a, bool in_bf16, bool out_bf16, 
   if (burst && !with_mem && in_bf16 && !out_bf16) kern = spectre_mix_regtile64p<5, 3, false, true, false, true, true>;
   if (burst && !with_mem && in_bf16 && out_bf16) kern = spectre_mix_regtile64p<5, 3, false, true, true, true, true>;
 
-  const int variant = in_bf16 ? (out_bf16 ? (burst && !with_mem ? 6 : 3) : burst && !with_mem ? 5 : 2) : with_mem ? (burst ? 7 : 1) : burst ? 4 : 0;
+  // round 5: DYNAMIC tile tickets per gang (a.tickets = this launch's zeroed slice of the plan's ticket ring; spectre_hip.hip decides):
+  // the chip-wide window of open rows shrinks from every batch element to a few (kernel_regtile64p.h, TICKETS)
+  const bool tickets = a.tickets != nullptr && burst && !with_mem;
+  if (tickets && !in_bf16) kern = spectre_mix_regtile64p<3, 3, false, false, false, true, true, true>;
+  if (tickets && in_bf16 && !out_bf16) kern = spectre_mix_regtile64p<5, 3, false, true, false, true, true, true>;
+  if (tickets && in_bf16 && out_bf16) kern = spectre_mix_regtile64p<5, 3, false, true, true, true, true, true>;
+
+  const int variant = (in_bf16 ? (out_bf16 ? (burst && !with_mem ? 6 : 3) : burst && !with_mem ? 5 : 2) : with_mem ? (burst ? 7 : 1) : burst ? 4 : 0) + (tickets ? 8 : 0);
+  const int lds = tickets ? kP64LdsTotalT : kP64LdsTotal;
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev < 0 || dev >= 16 || !lds_opt_in[dev][variant]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kP64LdsTotal);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 16) lds_opt_in[dev][variant] = true;
   }
-  hipLaunchKernelGGL(kern, dim3(a.n_wg), dim3(512), kP64LdsTotal, stream, a);
+  hipLaunchKernelGGL(kern, dim3(a.n_wg), dim3(512), lds, stream, a);
   return hipGetLastError();
 }
 }  // namespace sfft

@@ -5,6 +5,7 @@
 // No computation happens on the host beyond twiddle/chirp tables (double precision, once per plan).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -18,6 +19,7 @@
 
 #include "../../include/spectre_hip.h"
 #include "kernel_regtile_grad.h"
+#include "kernel_regtile64p.h"   // (the ticket-slice layout constants)
 #include "kernel_regtile_wide.h"
 #include "kernel_regtile_mixed_grad.h"
 #include "kernel_stockham.h"
@@ -152,7 +154,7 @@ const char* tuning_env(const char* name) {
 }
 std::string tuning_overrides() {
   std::string r;
-  for (const char* n : {"SPECTRE_P64", "SPECTRE_P64_BF16", "SPECTRE_P64_BURST", "SPECTRE_WIDE", "SPECTRE_WIDE_MAX", "SPECTRE_WIDE_NT", "SPECTRE_MIXEDP", "SPECTRE_STOCKHAM_PMAX", "SPECTRE_TPW", "SPECTRE_P64_TPW", "SPECTRE_GATE_GRAD"})
+  for (const char* n : {"SPECTRE_P64", "SPECTRE_P64_BF16", "SPECTRE_P64_BURST", "SPECTRE_P64_TICKETS", "SPECTRE_P64_TICKETS_BF16", "SPECTRE_WIDE", "SPECTRE_WIDE_MAX", "SPECTRE_WIDE_NT", "SPECTRE_MIXEDP", "SPECTRE_STOCKHAM_PMAX", "SPECTRE_TPW", "SPECTRE_P64_TPW", "SPECTRE_GATE_GRAD"})
     if (const char* e = tuning_env(n)) r += std::string(r.empty() ? "" : " ") + n + "=" + e;
   return r;
 }
@@ -169,6 +171,8 @@ int fail(int code, const char* fmt, ...) {
 
 constexpr size_t kLdsBytes = 160 * 1024;   // gfx950: 160 KiB per CU, one workgroup may take all of it
 
+constexpr int kTicketSlices = 64;
+
 struct Plan {
   int device = 0;
   int64_t n = 0;
@@ -183,6 +187,12 @@ struct Plan {
   float2* tw_m = nullptr;
   float2* chirp = nullptr;
   float2* bhat = nullptr;
+  // n_fft = 4096, round 5: ring of ticket slices for the dynamic tile order of kernel_regtile64p.h (TICKETS): UNCACHED device memory
+  // (scalar atomics carry no scope bits, so only memory the L2 does not keep is coherent between XCDs for them).  Every launch takes the
+  // next slice and zeroes the part it uses on its own stream, so launches in flight on different streams never share one (up to
+  // kTicketSlices of them).  nullptr (allocation refused): the static tile map.
+  unsigned* tk_ring = nullptr;
+  mutable std::atomic<unsigned> tk_next{0};
 
   ~Plan() {
     // best effort: the owning device must be current for hipFree
@@ -193,6 +203,7 @@ struct Plan {
       if (tw_m) (void)hipFree(tw_m);
       if (chirp) (void)hipFree(chirp);
       if (bhat) (void)hipFree(bhat);
+      if (tk_ring) (void)hipFree(tk_ring);
       (void)hipSetDevice(cur);
     }
   }
@@ -286,6 +297,11 @@ int build_plan(int device, int64_t n, Plan** out) {
     for (int64_t j = 0; j < m; ++j) bh[(size_t)j] = make_float2((float)bt[(size_t)j].first, (float)bt[(size_t)j].second);
     if ((e = upload(w, &plan->chirp)) != hipSuccess || (e = upload(bh, &plan->bhat)) != hipSuccess)
       return fail(SPECTRE_E_HIP, "plan(bluestein tables): %s", hipGetErrorString(e));
+  }
+  if (n == 4096) {                                   // ticket ring (optional: without it the kernels keep the static tile map)
+    void* ring = nullptr;
+    if (hipExtMallocWithFlags(&ring, (size_t)kTicketSlices * sfft::kP64TkSliceWords * 4, hipDeviceMallocUncached) == hipSuccess) plan->tk_ring = static_cast<unsigned*>(ring);
+    else (void)hipGetLastError();
   }
   *out = plan.get();
   g_plans[{device, n}] = std::move(plan);
@@ -466,6 +482,17 @@ struct DeviceGuard {
   ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 
+// n_fft = 4096 pipelined kernel: does this launch take the dynamic tile order?  (SPECTRE_P64_TICKETS=0: the static map, tuning aid.)
+// Built for fp32 rows without memory_fft; the mailboxes of n_wg / gang gangs and one claim bit per tile have to fit the slice.
+bool p64_tickets(const SpectreMixArgs* a, const Plan* plan, int n_tiles, int n_wg, int gang) {
+  static const bool off = [] { const char* e = tuning_env("SPECTRE_P64_TICKETS"); return e && atoi(e) == 0; }();
+  static const bool burst_off = [] { const char* e2 = tuning_env("SPECTRE_P64_BURST"); return e2 && atoi(e2) == 0; }();
+  static const bool bf16_on = [] { const char* e3 = tuning_env("SPECTRE_P64_TICKETS_BF16"); return e3 && atoi(e3) != 0; }();
+  const bool bf = a->in_dtype == SPECTRE_BF16 || a->out_dtype == SPECTRE_BF16;
+  return plan->tk_ring && !off && !burst_off && !a->mem && (!bf || bf16_on) && n_tiles <= sfft::p64_ticket_capacity() &&
+         n_wg / gang <= (sfft::kP64TkClaim - sfft::kP64TkBox) / 8 && n_wg >= gang;
+}
+
 int launch(const SpectreMixArgs* a, const Plan* plan, const Choice& c, bool conj_gate = false) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(a->stream);
   if (a->B == 0) return SPECTRE_OK;
@@ -500,6 +527,13 @@ int launch(const SpectreMixArgs* a, const Plan* plan, const Choice& c, bool conj
       const int slots = std::max(gang, ncu / gang * gang);
       k.tpw = forced > 0 ? forced : std::max(1, (k.n_tiles + slots - 1) / slots);
       k.n_wg = gang * ((k.n_tiles + gang * k.tpw - 1) / (gang * k.tpw));
+      // round 5: dynamic tile order (one ticket per gang from a chip-wide counter) where the ring exists and the launch fits a slice
+      if (p64_tickets(a, plan, k.n_tiles, k.n_wg, gang)) {
+        unsigned* slice = plan->tk_ring + (size_t)(plan->tk_next.fetch_add(1, std::memory_order_relaxed) % kTicketSlices) * sfft::kP64TkSliceWords;
+        const size_t used = ((size_t)sfft::kP64TkClaim + (size_t)(k.n_tiles + 31) / 32) * 4;
+        if ((e = hipMemsetAsync(slice, 0, used, stream)) != hipSuccess) return fail(SPECTRE_E_HIP, "ticket slice reset: %s", hipGetErrorString(e));
+        k.tickets = slice;
+      }
       e = sfft::launch_regtile64p(k, ib, ob, !burst_off, stream);
     } else if (c.mixedp) {   // one workgroup per CU, pairs of workgroups on adjacent tiles (kernel_regtile_mixedp.h)
       const int ncu = cu_count(a->device);
@@ -632,6 +666,14 @@ int spectre_mix_describe(const SpectreMixArgs* a, char* buf, size_t cap) {
     snprintf(buf, cap, "stockham P=%d solo=%d L=%lld radices=%s bluestein=%d in=%s out=%s (regtile: %s)", c.P, c.solo,
              (long long)(plan->bluestein ? plan->m : a->n_fft), r.c_str(), plan->bluestein ? 1 : 0, in, out,
              c.why_not_regtile[0] ? c.why_not_regtile : "not selected");
+  }
+  if (c.regtile && c.pipelined && !c.wide) {         // the tile order of the persistent 4096 kernel (as launch() decides it)
+    const bool ib = a->in_dtype == SPECTRE_BF16, ob = a->out_dtype == SPECTRE_BF16;
+    const int gang = (ib || ob) ? 4 : 2, ncu = cu_count(a->device), n_tiles = (int)(a->B * ((a->D + 15) / 16));
+    const int slots = std::max(gang, ncu / gang * gang), tpw = std::max(1, (n_tiles + slots - 1) / slots);
+    const int n_wg = gang * ((n_tiles + gang * tpw - 1) / (gang * tpw));
+    const size_t l = strlen(buf);
+    snprintf(buf + l, cap - l, " order=%s", p64_tickets(a, plan, n_tiles, n_wg, gang) ? "tickets" : "static");
   }
   const std::string ov = tuning_overrides();
   if (!ov.empty()) { const size_t l = strlen(buf); snprintf(buf + l, cap - l, " [tuning: %s]", ov.c_str()); }

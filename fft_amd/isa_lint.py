@@ -58,6 +58,8 @@ class Ins:
         self.is_dma = self.is_vmem and text.rstrip().endswith(" lds")
         m = WAIT_VM.match(text)
         self.guard = int(m.group(1)) if (m and inline) else None
+        if self.guard == 0 and re.search(r"lint:\s*drain", comment):
+            self.guard = None                      # an explicit full drain (nothing in flight afterwards) guards no landing slot: always safe
 
 
 def compile_asm(src, flags):

@@ -1,0 +1,15 @@
+#!/bin/bash
+# round 5, GPU call 3: the ticket kernels of the library (robustness cases + timing), the GPU test tier, a bench line
+set -u
+cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
+timeout 600 tools/tickets_lab 5 > gpurun_out/r05_tickets_lab.log 2>&1
+echo "tickets_lab rc $?"; tail -30 gpurun_out/r05_tickets_lab.log
+timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/r05_pytest_gpu_1.log 2>&1
+echo "pytest rc $?"; tail -15 gpurun_out/r05_pytest_gpu_1.log
+timeout 600 python bench.py > gpurun_out/r05_bench_1.json 2> gpurun_out/r05_bench_1.err
+echo "bench rc $?"; python - <<'PY'
+import json
+d=json.loads([l for l in open('gpurun_out/r05_bench_1.json') if l.startswith('{')][-1])
+r=d['roofline']; print('kernel', d['config']['kernel']); print('ms_per_step', d['ms_per_step'], 'kernel_ms', r['kernel_ms'], 'frac', r['frac'], 'cold', d.get('cold_start',{}).get('kernel_ms'))
+print({k:(round(v['kernel_ms'],4), round(v['roofline_frac'],3)) for k,v in d['variants'].items()})
+PY
