@@ -69,6 +69,8 @@ static_assert(kP64LdsTotal <= 160 * 1024, "LDS budget");
 // TICKETS (round 5): the launch's slice of the plan's ticket ring (RegtileArgs::tickets; UNCACHED device memory — the counter is driven
 // by scalar atomics, which carry no scope bits: only memory the L2 does not keep is coherent between XCDs for them), in 32-bit words:
 //   [0]                      the chip-wide ticket counter
+//   [1]                      how many tiles have been claimed so far (a workgroup that runs out of tickets and finds n_tiles here is done
+//                            without looking at the claim bits: 9 us -> 3 us at the end of every launch)
 //   [kP64TkBox + 8 g ...]    mailbox of gang g: 8 slots, (tag << 24) | ticket, tag = sequence % 255 + 1 (never 0 = the reset state)
 //   [kP64TkClaim ...]        one claim bit per TILE (tile index = GANG * ticket + member)
 // and two LDS words behind everything else (the next-but-one tile on its way from wave 0 to the other waves).
@@ -241,7 +243,7 @@ template <int SPLIT> constexpr int p64_younger_first() { return 4 * (8 - SPLIT) 
 //         A ticket whose tile this member did not get (claimed by a sweeper, or beyond the last tile) is a PHANTOM tile: the same
 //         instruction stream over empty buffer ranges, so that the gang stays in step.  Harness, same box, one process: -3.3 % with one
 //         counter per XCD (profiles/r05_p64v_ab_31_pair_tickets.log).
-template <int SPLIT, int PF, bool WITH_MEM = false, bool IN_BF16 = false, bool OUT_BF16 = false, bool BURST = false, bool SPREAD = false, bool TICKETS = false>
+template <int SPLIT, int PF, bool WITH_MEM = false, bool IN_BF16 = false, bool OUT_BF16 = false, bool BURST = false, bool SPREAD = false, int TICKETS = 0>
 __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileArgs a) {
   constexpr int ESI = IN_BF16 ? 2 : 4, ESO = OUT_BF16 ? 2 : 4;   // bytes per input / output element
   constexpr float inv_n = 1.0f / 4096.0f;
@@ -302,6 +304,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
   [[maybe_unused]] int cur_tile = -2, nxt_tile = -2;
   [[maybe_unused]] int tk_seq = 2;                 // sequence number (within the gang's stream) of the ticket being acquired
   [[maybe_unused]] bool tk_follow = true;          // false: the leader stopped publishing in time (or the stream ended): go and sweep
+  [[maybe_unused]] bool tk_grace = false;          // sweep: the grace period behind the end of the stream is over
 
   float2 z[64];
   float4 dfr[PF > 0 ? 4 * PF : 1];                 // deferred results of the previous tile / prefetched rows of the next one
@@ -460,7 +463,9 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
             tl = -1;
             if (ti < (unsigned)a.n_tiles && !(__hip_atomic_fetch_or(tk_claim + (ti >> 5), 1u << (ti & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (1u << (ti & 31)))) tl = (int)ti;
           }
+          if (tl >= 0) __hip_atomic_fetch_add(tk_cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           tk_lds[sq] = tl;
+          if (tl == -2) { tk_lds[1] = -2; break; }       // the stream has ended (or the leader is silent): claim nothing behind it
         }
       }
       __syncthreads();
@@ -469,33 +474,57 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
       tk_follow = nxt_tile != -2;
       if (cur_tile == -2) nxt_tile = -2;
     } else {
+      if constexpr (TICKETS == 2) break;               // (measurement only, tools/tickets_lab.hip: what the look at the claim bits costs at the end of a launch)
       // sweep: the lowest tile whose claim bit is still clear (every thread looks at its share of the bit words; LDS minimum)
       asm volatile("s_waitcnt vmcnt(0) ; lint: drain" ::: "memory");
       __syncthreads();
-      if (tid0 == 0) tk_lds[0] = 0x7fffffff;
+      if (tid0 == 0) { tk_lds[0] = 0x7fffffff; tk_lds[1] = (int)__hip_atomic_load(tk_cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
       __syncthreads();
-      const int n_words = (a.n_tiles + 31) >> 5;
-      const int sw = (int)((long long)wg_lin * n_words / a.n_wg);   // every workgroup starts looking somewhere else (fewer collisions when many sweep)
-      for (int w = tid0; w < n_words; w += 512) {
+      if (__builtin_amdgcn_readfirstlane(tk_lds[1]) >= a.n_tiles) break;      // every tile has an owner (the usual end of a launch)
+      __syncthreads();
+      // Only tiles that are certainly nobody's any more: a ticket stays unclaimed for a moment between the leader's draw and each member's
+      // claim, and a gang has at most three tickets on their way (this tile, the next, the one after), so while the stream is running the
+      // sweep looks below  counter - 3 * gangs.  Once the counter has passed the end, one grace period (~ a tile) later everything counts.
+      if (tid0 == 0) tk_lds[1] = (int)__hip_atomic_load(tk_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // ONE reading for the whole workgroup:
+      __syncthreads();                                                                                           // every wave must take the same way out
+      const unsigned tk_now = (unsigned)__builtin_amdgcn_readfirstlane(tk_lds[1]);
+      __syncthreads();
+      const unsigned n_gangs = (unsigned)(a.n_wg / GANG);
+      const bool tk_all = tk_now >= tk_total && tk_grace;
+      const long long tk_old = tk_all ? (long long)tk_total : (long long)tk_now - 3LL * n_gangs;
+      const int lim = (int)(tk_old <= 0 ? 0 : tk_old * GANG > a.n_tiles ? a.n_tiles : tk_old * GANG);      // tiles below this are fair game
+      const int n_words = (lim + 31) >> 5, all_words = (a.n_tiles + 31) >> 5;
+      const int sw = n_words ? (int)((long long)wg_lin * n_words / a.n_wg) : 0;   // every workgroup starts looking somewhere else (fewer collisions when many sweep)
+      if (tid0 == 0) tk_lds[1] = 0;
+      __syncthreads();
+      for (int w = tid0; w < all_words; w += 512) {
         unsigned fr = ~__hip_atomic_load(tk_claim + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (32 * w + 32 > a.n_tiles) fr &= (1u << (a.n_tiles - 32 * w)) - 1u;
+        if (fr) tk_lds[1] = 1;                       // something is unclaimed somewhere (the usual end of a launch: nothing is)
+        if (32 * w + 32 > lim) fr &= 32 * w >= lim ? 0u : (1u << (lim - 32 * w)) - 1u;
         if (fr) atomicMin(const_cast<int*>(tk_lds), 32 * (w >= sw ? w - sw : w - sw + n_words) + (int)__builtin_ctz(fr));
       }
       __syncthreads();
-      const int key = __builtin_amdgcn_readfirstlane(tk_lds[0]);
+      const int key = __builtin_amdgcn_readfirstlane(tk_lds[0]), any_free = __builtin_amdgcn_readfirstlane(tk_lds[1]);
       __syncthreads();
-      if (key == 0x7fffffff) break;                  // every tile has an owner: done
+      if (key == 0x7fffffff) {
+        if (tk_all || !any_free) break;              // every tile has an owner: done
+        for (int i = 0; i < 8; ++i) __builtin_amdgcn_s_sleep(127);       // ~ 25 us: let the members that are on their way claim what is theirs
+        if (tk_now >= tk_total) tk_grace = true;
+        continue;
+      }
       const int cand = 32 * (((key >> 5) + sw) % n_words) + (key & 31);
       if (tid0 == 0) tk_lds[1] = (__hip_atomic_fetch_or(tk_claim + (cand >> 5), 1u << (cand & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (cand & 31)) & 1u;
       __syncthreads();
       const int lost = __builtin_amdgcn_readfirstlane(tk_lds[1]);
       __syncthreads();
       if (lost) continue;                            // somebody else took it in the meantime: look again
+      if (tid0 == 0) __hip_atomic_fetch_add(tk_cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       cur_tile = cand; nxt_tile = -2;
     }
     if (cur_tile == -2) continue;                    // (round 0 without a single ticket: straight to the sweep)
   }
-  [[maybe_unused]] bool prev_live = false;         // TICKETS: the previous tile of this round was a real one (its deferred results are stored)
+  [[maybe_unused]] bool prev_live = false;         // TICKETS: dfr holds the deferred results of a real previous tile (they are stored in F1)
   // ---- prologue: request tile 0 the same way every later tile is requested --------------------------------------------
   {
     const char* vb; char* ob; const float2* gp;
@@ -533,6 +562,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
     };
     [[maybe_unused]] auto tk_claim_result = [&]() {                 // (behind a wait for lgkmcnt(0)) -> the LDS word the other waves read
       if (tk_tile >= 0) { asm volatile("" : "+s"(tk_b)); if (tk_b & tk_bit) tk_tile = -1; }
+      if (tk_tile >= 0) { const unsigned one = 1u; unsigned* cp = tk_cnt + 1; asm volatile("s_atomic_add %0, %1, 0x0" :: "s"(one), "s"(cp) : "memory"); }   // (no return value)
       if (lane == 0) tk_lds[0] = tk_tile;
     };
     if constexpr (TICKETS) { if (tk_lead) asm volatile("s_atomic_add %0, %1, 0x0 glc" : "+s"(tk_a) : "s"(tk_cnt) : "memory"); }   // H0
@@ -844,7 +874,8 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
     obp = ob;
     gate_fetch(gpn);     // committed to LDS at the end of the next tile's F1 (after the last tile: a harmless re-read of this tile's bins)
     if constexpr (TICKETS) {
-      prev_live = cur_live; cur_tile = nxt_tile; nxt_tile = fut_tile; ++tk_seq;
+      prev_live = cur_live && more;                  // (only then did this tile's deferred results go into dfr; without a next tile they were stored above)
+      cur_tile = nxt_tile; nxt_tile = fut_tile; ++tk_seq;
       if (fut_tile == -2) tk_follow = false;         // the stream has ended (or the leader fell silent): no more requests
     }
   }  // tile loop

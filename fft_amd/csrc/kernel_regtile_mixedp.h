@@ -13,6 +13,7 @@
 // next / previous tile), the gate bins requested raw and fixed up at commit time, the twiddle bases requested BEFORE the deferred block.
 #pragma once
 #include "kernel_regtile_mixed.h"
+#include "kernel_tickets.h"
 
 namespace sfft {
 
@@ -78,8 +79,14 @@ template <int RF, int RS, int S> constexpr int mixedp_lds_total() { return S == 
 // block of a pair — and at 60 x 60 the 480 threads of the team would leave wave 7, which owns row classes 56-59, with half its lanes.
 // The threads beyond the team (u >= RF and u >= RS) own neither rows nor bins and only take part in the barriers and the requests.
 template <int RF, int RS> constexpr int mixedp_launch_threads() { return (mixed_threads<RF, RS>() + 63) & ~63; }
-template <int RF, int RS, int P, bool FIRST = false, int S = 0, int XP = 0>
+// TICKETS (round 5): the pairs take adjacent tile pairs from one chip-wide counter in address order instead of walking through their own
+// regions (kernel_tickets.h; the long story is in kernel_regtile64p.h): two LDS words behind everything else carry the tile after next.
+template <int RF, int RS, int S> constexpr int mixedp_tk_off() { return (mixedp_lds_total<RF, RS, S>() + 15) & ~15; }
+template <int RF, int RS, int S, bool TICKETS> constexpr int mixedp_lds_bytes() { return TICKETS ? mixedp_tk_off<RF, RS, S>() + 16 : mixedp_lds_total<RF, RS, S>(); }
+template <int RF, int RS, int P, bool FIRST = false, int S = 0, int XP = 0, bool TICKETS = false>
 __global__ void __launch_bounds__((mixedp_launch_threads<RF, RS>()), 1) spectre_mix_regtile_mixedp(const RegtileArgs a) {
+  static_assert(!TICKETS || ((XP & 8) != 0 && S > 0), "TICKETS: built on the form with the deferred loads in the gaps of E1 / E2");
+  static_assert(mixedp_lds_bytes<RF, RS, S, TICKETS>() <= 160 * 1024, "LDS budget");
   constexpr int D0 = FIRST ? 0 : RF - P;           // the deferred row blocks are [D0, D0 + P) of the order F1 uses them (the last ones: measured
                                                    // 1 % better than the first ones, 1.586 vs 1.605 ms)
   static_assert(S % 2 == 0 && S >= 0 && (S == 0 || (!FIRST && S <= D0)), "staged row blocks: the first S of F1's order, in pairs; the deferred ones are the last P");
@@ -111,7 +118,10 @@ __global__ void __launch_bounds__((mixedp_launch_threads<RF, RS>()), 1) spectre_
 
   const int wg_lin = xcd_contiguous(blockIdx.x, a.n_wg);
   const int pair_base = (wg_lin >> 1) * a.tpw * 2 + (wg_lin & 1);   // workgroups 2m, 2m+1 walk through adjacent tiles
-  if (pair_base >= a.n_tiles) return;
+  if constexpr (!TICKETS) { if (pair_base >= a.n_tiles) return; }
+  [[maybe_unused]] GangTickets<2> tk;
+  [[maybe_unused]] int cur_tile = -2, nxt_tile = -2;
+  if constexpr (TICKETS) tk.init(a.tickets, wg_lin >> 1, wg_lin & 1, a.n_tiles, reinterpret_cast<volatile int*>(smem + mixedp_tk_off<RF, RS, S>()), tid0);
 
   float2 z[NZ];
   float2 dfr[P > 0 ? P : 1];                        // deferred results of the previous tile / prefetched row blocks of the next one
@@ -219,11 +229,23 @@ __global__ void __launch_bounds__((mixedp_launch_threads<RF, RS>()), 1) spectre_
     static_for<1, RBF>([&](auto jc) { constexpr int j = decltype(jc)::value; wb[j] = a.tw[uu * RAF * j]; });
   };
 
+  // TICKETS: round 0 follows the pair's tickets; every later round processes ONE tile nobody has claimed (the sweep).  Static map: one round.
+  for (int round = 0;; ++round) {
+  if constexpr (TICKETS) {
+    if (round == 0) tk.first_two(tid0, cur_tile, nxt_tile);
+    else {
+      asm volatile("s_waitcnt vmcnt(0) ; lint: drain" ::: "memory");
+      if (!tk.sweep(tid0, mixedp_launch_threads<RF, RS>(), wg_lin, a.n_wg, cur_tile)) break;
+      nxt_tile = -2;
+    }
+    if (cur_tile == -2) continue;
+  }
+  [[maybe_unused]] bool prev_live = false;          // TICKETS: dfr holds the deferred results of a real previous tile
   // ---- prologue: the whole first tile is loaded the way the non-deferred row blocks of every later tile are --------------------
   {
     const char* vb; char* ob; const float2* gp;
-    tile_ptrs(pair_base, vb, ob, gp);
-    const __amdgpu_buffer_rsrc_t rs = rsrc(vb, a.v_sn, a.rows_in);
+    tile_ptrs(TICKETS ? (cur_tile >= 0 ? cur_tile : 0) : pair_base, vb, ob, gp);
+    const __amdgpu_buffer_rsrc_t rs = rsrc(vb, a.v_sn, (!TICKETS || cur_tile >= 0) ? a.rows_in : 0);
     const uint32_t voff = rows ? (uint32_t)(((long long)u * a.v_sn + 2 * p) * 4) : 0x80000000u;
     if constexpr (S > 0) stage_coords(a.v_sn);
     static_for<0, S / 2>([&](auto jc) { stage_pair(rs, a.v_sn, jc); });
@@ -232,22 +254,25 @@ __global__ void __launch_bounds__((mixedp_launch_threads<RF, RS>()), 1) spectre_
     gate_fetch(gp);
   }
 
-  for (int it = 0; it < a.tpw; ++it) {
-    const int tile = pair_base + 2 * it;
-    if (tile >= a.n_tiles) break;                    // workgroup-uniform
-    const bool more = (it + 1 < a.tpw) && (tile + 2 < a.n_tiles);
+  for (int it = 0; TICKETS || it < a.tpw; ++it) {
+    const int tile = TICKETS ? (cur_tile >= 0 ? cur_tile : 0) : pair_base + 2 * it;
+    if (TICKETS ? cur_tile == -2 : tile >= a.n_tiles) break;                    // workgroup-uniform
+    const bool more = TICKETS ? nxt_tile >= 0 : (it + 1 < a.tpw) && (tile + 2 < a.n_tiles);
+    [[maybe_unused]] const bool cur_live = TICKETS ? cur_tile >= 0 : true;       // false: a phantom tile (empty buffer ranges)
     coords();
+    [[maybe_unused]] const bool tk_lead = TICKETS && round == 0 && tk.leading(), tk_foll = TICKETS && round == 0 && tk.following();
+    if constexpr (TICKETS) { tk.begin_tile(); if (tk_lead) tk.draw(); }
     long long v_sn = a.v_sn, out_sn = a.out_sn;
     asm volatile("" : "+s"(v_sn), "+s"(out_sn));
     const char* vb; char* ob; const float2* gp;
     tile_ptrs(tile, vb, ob, gp);
     const char* vbn = vb; char* obn = ob; const float2* gpn = gp;
-    if (more) tile_ptrs(tile + 2, vbn, obn, gpn);
+    if (more) tile_ptrs(TICKETS ? nxt_tile : tile + 2, vbn, obn, gpn);
     // (obp is carried across the back edge in VGPRs, so hipcc wraps each of the P deferred stores in a waterfall loop — v_readfirstlane,
     //  v_cmp, s_and_saveexec.  Recomputing the pointer from tile - 2 removes the loops and is SLOWER, 1.6 % at 60 x 50 and 7 % at 64 x 40
     //  (profiles/r03_mixedp_opt_matrix.log, OPT=8 against OPT=0): the loops pace the stores of the quiet part.  Left as hipcc emits it.)
-    const __amdgpu_buffer_rsrc_t rs_next = rsrc(vbn, v_sn, more ? a.rows_in : 0), rs_out = rsrc(ob, out_sn, a.rows_out),
-                                 rs_prev = rsrc(obp, out_sn, it > 0 ? a.rows_out : 0);
+    const __amdgpu_buffer_rsrc_t rs_next = rsrc(vbn, v_sn, more ? a.rows_in : 0), rs_out = rsrc(ob, out_sn, cur_live ? a.rows_out : 0),
+                                 rs_prev = rsrc(obp, out_sn, (TICKETS ? prev_live : it > 0) ? a.rows_out : 0);
     const uint32_t voff = rows ? (uint32_t)(((long long)u * v_sn + 2 * p) * 4) : 0x80000000u;
     const uint32_t ooff = rows ? (uint32_t)(((long long)u * out_sn + 2 * p) * 4) : 0x80000000u;
 
@@ -300,9 +325,11 @@ __global__ void __launch_bounds__((mixedp_launch_threads<RF, RS>()), 1) spectre_
     const MixedM0 m0 = mixed_m0(img, tid);
     auto wr = [&](auto offc, float v) { mixed_write_addtid<decltype(offc)::value * 4>(v, m0); };
     rt_lds_barrier();
+    if constexpr (TICKETS) { if (tk_lead) tk.publish(); }      // (the barrier waited for lgkmcnt(0): the ticket is here)
     gap_loads(std::integral_constant<int, 0>{});
     if (rows) static_for<0, RF>([&](auto kc) { constexpr int k1 = decltype(kc)::value; wr(std::integral_constant<int, k1 * ROW1>{}, z[out_pos<RF>(k1)].x); });
     rt_lds_barrier();
+    if constexpr (TICKETS) { if (tk_lead) tk.result(tid0 & 63); }
     gap_loads(std::integral_constant<int, 1>{});
     if (bins) static_for<0, RS>([&](auto nc) { constexpr int n2 = decltype(nc)::value; z[n2].x = mp_lds_read<n2 * kPC * 4>(r1); });
     rt_lds_barrier();
@@ -315,6 +342,7 @@ __global__ void __launch_bounds__((mixedp_launch_threads<RF, RS>()), 1) spectre_
     rt_lds_barrier();
     mp_pin<0, RS, true>(z);
     gap_loads(std::integral_constant<int, 4>{});
+    if constexpr (TICKETS) { if (tk_foll) tk.ask(); }
 
     // ---- bins k = u + RF*k2: F2 over n2, gate, I1 over k2 ------------------------------------------------------------------
     using BinMap = OutPosMap<RS>;
@@ -342,10 +370,12 @@ __global__ void __launch_bounds__((mixedp_launch_threads<RF, RS>()), 1) spectre_
 
     // ---- E2 ---------------------------------------------------------------------------------------------------------------
     if (bins) static_for<0, RS>([&](auto nc) { constexpr int n2 = decltype(nc)::value; wr(std::integral_constant<int, n2 * ROW2>{}, z[BinMap::at(out_pos<RS>(n2))].x); });
+    if constexpr (TICKETS) { if (tk_foll) tk.check(); }
     rt_lds_barrier();
     gap_loads(std::integral_constant<int, 5>{});
     if (rows) static_for<0, RF>([&](auto kc) { constexpr int k1 = decltype(kc)::value; z[k1].x = mp_lds_read<k1 * kPC * 4>(r2); });
     rt_lds_barrier();
+    if constexpr (TICKETS) { if (tk_foll) tk.result(tid0 & 63); }
     mp_pin<0, RF, false>(z);
     gap_loads(std::integral_constant<int, 6>{});
     if (bins) static_for<0, RS>([&](auto nc) { constexpr int n2 = decltype(nc)::value; wr(std::integral_constant<int, n2 * ROW2>{}, z[BinMap::at(out_pos<RS>(n2))].y); });
@@ -357,6 +387,8 @@ __global__ void __launch_bounds__((mixedp_launch_threads<RF, RS>()), 1) spectre_
     gap_loads(std::integral_constant<int, 8>{});
 
     // ---- conj twiddle, I2 over k1, store rows u + RS*n1 (spectre.py:553), reload / trade places -------------------------------
+    [[maybe_unused]] int fut_tile = -2;
+    if constexpr (TICKETS) { if (round == 0) fut_tile = tk.handed_over(); }
     load_twiddle_bases(wa, wb);
     if constexpr (S > 0) {
       // every wave is behind E2's last read: the image is idle, the next tile's first S row blocks may land in it.  The twiddle bases come
@@ -406,7 +438,14 @@ __global__ void __launch_bounds__((mixedp_launch_threads<RF, RS>()), 1) spectre_
     });
     obp = ob;
     gate_fetch(gpn);                                 // (after the last tile: a harmless re-read of this tile's bins)
+    if constexpr (TICKETS) {
+      prev_live = cur_live && more;                   // (only then did this tile's deferred results go into dfr)
+      cur_tile = nxt_tile; nxt_tile = fut_tile;
+      if (round == 0) tk.advance(fut_tile);
+    }
   }
+  if constexpr (!TICKETS) break;
+  }  // rounds
 }
 
 template <int RF, int RS>

@@ -12,16 +12,21 @@ namespace sfft {
 #define SFFT_DEFINE_MIXEDP_LAUNCHER(RF_, RS_, P_, S_, XP_)                                                                      \
   template <>                                                                                                          \
   hipError_t launch_regtile_mixedp<RF_, RS_>(const RegtileArgs& a, hipStream_t stream) {                                \
-    auto kern = spectre_mix_regtile_mixedp<RF_, RS_, P_, false, S_, XP_>;                                               \
-    static std::atomic<bool> lds_opt_in[16];                                                                            \
-    const size_t lds = mixedp_lds_total<RF_, RS_, S_>();                                                                \
+    void (*kern)(const RegtileArgs) = spectre_mix_regtile_mixedp<RF_, RS_, P_, false, S_, XP_>;                         \
+    static std::atomic<bool> lds_opt_in[16][2];                                                                         \
+    size_t lds = mixedp_lds_total<RF_, RS_, S_>();                                                                      \
+    bool tickets = false;                                                                                               \
+    if constexpr (((XP_) & 8) != 0 && (S_) > 0) {      /* round 5: dynamic tile order (kernel_tickets.h) where spectre_hip.hip hands over a ticket slice */ \
+      if (a.tickets) { kern = spectre_mix_regtile_mixedp<RF_, RS_, P_, false, S_, XP_, true>; lds = mixedp_lds_bytes<RF_, RS_, S_, true>(); tickets = true; } \
+    }                                                                                                                   \
+    if (a.tickets && !tickets) return hipErrorInvalidValue;   /* (the host only offers tickets to the lengths built with them) */ \
     int dev = 0;                                                                                                        \
     (void)hipGetDevice(&dev);                                                                                           \
-    if (dev < 0 || dev >= 16 || !lds_opt_in[dev]) {                                                                     \
+    if (dev < 0 || dev >= 16 || !lds_opt_in[dev][tickets]) {                                                            \
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
       if (e != hipSuccess) return e;                                                                                    \
       if ((e = mixed_check_lds_layout(reinterpret_cast<const void*>(kern))) != hipSuccess) return e;                    \
-      if (dev >= 0 && dev < 16) lds_opt_in[dev] = true;                                                                 \
+      if (dev >= 0 && dev < 16) lds_opt_in[dev][tickets] = true;                                                        \
     }                                                                                                                   \
     hipLaunchKernelGGL(kern, dim3(a.n_wg), dim3(mixedp_launch_threads<RF_, RS_>()), lds, stream, a);                            \
     return hipGetLastError();                                                                                           \

@@ -20,6 +20,7 @@
 #include "../../include/spectre_hip.h"
 #include "kernel_regtile_grad.h"
 #include "kernel_regtile64p.h"   // (the ticket-slice layout constants)
+#include "kernel_tickets.h"
 #include "kernel_regtile_wide.h"
 #include "kernel_regtile_mixed_grad.h"
 #include "kernel_stockham.h"
@@ -154,7 +155,7 @@ const char* tuning_env(const char* name) {
 }
 std::string tuning_overrides() {
   std::string r;
-  for (const char* n : {"SPECTRE_P64", "SPECTRE_P64_BF16", "SPECTRE_P64_BURST", "SPECTRE_P64_TICKETS", "SPECTRE_P64_TICKETS_BF16", "SPECTRE_WIDE", "SPECTRE_WIDE_MAX", "SPECTRE_WIDE_NT", "SPECTRE_MIXEDP", "SPECTRE_STOCKHAM_PMAX", "SPECTRE_TPW", "SPECTRE_P64_TPW", "SPECTRE_GATE_GRAD"})
+  for (const char* n : {"SPECTRE_P64", "SPECTRE_P64_BF16", "SPECTRE_P64_BURST", "SPECTRE_P64_TICKETS", "SPECTRE_P64_TICKETS_BF16", "SPECTRE_MIXEDP_TICKETS", "SPECTRE_WIDE", "SPECTRE_WIDE_MAX", "SPECTRE_WIDE_NT", "SPECTRE_MIXEDP", "SPECTRE_STOCKHAM_PMAX", "SPECTRE_TPW", "SPECTRE_P64_TPW", "SPECTRE_GATE_GRAD"})
     if (const char* e = tuning_env(n)) r += std::string(r.empty() ? "" : " ") + n + "=" + e;
   return r;
 }
@@ -298,7 +299,7 @@ int build_plan(int device, int64_t n, Plan** out) {
     if ((e = upload(w, &plan->chirp)) != hipSuccess || (e = upload(bh, &plan->bhat)) != hipSuccess)
       return fail(SPECTRE_E_HIP, "plan(bluestein tables): %s", hipGetErrorString(e));
   }
-  if (n == 4096) {                                   // ticket ring (optional: without it the kernels keep the static tile map)
+  if (n == 4096 || n == 3000 || n == 3600 || n == 3840) {   // ticket ring (optional: without it the kernels keep the static tile map)
     void* ring = nullptr;
     if (hipExtMallocWithFlags(&ring, (size_t)kTicketSlices * sfft::kP64TkSliceWords * 4, hipDeviceMallocUncached) == hipSuccess) plan->tk_ring = static_cast<unsigned*>(ring);
     else (void)hipGetLastError();
@@ -487,10 +488,21 @@ struct DeviceGuard {
 bool p64_tickets(const SpectreMixArgs* a, const Plan* plan, int n_tiles, int n_wg, int gang) {
   static const bool off = [] { const char* e = tuning_env("SPECTRE_P64_TICKETS"); return e && atoi(e) == 0; }();
   static const bool burst_off = [] { const char* e2 = tuning_env("SPECTRE_P64_BURST"); return e2 && atoi(e2) == 0; }();
+  // bf16 rows in / fp32 rows out: -0.2 ... -3.5 % on five boxes, on; bf16 rows out: +-0.5 %, static unless SPECTRE_P64_TICKETS_BF16=1
   static const bool bf16_on = [] { const char* e3 = tuning_env("SPECTRE_P64_TICKETS_BF16"); return e3 && atoi(e3) != 0; }();
-  const bool bf = a->in_dtype == SPECTRE_BF16 || a->out_dtype == SPECTRE_BF16;
+  const bool bf = a->out_dtype == SPECTRE_BF16;
   return plan->tk_ring && !off && !burst_off && !a->mem && (!bf || bf16_on) && n_tiles <= sfft::p64_ticket_capacity() &&
          n_wg / gang <= (sfft::kP64TkClaim - sfft::kP64TkBox) / 8 && n_wg >= gang;
+}
+
+// the persistent mixed-radix kernels built with tickets (regtile_mixedp.hip: the lengths whose deferred loads sit in the exchange gaps)
+bool mixedp_tickets(const SpectreMixArgs* a, const Plan* plan, int n_tiles, int n_wg) {
+  // Built and tested (tools/tickets_lab.hip), but OFF unless SPECTRE_TUNING=1 SPECTRE_MIXEDP_TICKETS=1: at (256, 3000, 768) the dynamic order is
+  // worth -4.5 % on a box whose allocations are of the slow class and costs +1.4 ... +3.9 % on two whose are fast
+  // (profiles/r05_tickets_lab_box*.log) — no expected gain, so the static map stays.
+  static const bool on = [] { const char* e = tuning_env("SPECTRE_MIXEDP_TICKETS"); return e && atoi(e) != 0; }();
+  const int64_t n = a->n_fft;
+  return plan->tk_ring && on && (n == 3000 || n == 3600 || n == 3840) && n_tiles <= sfft::tk_capacity() && n_wg / 2 <= sfft::tk_max_gangs() && n_wg >= 2;
 }
 
 int launch(const SpectreMixArgs* a, const Plan* plan, const Choice& c, bool conj_gate = false) {
@@ -541,6 +553,12 @@ int launch(const SpectreMixArgs* a, const Plan* plan, const Choice& c, bool conj
       k.tpw = std::max(1, (k.n_tiles + slots - 1) / slots);
       k.n_wg = 2 * ((k.n_tiles + 2 * k.tpw - 1) / (2 * k.tpw));
       const int64_t n = a->n_fft;
+      if (mixedp_tickets(a, plan, k.n_tiles, k.n_wg)) {      // round 5: dynamic tile order, as at 4096
+        unsigned* slice = plan->tk_ring + (size_t)(plan->tk_next.fetch_add(1, std::memory_order_relaxed) % kTicketSlices) * sfft::kTkSliceWords;
+        const size_t used = ((size_t)sfft::kTkClaim + (size_t)(k.n_tiles + 31) / 32) * 4;
+        if ((e = hipMemsetAsync(slice, 0, used, stream)) != hipSuccess) return fail(SPECTRE_E_HIP, "ticket slice reset: %s", hipGetErrorString(e));
+        k.tickets = slice;
+      }
       e = n == 3000 ? sfft::launch_regtile_mixedp<60, 50>(k, stream) : n == 2560 ? sfft::launch_regtile_mixedp<64, 40>(k, stream)
         : n == 2400 ? sfft::launch_regtile_mixedp<60, 40>(k, stream) : n == 3072 ? sfft::launch_regtile_mixedp<64, 48>(k, stream)
         : n == 3600 ? sfft::launch_regtile_mixedp<60, 60>(k, stream) : sfft::launch_regtile_mixedp<64, 60>(k, stream);
@@ -674,6 +692,12 @@ int spectre_mix_describe(const SpectreMixArgs* a, char* buf, size_t cap) {
     const int n_wg = gang * ((n_tiles + gang * tpw - 1) / (gang * tpw));
     const size_t l = strlen(buf);
     snprintf(buf + l, cap - l, " order=%s", p64_tickets(a, plan, n_tiles, n_wg, gang) ? "tickets" : "static");
+  }
+  if (c.regtile && c.mixedp) {
+    const int ncu = cu_count(a->device), n_tiles = (int)(a->B * ((a->D + 15) / 16));
+    const int slots = std::max(2, ncu / 2 * 2), tpw = std::max(1, (n_tiles + slots - 1) / slots), n_wg = 2 * ((n_tiles + 2 * tpw - 1) / (2 * tpw));
+    const size_t l = strlen(buf);
+    snprintf(buf + l, cap - l, " order=%s", mixedp_tickets(a, plan, n_tiles, n_wg) ? "tickets" : "static");
   }
   const std::string ov = tuning_overrides();
   if (!ov.empty()) { const size_t l = strlen(buf); snprintf(buf + l, cap - l, " [tuning: %s]", ov.c_str()); }
