@@ -56,7 +56,7 @@ def hipcc() -> str:
 #   * the units below additionally: hand-counted `s_waitcnt vmcnt(N)` in front of the LDS-DMA landing slots / inline-asm ds_read_b32
 #     consumed behind `s_waitcnt lgkmcnt(0)`.
 LINTED = {"regtile_n4096p.hip": {"vmcnt_kernel": "regtile64p"},
-          "regtile_mixedp.hip": {"lds_kernel": "mixedp"}}
+          "regtile_mixedp.hip": {"lds_kernel": "mixedp", "vmcnt_kernel": "mixedp"}}
 
 
 def _newest(paths):

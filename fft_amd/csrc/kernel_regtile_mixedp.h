@@ -279,9 +279,17 @@ __global__ void __launch_bounds__((mixedp_launch_threads<RF, RS>()), 1) spectre_
     // ---- rows u + RS*q, q < RF: F1 over q, W_N^(u k1) ---------------------------------------------------------------------
     float2 wa[RAF], wb[RBF];
     if constexpr (S == 0) load_twiddle_bases(wa, wb);
-    // the staged row blocks: requested before the previous tile's stores; hipcc puts the s_waitcnt vmcnt(N) in front of these reads itself
-    // (N = the requests that are certainly younger than the last LDS-DMA: that tile's stores, its reloads, the gate fetch, the twiddle bases)
+    // the staged row blocks: requested before the previous tile's stores.  hipcc puts an s_waitcnt vmcnt(N) in front of these reads itself
+    // (N = the requests that are certainly younger than the last LDS-DMA: that tile's stores, its reloads, the gate fetch); the same wait is
+    // ALSO written out by hand, tagged for fft_amd/isa_lint.py, so that a compiler whose LDS-DMA alias tracking changes cannot turn the
+    // read-back into a silent race: completion is in order, so with N requests issued behind the last LDS-DMA on every path
+    // (the fewest: a tile with a successor — RF - P stores, RF - S - P reloads, GS gate loads; first tile: RF - S loads, GS gate loads),
+    // vmcnt(N) means the staged row blocks have landed.
     if constexpr (S > 0) {
+      if (it == 0) asm volatile("s_waitcnt vmcnt(%0) ; lint: first" :: "n"(RF - S + GS) : "memory");
+      else if constexpr ((RF - P) + (RF - S - P) + GS <= 63) asm volatile("s_waitcnt vmcnt(%0) ; lint: steady" :: "n"((RF - P) + (RF - S - P) + GS) : "memory");
+      // (more than 63 requests behind the LDS-DMA — 64 x 40, 60 x 40 —: the counter has 6 bits and a wave cannot have more than 63 requests
+      //  outstanding, so by the time the 64th has been issued the LDS-DMA in front of them has completed; nothing to wait for)
       const char* rb = staged_base();
       static_for<0, S>([&](auto ic) { z[decltype(row_q(ic))::value] = staged_read(rb, ic); });
     }

@@ -155,7 +155,7 @@ const char* tuning_env(const char* name) {
 }
 std::string tuning_overrides() {
   std::string r;
-  for (const char* n : {"SPECTRE_P64", "SPECTRE_P64_BF16", "SPECTRE_P64_BURST", "SPECTRE_P64_TICKETS", "SPECTRE_P64_TICKETS_BF16", "SPECTRE_MIXEDP_TICKETS", "SPECTRE_WIDE", "SPECTRE_WIDE_MAX", "SPECTRE_WIDE_NT", "SPECTRE_MIXEDP", "SPECTRE_STOCKHAM_PMAX", "SPECTRE_TPW", "SPECTRE_P64_TPW", "SPECTRE_GATE_GRAD"})
+  for (const char* n : {"SPECTRE_P64", "SPECTRE_P64_BF16", "SPECTRE_P64_BURST", "SPECTRE_P64_TICKETS", "SPECTRE_MIXEDP_TICKETS", "SPECTRE_TILE_ORDER", "SPECTRE_WIDE", "SPECTRE_WIDE_MAX", "SPECTRE_WIDE_NT", "SPECTRE_MIXEDP", "SPECTRE_STOCKHAM_PMAX", "SPECTRE_TPW", "SPECTRE_P64_TPW", "SPECTRE_GATE_GRAD"})
     if (const char* e = tuning_env(n)) r += std::string(r.empty() ? "" : " ") + n + "=" + e;
   return r;
 }
@@ -194,6 +194,24 @@ struct Plan {
   // kTicketSlices of them).  nullptr (allocation refused): the static tile map.
   unsigned* tk_ring = nullptr;
   mutable std::atomic<unsigned> tk_next{0};
+  // ... and WHICH order a launch takes is measured, per (V, out) pair: the static map wins by 2-6 % where the driver has placed the two tensors
+  // in memory of the fast class and loses by 3-5 % elsewhere (allocation classes) — nothing a library can see from a
+  // pointer.  So the first twelve launches on a pair take the two orders in the pattern T S S T (a clock that is still ramping up cancels out)
+  // with a HIP event pair around each (recorded on the caller's stream, looked at later with hipEventQuery: nothing ever waits), and once both
+  // orders have four samples behind two warm-up launches each, the faster one stays.  Same bits either way.  Not under stream capture (no events
+  // there: the current choice, or tickets).
+  struct OrderPending { hipEvent_t e0, e1; int mode; };
+  struct OrderEntry {
+    uint64_t key[6] = {0, 0, 0, 0, 0, 0};
+    int decided = -1;                              // -1 exploring, 0 static, 1 tickets
+    int issued[2] = {0, 0}, samples[2] = {0, 0};
+    float sum[2] = {0.f, 0.f};                     // of the samples behind the two warm-up launches of each order
+    std::vector<OrderPending> pending;
+    uint64_t last_use = 0;
+  };
+  mutable std::mutex order_mu;
+  mutable std::vector<OrderEntry> orders;
+  mutable uint64_t order_clock = 0;
 
   ~Plan() {
     // best effort: the owning device must be current for hipFree
@@ -205,6 +223,7 @@ struct Plan {
       if (chirp) (void)hipFree(chirp);
       if (bhat) (void)hipFree(bhat);
       if (tk_ring) (void)hipFree(tk_ring);
+      for (auto& en : orders) for (auto& pd : en.pending) { (void)hipEventDestroy(pd.e0); (void)hipEventDestroy(pd.e1); }
       (void)hipSetDevice(cur);
     }
   }
@@ -488,21 +507,105 @@ struct DeviceGuard {
 bool p64_tickets(const SpectreMixArgs* a, const Plan* plan, int n_tiles, int n_wg, int gang) {
   static const bool off = [] { const char* e = tuning_env("SPECTRE_P64_TICKETS"); return e && atoi(e) == 0; }();
   static const bool burst_off = [] { const char* e2 = tuning_env("SPECTRE_P64_BURST"); return e2 && atoi(e2) == 0; }();
-  // bf16 rows in / fp32 rows out: -0.2 ... -3.5 % on five boxes, on; bf16 rows out: +-0.5 %, static unless SPECTRE_P64_TICKETS_BF16=1
-  static const bool bf16_on = [] { const char* e3 = tuning_env("SPECTRE_P64_TICKETS_BF16"); return e3 && atoi(e3) != 0; }();
-  const bool bf = a->out_dtype == SPECTRE_BF16;
-  return plan->tk_ring && !off && !burst_off && !a->mem && (!bf || bf16_on) && n_tiles <= sfft::p64_ticket_capacity() &&
+  // (whether an eligible launch then TAKES the ticket order is measured per tensor pair: choose_tile_order.  fp32 rows -3 ... -5 % on slow-class
+  //  pairs, +2 ... +6 % on fast ones; bf16 rows in / fp32 out -0.2 ... -3.5 %; bf16 rows out +-0.8 %)
+  return plan->tk_ring && !off && !burst_off && !a->mem && n_tiles <= sfft::p64_ticket_capacity() &&
          n_wg / gang <= (sfft::kP64TkClaim - sfft::kP64TkBox) / 8 && n_wg >= gang;
 }
 
 // the persistent mixed-radix kernels built with tickets (regtile_mixedp.hip: the lengths whose deferred loads sit in the exchange gaps)
 bool mixedp_tickets(const SpectreMixArgs* a, const Plan* plan, int n_tiles, int n_wg) {
-  // Built and tested (tools/tickets_lab.hip), but OFF unless SPECTRE_TUNING=1 SPECTRE_MIXEDP_TICKETS=1: at (256, 3000, 768) the dynamic order is
-  // worth -4.5 % on a box whose allocations are of the slow class and costs +1.4 ... +3.9 % on two whose are fast
-  // (profiles/r05_tickets_lab_box*.log) — no expected gain, so the static map stays.
-  static const bool on = [] { const char* e = tuning_env("SPECTRE_MIXEDP_TICKETS"); return e && atoi(e) != 0; }();
+  // At (256, 3000, 768) the dynamic order is worth -4.5 % on one box and costs +1.4 ... +3.9 % on four others (profiles/r05_tickets_lab_box*.log):
+  // eligible, and taken where it measures faster (choose_tile_order).  SPECTRE_MIXEDP_TICKETS=0: never.
+  static const bool off = [] { const char* e = tuning_env("SPECTRE_MIXEDP_TICKETS"); return e && atoi(e) == 0; }();
   const int64_t n = a->n_fft;
-  return plan->tk_ring && on && (n == 3000 || n == 3600 || n == 3840) && n_tiles <= sfft::tk_capacity() && n_wg / 2 <= sfft::tk_max_gangs() && n_wg >= 2;
+  return plan->tk_ring && !off && (n == 3000 || n == 3600 || n == 3840) && n_tiles <= sfft::tk_capacity() && n_wg / 2 <= sfft::tk_max_gangs() && n_wg >= 2;
+}
+
+// The reset of a ticket slice: OUR OWN kernel, not hipMemsetAsync.  Captured into a hipGraph, the runtime's memset node did not reliably
+// clear the (uncached) slice on the second and later replays — the ticket kernel then found a spent counter and processed nothing
+// (tools/graph_dbg.py) — while a kernel node is replayed like any other launch.  Same cost (a 10-KB store), same stream ordering.
+__global__ void __launch_bounds__(256) spectre_ticket_reset(unsigned* slice, int words) {
+  for (int i = threadIdx.x; i < words; i += 256) __hip_atomic_store(slice + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+hipError_t ticket_reset(unsigned* slice, size_t bytes, hipStream_t stream) {
+  hipLaunchKernelGGL(spectre_ticket_reset, dim3(1), dim3(256), 0, stream, slice, (int)(bytes / 4));
+  return hipGetLastError();
+}
+
+// SPECTRE_TILE_ORDER = auto (default: measured per tensor pair) | tickets | static   (under SPECTRE_TUNING=1)
+int tile_order_policy() {
+  static const int pol = [] { const char* e = tuning_env("SPECTRE_TILE_ORDER"); return !e ? 2 : !strcmp(e, "static") ? 0 : !strcmp(e, "tickets") ? 1 : 2; }();
+  return pol;
+}
+
+Plan::OrderEntry* order_entry(const SpectreMixArgs* a, const Plan* plan, bool create) {     // (plan->order_mu held)
+  const uint64_t key[6] = {(uint64_t)(uintptr_t)a->v, (uint64_t)(uintptr_t)a->out, (uint64_t)a->B, (uint64_t)a->D,
+                           (uint64_t)a->N_in * 4 + (uint64_t)a->in_dtype * 2 + (uint64_t)a->out_dtype, (uint64_t)a->v_sn ^ ((uint64_t)a->out_sn << 32)};
+  for (auto& en : plan->orders) if (!memcmp(en.key, key, sizeof key)) { en.last_use = ++plan->order_clock; return &en; }
+  if (!create) return nullptr;
+  if (plan->orders.size() >= 64) {                 // forget the pair that has not been used for the longest time (its events with it)
+    size_t old = 0;
+    for (size_t i = 1; i < plan->orders.size(); ++i) if (plan->orders[i].last_use < plan->orders[old].last_use) old = i;
+    for (auto& pd : plan->orders[old].pending) { (void)hipEventDestroy(pd.e0); (void)hipEventDestroy(pd.e1); }
+    plan->orders.erase(plan->orders.begin() + (long)old);
+  }
+  plan->orders.emplace_back();
+  memcpy(plan->orders.back().key, key, sizeof key);
+  plan->orders.back().last_use = ++plan->order_clock;
+  return &plan->orders.back();
+}
+
+// Which order does THIS launch take (1 = tickets), and does it carry an event pair (returned in *ev, recorded by the caller around the launch)?
+int choose_tile_order(const SpectreMixArgs* a, const Plan* plan, hipStream_t stream, Plan::OrderPending* ev, bool* timed) {
+  *timed = false;
+  const int pol = tile_order_policy();
+  if (pol != 2) return pol;
+  std::lock_guard<std::mutex> lk(plan->order_mu);
+  Plan::OrderEntry* en = order_entry(a, plan, true);
+  // a stream that is being captured: no event calls at all (they are not capture-safe — a query of an outside event during the capture
+  // left the captured launch without its slice reset on replay); the order this pair has settled on, or tickets
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return en->decided >= 0 ? en->decided : 1;
+  // harvest what has finished (in issue order; nothing waits)
+  while (!en->pending.empty() && hipEventQuery(en->pending.front().e1) == hipSuccess) {
+    Plan::OrderPending pd = en->pending.front();
+    en->pending.erase(en->pending.begin());
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, pd.e0, pd.e1) == hipSuccess && ms > 0.f) {
+      if (en->samples[pd.mode]++ >= 2) en->sum[pd.mode] += ms;       // (the first two samples of an order are its warm-up)
+    }
+    (void)hipEventDestroy(pd.e0); (void)hipEventDestroy(pd.e1);
+  }
+  (void)hipGetLastError();                         // (hipEventQuery's hipErrorNotReady is not an error of ours)
+  if (en->decided < 0 && en->samples[0] >= 6 && en->samples[1] >= 6)
+    en->decided = en->sum[1] / (float)(en->samples[1] - 2) <= en->sum[0] / (float)(en->samples[0] - 2) ? 1 : 0;
+  if (en->decided >= 0) return en->decided;
+  // exploring: T S S T T S S T T S S T, six timed launches per order
+  const int k = en->issued[0] + en->issued[1];
+  const int mode = (k & 3) == 0 || (k & 3) == 3 ? 1 : 0;
+  if (k >= 12) return 1;
+  if (hipEventCreate(&ev->e0) != hipSuccess) { (void)hipGetLastError(); return 1; }
+  if (hipEventCreate(&ev->e1) != hipSuccess) { (void)hipEventDestroy(ev->e0); (void)hipGetLastError(); return 1; }
+  ev->mode = mode;
+  ++en->issued[mode];
+  *timed = true;
+  return mode;
+}
+
+void tile_order_timed(const SpectreMixArgs* a, const Plan* plan, const Plan::OrderPending& ev) {     // the event pair is on the stream: remember it
+  std::lock_guard<std::mutex> lk(plan->order_mu);
+  if (Plan::OrderEntry* en = order_entry(a, plan, false)) en->pending.push_back(ev);
+  else { (void)hipEventDestroy(ev.e0); (void)hipEventDestroy(ev.e1); }
+}
+
+const char* tile_order_name(const SpectreMixArgs* a, const Plan* plan) {
+  const int pol = tile_order_policy();
+  if (pol == 0) return "static";
+  if (pol == 1) return "tickets";
+  std::lock_guard<std::mutex> lk(plan->order_mu);
+  const Plan::OrderEntry* en = order_entry(a, plan, false);
+  return !en || en->decided < 0 ? "auto" : en->decided ? "auto:tickets" : "auto:static";
 }
 
 int launch(const SpectreMixArgs* a, const Plan* plan, const Choice& c, bool conj_gate = false) {
@@ -540,28 +643,36 @@ int launch(const SpectreMixArgs* a, const Plan* plan, const Choice& c, bool conj
       k.tpw = forced > 0 ? forced : std::max(1, (k.n_tiles + slots - 1) / slots);
       k.n_wg = gang * ((k.n_tiles + gang * k.tpw - 1) / (gang * k.tpw));
       // round 5: dynamic tile order (one ticket per gang from a chip-wide counter) where the ring exists and the launch fits a slice
-      if (p64_tickets(a, plan, k.n_tiles, k.n_wg, gang)) {
+      Plan::OrderPending ev{}; bool timed = false;
+      if (p64_tickets(a, plan, k.n_tiles, k.n_wg, gang) && choose_tile_order(a, plan, stream, &ev, &timed)) {
+        if (timed) (void)hipEventRecord(ev.e0, stream);
         unsigned* slice = plan->tk_ring + (size_t)(plan->tk_next.fetch_add(1, std::memory_order_relaxed) % kTicketSlices) * sfft::kP64TkSliceWords;
         const size_t used = ((size_t)sfft::kP64TkClaim + (size_t)(k.n_tiles + 31) / 32) * 4;
-        if ((e = hipMemsetAsync(slice, 0, used, stream)) != hipSuccess) return fail(SPECTRE_E_HIP, "ticket slice reset: %s", hipGetErrorString(e));
+        if ((e = ticket_reset(slice, used, stream)) != hipSuccess) return fail(SPECTRE_E_HIP, "ticket slice reset: %s", hipGetErrorString(e));
         k.tickets = slice;
       }
+      else if (timed) (void)hipEventRecord(ev.e0, stream);
       e = sfft::launch_regtile64p(k, ib, ob, !burst_off, stream);
+      if (timed) { (void)hipEventRecord(ev.e1, stream); tile_order_timed(a, plan, ev); }
     } else if (c.mixedp) {   // one workgroup per CU, pairs of workgroups on adjacent tiles (kernel_regtile_mixedp.h)
       const int ncu = cu_count(a->device);
       const int slots = std::max(2, ncu / 2 * 2);
       k.tpw = std::max(1, (k.n_tiles + slots - 1) / slots);
       k.n_wg = 2 * ((k.n_tiles + 2 * k.tpw - 1) / (2 * k.tpw));
       const int64_t n = a->n_fft;
-      if (mixedp_tickets(a, plan, k.n_tiles, k.n_wg)) {      // round 5: dynamic tile order, as at 4096
+      Plan::OrderPending ev{}; bool timed = false;
+      if (mixedp_tickets(a, plan, k.n_tiles, k.n_wg) && choose_tile_order(a, plan, stream, &ev, &timed)) {      // round 5: dynamic tile order, as at 4096
+        if (timed) (void)hipEventRecord(ev.e0, stream);
         unsigned* slice = plan->tk_ring + (size_t)(plan->tk_next.fetch_add(1, std::memory_order_relaxed) % kTicketSlices) * sfft::kTkSliceWords;
         const size_t used = ((size_t)sfft::kTkClaim + (size_t)(k.n_tiles + 31) / 32) * 4;
-        if ((e = hipMemsetAsync(slice, 0, used, stream)) != hipSuccess) return fail(SPECTRE_E_HIP, "ticket slice reset: %s", hipGetErrorString(e));
+        if ((e = ticket_reset(slice, used, stream)) != hipSuccess) return fail(SPECTRE_E_HIP, "ticket slice reset: %s", hipGetErrorString(e));
         k.tickets = slice;
       }
+      else if (timed) (void)hipEventRecord(ev.e0, stream);
       e = n == 3000 ? sfft::launch_regtile_mixedp<60, 50>(k, stream) : n == 2560 ? sfft::launch_regtile_mixedp<64, 40>(k, stream)
         : n == 2400 ? sfft::launch_regtile_mixedp<60, 40>(k, stream) : n == 3072 ? sfft::launch_regtile_mixedp<64, 48>(k, stream)
         : n == 3600 ? sfft::launch_regtile_mixedp<60, 60>(k, stream) : sfft::launch_regtile_mixedp<64, 60>(k, stream);
+      if (timed) { (void)hipEventRecord(ev.e1, stream); tile_order_timed(a, plan, ev); }
     } else {
       e = c.tile->launch(k, ib, ob, c.mode, stream);
     }
@@ -691,13 +802,13 @@ int spectre_mix_describe(const SpectreMixArgs* a, char* buf, size_t cap) {
     const int slots = std::max(gang, ncu / gang * gang), tpw = std::max(1, (n_tiles + slots - 1) / slots);
     const int n_wg = gang * ((n_tiles + gang * tpw - 1) / (gang * tpw));
     const size_t l = strlen(buf);
-    snprintf(buf + l, cap - l, " order=%s", p64_tickets(a, plan, n_tiles, n_wg, gang) ? "tickets" : "static");
+    snprintf(buf + l, cap - l, " order=%s", p64_tickets(a, plan, n_tiles, n_wg, gang) ? tile_order_name(a, plan) : "static");
   }
   if (c.regtile && c.mixedp) {
     const int ncu = cu_count(a->device), n_tiles = (int)(a->B * ((a->D + 15) / 16));
     const int slots = std::max(2, ncu / 2 * 2), tpw = std::max(1, (n_tiles + slots - 1) / slots), n_wg = 2 * ((n_tiles + 2 * tpw - 1) / (2 * tpw));
     const size_t l = strlen(buf);
-    snprintf(buf + l, cap - l, " order=%s", mixedp_tickets(a, plan, n_tiles, n_wg) ? "tickets" : "static");
+    snprintf(buf + l, cap - l, " order=%s", mixedp_tickets(a, plan, n_tiles, n_wg) ? tile_order_name(a, plan) : "static");
   }
   const std::string ov = tuning_overrides();
   if (!ov.empty()) { const size_t l = strlen(buf); snprintf(buf + l, cap - l, " [tuning: %s]", ov.c_str()); }

@@ -144,12 +144,14 @@ def spectral_mix_backward(V: torch.Tensor, gate: torch.Tensor, grad_out: torch.T
     return dv, dgate
 
 
-def describe(V, gate, memory_fft=None, n_fft=None, *, out_dtype=None, algo="auto") -> str:
-    """Name of the kernel `spectral_mix` would launch for these arguments."""
+def describe(V, gate, memory_fft=None, n_fft=None, *, out_dtype=None, algo="auto", out=None) -> str:
+    """Name of the kernel `spectral_mix` would launch for these arguments.  `out`: the output tensor of the launch in question (the tile
+    order of the persistent kernels is measured per (V, out) pair: `order=auto` until it has been, then `auto:tickets` / `auto:static`)."""
     lib = _native.load()
     if n_fft is None:
         n_fft = V.shape[1]
-    out = _empty_out(V, n_fft, out_dtype)
+    if out is None:
+        out = _empty_out(V, n_fft, out_dtype)
     a, keep = _args(V, gate, memory_fft, n_fft, out, algo)
     buf = ctypes.create_string_buffer(512)
     _native.check(lib.spectre_mix_describe(ctypes.byref(a), buf, 512), "spectre_mix_describe")

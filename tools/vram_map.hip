@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <algorithm>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 typedef float f4 __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(256) st(f4* __restrict__ dst) { dst[(size_t)blockIdx.x * 256 + threadIdx.x] = f4{1.f, 2.f, 3.f, 4.f}; }
@@ -35,11 +36,39 @@ __global__ void __launch_bounds__(512) st_tiles(char* __restrict__ dst, int n_ti
       for (int q = 0; q < 8; ++q) *reinterpret_cast<f4*>(dst + base + lane_off + (long long)(c * 8 + q) * step) = f4{1.f, 2.f, 3.f, 4.f};
   }
 }
+// a buffer assembled from physical chunks of `chunk` bytes through the virtual-memory API, mapped in a SHUFFLED order (every chunk is a
+// separate allocation of the driver: physically scattered by construction)
+static char* vmm_buffer(size_t bytes, size_t chunk, unsigned seed) {
+  hipMemAllocationProp prop{};
+  prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = 0;
+  size_t gran = 0; CK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum));
+  if (chunk % gran) { fprintf(stderr, "chunk %zu is not a multiple of the granularity %zu\n", chunk, gran); exit(1); }
+  void* va = nullptr; CK(hipMemAddressReserve(&va, bytes, 0, nullptr, 0));
+  const size_t n = bytes / chunk;
+  std::vector<hipMemGenericAllocationHandle_t> h(n);
+  for (size_t i = 0; i < n; ++i) CK(hipMemCreate(&h[i], chunk, &prop, 0));
+  std::vector<size_t> order(n); for (size_t i = 0; i < n; ++i) order[i] = i;
+  for (size_t i = n - 1; i > 0; --i) { seed = seed * 1664525u + 1013904223u; std::swap(order[i], order[(seed >> 8) % (i + 1)]); }
+  for (size_t i = 0; i < n; ++i) CK(hipMemMap((char*)va + i * chunk, chunk, 0, h[order[i]], 0));
+  hipMemAccessDesc acc{}; acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
+  CK(hipMemSetAccess(va, bytes, &acc, 1));
+  return (char*)va;
+}
 int main(int argc, char** argv) {
   const int want = argc > 1 ? atoi(argv[1]) : 80;
   const size_t bytes = (size_t)(argc > 2 ? atoi(argv[2]) : 3) << 30;
   std::vector<char*> bufs;
-  for (int i = 0; i < want; ++i) { char* p = nullptr; if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); break; } bufs.push_back(p); }
+  std::vector<const char*> kind;
+  if (argc > 3) {                                  // "vmm": a few hipMalloc buffers, then buffers assembled from 2-MiB / 32-MiB / 256-MiB / 1-GiB chunks
+    for (int i = 0; i < 6; ++i) { char* p = nullptr; CK(hipMalloc(&p, bytes)); bufs.push_back(p); kind.push_back("hipMalloc"); }
+    for (int rep = 0; rep < 3; ++rep) {
+      bufs.push_back(vmm_buffer(bytes, (size_t)2 << 20, 1 + rep)); kind.push_back("vmm 2 MiB chunks, shuffled");
+      bufs.push_back(vmm_buffer(bytes, (size_t)32 << 20, 11 + rep)); kind.push_back("vmm 32 MiB chunks, shuffled");
+      bufs.push_back(vmm_buffer(bytes, (size_t)256 << 20, 21 + rep)); kind.push_back("vmm 256 MiB chunks, shuffled");
+      bufs.push_back(vmm_buffer(bytes, (size_t)1 << 30, 31 + rep)); kind.push_back("vmm 1 GiB chunks, shuffled");
+    }
+  } else
+  for (int i = 0; i < want; ++i) { char* p = nullptr; if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); break; } bufs.push_back(p); kind.push_back("hipMalloc"); }
   printf("%zu buffers of %.0f GiB\n", bufs.size(), bytes / 1073741824.0);
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   f4* sink; CK(hipMalloc(&sink, 64));
@@ -62,6 +91,7 @@ int main(int argc, char** argv) {
         CK(hipEventRecord(e0)); for (int r = 0; r < 8; ++r) go(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         CK(hipEventElapsedTime(&ms[w], e0, e1)); ms[w] /= 8;
       }
+      printf("[%s] ", kind[i]);
       printf("pass %d buffer %3zu  va %p  store %.4f ms %7.1f GB/s   load %.4f ms %7.1f GB/s   tile-shaped store %.4f ms %7.1f GB/s   rot1 %.4f ms  rot5 %.4f ms   240 elements padded by 1 / 16 / 64 / 171 rows: %.4f %.4f %.4f %.4f ms (x 256/240: %.4f %.4f %.4f %.4f)\n", pass, i, (void*)bufs[i], ms[0], bytes / ms[0] / 1e6, ms[1], bytes / ms[1] / 1e6,
              ms[2], (double)n_tiles * 4096 * 128 / ms[2] / 1e6, ms[3], ms[4], ms[5], ms[6], ms[7], ms[8], ms[5] * 256 / 240, ms[6] * 256 / 240, ms[7] * 256 / 240, ms[8] * 256 / 240);
     }
