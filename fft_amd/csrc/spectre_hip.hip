@@ -5,6 +5,7 @@
 // No computation happens on the host beyond twiddle/chirp tables (double precision, once per plan).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdarg>
@@ -173,6 +174,7 @@ int fail(int code, const char* fmt, ...) {
 constexpr size_t kLdsBytes = 160 * 1024;   // gfx950: 160 KiB per CU, one workgroup may take all of it
 
 constexpr int kTicketSlices = 64;
+constexpr int kOrderWarmLaunches = 24;
 
 struct Plan {
   int device = 0;
@@ -196,16 +198,20 @@ struct Plan {
   mutable std::atomic<unsigned> tk_next{0};
   // ... and WHICH order a launch takes is measured, per (V, out) pair: the static map wins by 2-6 % where the driver has placed the two tensors
   // in memory of the fast class and loses by 3-5 % elsewhere (allocation classes) — nothing a library can see from a
-  // pointer.  So the first twelve launches on a pair take the two orders in the pattern T S S T (a clock that is still ramping up cancels out)
-  // with a HIP event pair around each (recorded on the caller's stream, looked at later with hipEventQuery: nothing ever waits), and once both
-  // orders have four samples behind two warm-up launches each, the faster one stays.  Same bits either way.  Not under stream capture (no events
-  // there: the current choice, or tickets).
+  // pointer.  So behind the first 24 launches on a pair (tickets: the chip needs ~25 launches to leave its idle power state, and a measurement
+  // taken while the clock ramps up picked the wrong order in bench.py) sixteen launches take the two orders in the pattern T S S T (what is
+  // left of a drift cancels out) with a HIP event pair around each (recorded on the caller's stream, looked at later with hipEventQuery:
+  // nothing ever waits), and once all sixteen have finished the order with the smaller median (behind the first sample of each) stays.
+  // Same bits either way.  Not under stream capture (no event calls there: the order the pair has settled on, or tickets).
   struct OrderPending { hipEvent_t e0, e1; int mode; };
   struct OrderEntry {
     uint64_t key[6] = {0, 0, 0, 0, 0, 0};
     int decided = -1;                              // -1 exploring, 0 static, 1 tickets
+    int launches = 0;                              // on this pair so far (the measurement starts behind kOrderWarmLaunches of them)
     int issued[2] = {0, 0}, samples[2] = {0, 0};
-    float sum[2] = {0.f, 0.f};                     // of the samples behind the two warm-up launches of each order
+    float ms[2][8] = {{0}, {0}};                   // the samples of each order, in issue order
+    float med[2] = {0.f, 0.f};                     // medians behind the first sample of each (what the decision was taken on)
+    char name[64] = "auto";
     std::vector<OrderPending> pending;
     uint64_t last_use = 0;
   };
@@ -573,18 +579,22 @@ int choose_tile_order(const SpectreMixArgs* a, const Plan* plan, hipStream_t str
     en->pending.erase(en->pending.begin());
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, pd.e0, pd.e1) == hipSuccess && ms > 0.f) {
-      if (en->samples[pd.mode]++ >= 2) en->sum[pd.mode] += ms;       // (the first two samples of an order are its warm-up)
+      if (en->samples[pd.mode] < 8) en->ms[pd.mode][en->samples[pd.mode]++] = ms;
     }
     (void)hipEventDestroy(pd.e0); (void)hipEventDestroy(pd.e1);
   }
   (void)hipGetLastError();                         // (hipEventQuery's hipErrorNotReady is not an error of ours)
-  if (en->decided < 0 && en->samples[0] >= 6 && en->samples[1] >= 6)
-    en->decided = en->sum[1] / (float)(en->samples[1] - 2) <= en->sum[0] / (float)(en->samples[0] - 2) ? 1 : 0;
+  if (en->decided < 0 && en->samples[0] >= 8 && en->samples[1] >= 8) {
+    for (int m = 0; m < 2; ++m) { float t[7]; memcpy(t, en->ms[m] + 1, sizeof t); std::sort(t, t + 7); en->med[m] = t[3]; }
+    en->decided = en->med[1] <= en->med[0] ? 1 : 0;
+    snprintf(en->name, sizeof en->name, "auto:%s (%.4f ms against %.4f)", en->decided ? "tickets" : "static", en->med[en->decided], en->med[1 - en->decided]);
+  }
   if (en->decided >= 0) return en->decided;
-  // exploring: T S S T T S S T T S S T, six timed launches per order
+  if (++en->launches <= kOrderWarmLaunches) return 1;
+  // measuring: T S S T T S S T T S S T T S S T, eight timed launches per order
   const int k = en->issued[0] + en->issued[1];
   const int mode = (k & 3) == 0 || (k & 3) == 3 ? 1 : 0;
-  if (k >= 12) return 1;
+  if (k >= 16) return 1;
   if (hipEventCreate(&ev->e0) != hipSuccess) { (void)hipGetLastError(); return 1; }
   if (hipEventCreate(&ev->e1) != hipSuccess) { (void)hipEventDestroy(ev->e0); (void)hipGetLastError(); return 1; }
   ev->mode = mode;
@@ -605,7 +615,9 @@ const char* tile_order_name(const SpectreMixArgs* a, const Plan* plan) {
   if (pol == 1) return "tickets";
   std::lock_guard<std::mutex> lk(plan->order_mu);
   const Plan::OrderEntry* en = order_entry(a, plan, false);
-  return !en || en->decided < 0 ? "auto" : en->decided ? "auto:tickets" : "auto:static";
+  static thread_local char buf[64];
+  snprintf(buf, sizeof buf, "%s", en ? en->name : "auto");
+  return buf;
 }
 
 int launch(const SpectreMixArgs* a, const Plan* plan, const Choice& c, bool conj_gate = false) {

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <cstring>
 #include <algorithm>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -59,6 +60,14 @@ int main(int argc, char** argv) {
   const size_t bytes = (size_t)(argc > 2 ? atoi(argv[2]) : 3) << 30;
   std::vector<char*> bufs;
   std::vector<const char*> kind;
+  if (argc > 3 && !strcmp(argv[3], "flags")) {     // hipMalloc against hipExtMallocWithFlags: uncached / fine-grained / contiguous
+    for (int rep = 0; rep < 5; ++rep) {
+      char* p = nullptr; CK(hipMalloc(&p, bytes)); bufs.push_back(p); kind.push_back("hipMalloc");
+      if (hipExtMallocWithFlags((void**)&p, bytes, hipDeviceMallocUncached) == hipSuccess) { bufs.push_back(p); kind.push_back("uncached"); } else (void)hipGetLastError();
+      if (hipExtMallocWithFlags((void**)&p, bytes, hipDeviceMallocFinegrained) == hipSuccess) { bufs.push_back(p); kind.push_back("fine-grained"); } else (void)hipGetLastError();
+      if (hipExtMallocWithFlags((void**)&p, bytes, hipDeviceMallocContiguous) == hipSuccess) { bufs.push_back(p); kind.push_back("contiguous"); } else (void)hipGetLastError();
+    }
+  } else
   if (argc > 3) {                                  // "vmm": a few hipMalloc buffers, then buffers assembled from 2-MiB / 32-MiB / 256-MiB / 1-GiB chunks
     for (int i = 0; i < 6; ++i) { char* p = nullptr; CK(hipMalloc(&p, bytes)); bufs.push_back(p); kind.push_back("hipMalloc"); }
     for (int rep = 0; rep < 3; ++rep) {
