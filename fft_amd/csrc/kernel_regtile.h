@@ -88,6 +88,19 @@ __device__ __forceinline__ uint32_t f32_to_bf16_rne(float f) {
   x += 0x7fffu + ((x >> 16) & 1u);
   return x >> 16;
 }
+// Two values -> one packed dword (a in the low half), the same rounding: gfx950 has an instruction for it (v_cvt_pk_bf16_f32, round to
+// nearest even) where the bit arithmetic above costs ~12 VALU instructions per pair — 700 of the ~5 400 per thread and 4096-row tile in the
+// kernels that write bf16 rows (round 5: those kernels are bound by their instruction stream, and by the power it draws).  NaNs are made the
+// canonical 0x7fc0 the scalar form (and torch's conversion) returns, so the result stays bit-identical for every input.
+typedef __bf16 rt_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float rt_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t f32x2_to_bf16x2_rne(float a, float b) {
+  const rt_f32x2 v = {a, b};
+  uint32_t r = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, rt_bf16x2));
+  if (a != a) r = (r & 0xffff0000u) | 0x7fc0u;
+  if (b != b) r = (r & 0x0000ffffu) | 0x7fc00000u;
+  return r;
+}
 
 // LDS exchange of one float plane at a time (real parts, then imaginary parts): the tile (RF*RS*8 columns*8 B =
 // 256 KiB at 4096) does not fit the 160 KiB LDS, and this keeps the live register set at RF complex values (re in +
@@ -468,7 +481,7 @@ spectre_mix_regtile(const RegtileArgs a) {
       if constexpr (GENERAL) {
         const uint32_t off = ooff_c + (uint32_t)((long long)n1 * RS * out_sn * ES_OUT);
         if constexpr (OUT_BF16) {
-          __builtin_amdgcn_raw_buffer_store_b32(f32_to_bf16_rne(z[j].x) | (f32_to_bf16_rne(z[j].y) << 16), rs_out, off, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(f32x2_to_bf16x2_rne(z[j].x, z[j].y), rs_out, off, 0, 0);
         } else {
           rt_u32x2 t;
           t.x = __float_as_uint(z[j].x); t.y = __float_as_uint(z[j].y);
@@ -477,7 +490,7 @@ spectre_mix_regtile(const RegtileArgs a) {
       } else {
         char* ptr = ob + (size_t)n1 * RS * out_sn * ES_OUT + ooff;
         if constexpr (OUT_BF16) {
-          *reinterpret_cast<uint32_t*>(ptr) = f32_to_bf16_rne(z[j].x) | (f32_to_bf16_rne(z[j].y) << 16);
+          *reinterpret_cast<uint32_t*>(ptr) = f32x2_to_bf16x2_rne(z[j].x, z[j].y);
         } else {
           *reinterpret_cast<float2*>(ptr) = z[j];
         }

@@ -378,7 +378,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
   auto store16 = [&](__amdgpu_buffer_rsrc_t rs, uint32_t off, const float4 v) {   // this lane's 4 channels of one row
     if constexpr (OUT_BF16) {
       rt_u32x2 t;
-      t.x = f32_to_bf16_rne(v.x) | (f32_to_bf16_rne(v.y) << 16); t.y = f32_to_bf16_rne(v.z) | (f32_to_bf16_rne(v.w) << 16);
+      t.x = f32x2_to_bf16x2_rne(v.x, v.y); t.y = f32x2_to_bf16x2_rne(v.z, v.w);
       __builtin_amdgcn_raw_buffer_store_b64(t, rs, off, 0, 0);
     } else {
       p64_u32x4 t;

@@ -283,7 +283,7 @@ spectre_mix_regtile_mixed(const RegtileArgs a) {
       if constexpr (GENERAL) {
         const uint32_t off = ooff_c + (uint32_t)((long long)n1 * RS * a.out_sn * ES_OUT);
         if constexpr (OUT_BF16) {
-          __builtin_amdgcn_raw_buffer_store_b32(f32_to_bf16_rne(z[pos].x) | (f32_to_bf16_rne(z[pos].y) << 16), rs_out, off, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(f32x2_to_bf16x2_rne(z[pos].x, z[pos].y), rs_out, off, 0, 0);
         } else {
           rt_u32x2 t;
           t.x = __float_as_uint(z[pos].x); t.y = __float_as_uint(z[pos].y);
@@ -292,7 +292,7 @@ spectre_mix_regtile_mixed(const RegtileArgs a) {
       } else {
         char* ptr = ob + (size_t)n1 * RS * a.out_sn * ES_OUT + ooff;
         if constexpr (OUT_BF16) {
-          *reinterpret_cast<uint32_t*>(ptr) = f32_to_bf16_rne(z[pos].x) | (f32_to_bf16_rne(z[pos].y) << 16);
+          *reinterpret_cast<uint32_t*>(ptr) = f32x2_to_bf16x2_rne(z[pos].x, z[pos].y);
         } else {
           *reinterpret_cast<float2*>(ptr) = z[pos];
         }

@@ -203,7 +203,7 @@ spectre_mix_regtile_wide(const RegtileArgs a) {
       if constexpr (PADDED) {
         const uint32_t off = ooff + (uint32_t)((long long)n1 * RS * out_sn * ES_OUT);
         if constexpr (OUT_BF16) {
-          __builtin_amdgcn_raw_buffer_store_b32(f32_to_bf16_rne(z[j].x) | (f32_to_bf16_rne(z[j].y) << 16), rs_out, off, 0, (NT & 2) ? 2 : 0);
+          __builtin_amdgcn_raw_buffer_store_b32(f32x2_to_bf16x2_rne(z[j].x, z[j].y), rs_out, off, 0, (NT & 2) ? 2 : 0);
         } else {
           rt_u32x2 t;
           t.x = __float_as_uint(z[j].x); t.y = __float_as_uint(z[j].y);
@@ -213,7 +213,7 @@ spectre_mix_regtile_wide(const RegtileArgs a) {
       }
       char* ptr = ob + (size_t)n1 * RS * out_sn * ES_OUT + ooff;
       if constexpr (OUT_BF16) {
-        const uint32_t w = f32_to_bf16_rne(z[j].x) | (f32_to_bf16_rne(z[j].y) << 16);
+        const uint32_t w = f32x2_to_bf16x2_rne(z[j].x, z[j].y);
         if constexpr (NT & 2) __builtin_nontemporal_store(w, reinterpret_cast<uint32_t*>(ptr)); else *reinterpret_cast<uint32_t*>(ptr) = w;
       }
       else if constexpr (NT & 2) { wide_f32x2 t; t.x = z[j].x; t.y = z[j].y; __builtin_nontemporal_store(t, reinterpret_cast<wide_f32x2*>(ptr)); }
