@@ -838,6 +838,9 @@ int spectre_mix_time(const SpectreMixArgs* a, int warmup, int iters, float* ms_p
   hipStream_t stream = reinterpret_cast<hipStream_t>(a->stream);
   for (int i = 0; i < warmup; ++i)
     if ((rc = launch(a, plan, c))) return rc;
+  // the warm-up launches have been ISSUED, not run: let them finish, so that a tile order that is still being measured (choose_tile_order:
+  // launches 25-40 on a tensor pair) is settled by what they measured before the timed launches start, instead of by whoever calls next
+  if (warmup > 0 && hipStreamSynchronize(stream) != hipSuccess) return fail(SPECTRE_E_HIP, "hipStreamSynchronize failed");
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(SPECTRE_E_HIP, "hipEventCreate failed");
   hipError_t e = hipEventRecord(e0, stream);

@@ -13,5 +13,5 @@ d=json.loads([l for l in open('gpurun_out/r05_bench_2.json') if l.startswith('{'
 r=d['roofline']; print('kernel', d['config']['kernel']); print('ms_per_step', d['ms_per_step'], 'kernel_ms', r['kernel_ms'], 'frac', r['frac'], 'cold', d.get('cold_start',{}).get('kernel_ms'))
 print({k:(round(v['kernel_ms'],4), round(v['roofline_frac'],3)) for k,v in d['variants'].items()})
 PY
-echo skip-profile
+timeout 1500 bash tools/profile_bench.sh r05 > gpurun_out/r05_profile_bench.log 2>&1; tail -3 gpurun_out/r05_profile_bench.log | cut -c1-300
 
