@@ -146,7 +146,7 @@ template <int SPLIT> constexpr int p64v_younger_first() { return 4 * (8 - SPLIT)
 //         right behind E2 of the previous one, none behind its stores (round 3: the fp32 kernel's late groups cost a memory latency
 //         per tile — same-box ablation: loads only 1.11 ms, stores only 0.90, neither 0.84).
 // OUT_BF16 = bf16 rows out (round to nearest even, like every other kernel here): a lane stores its 4 channels as 8 bytes.
-template <int SPLIT, int PF, bool WITH_MEM = false, bool IN_BF16 = false, bool OUT_BF16 = false, int GANGX = 0, int AUXD = 0, int AUXL = 0, int AUXS = 0, int PRIO = 0, int MAPX = 0, int DSPREAD = 0, int SYNCP = 0, int TSTAMP = 0, int PFL2 = 0, int STAG = 0, int PFSP = 0, int LATE = 0, int RLF = 0, int PARK = 0>
+template <int SPLIT, int PF, bool WITH_MEM = false, bool IN_BF16 = false, bool OUT_BF16 = false, int GANGX = 0, int AUXD = 0, int AUXL = 0, int AUXS = 0, int PRIO = 0, int MAPX = 0, int DSPREAD = 0, int SYNCP = 0, int TSTAMP = 0, int PFL2 = 0, int STAG = 0, int PFSP = 0, int LATE = 0, int RLF = 0, int PARK = 0, int ESPREAD = 1>
 __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) {
   constexpr int ESI = IN_BF16 ? 2 : 4, ESO = OUT_BF16 ? 2 : 4;   // bytes per input / output element
   constexpr float inv_n = 1.0f / 4096.0f;
@@ -233,6 +233,14 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
   [[maybe_unused]] const int per_xcd4 = MAPX == 5 ? a.n_tiles / 2 : a.n_tiles / 16;   // MAPX = 5: ONE counter for the chip (a.mem must then be device-coherent for scalar atomics: uncached memory)
   [[maybe_unused]] const int base4 = MAPX == 5 ? 0 : xcd_base;
   if constexpr (MAPX == 5) tick_cnt = reinterpret_cast<unsigned*>(const_cast<float*>(a.mem));
+  // ESPREAD (round 5, batch 34): consecutive tickets cycle over ESPREAD batch elements instead of walking through the columns of one
+  // (1 = address order: ~5 elements open; 128 = every pair in its own element, like the static map but handed out dynamically)
+  [[maybe_unused]] auto remap4 = [&](int t) -> int {
+    if constexpr (ESPREAD <= 1) return t;
+    const int cols = a.tiles_per_row / 2, per = cols * ESPREAD;
+    const int blk = t / per, w = t - blk * per;
+    return (blk * ESPREAD + w % ESPREAD) * cols + w / ESPREAD;
+  };
   if constexpr (MAPX == 4 || MAPX == 5) {
     if (tid0 == 0) {
       unsigned t0, t1;
@@ -251,7 +259,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
     cur_t = __builtin_amdgcn_readfirstlane((int)tick_lds[0]); nxt_t = __builtin_amdgcn_readfirstlane((int)tick_lds[1]);
     __syncthreads();
   }
-  const int pair_base = (MAPX == 4 || MAPX == 5) ? base4 + 2 * cur_t + member4 : MAPX == 3 ? xcd_base + cur_t : MAPX == 2 ? ((bx / 16) * 8 + bx % 8) * 2 + (bx / 8) % 2 : MAPX ? wg_lin : (wg_lin / GANG) * a.tpw * GANG + (wg_lin % GANG);
+  const int pair_base = (MAPX == 4 || MAPX == 5) ? base4 + 2 * remap4(cur_t) + member4 : MAPX == 3 ? xcd_base + cur_t : MAPX == 2 ? ((bx / 16) * 8 + bx % 8) * 2 + (bx / 8) % 2 : MAPX ? wg_lin : (wg_lin / GANG) * a.tpw * GANG + (wg_lin % GANG);
   const int TS = MAPX ? a.n_wg : GANG;
   if ((MAPX == 4 || MAPX == 5) ? cur_t >= per_xcd4 : MAPX == 3 ? cur_t >= per_xcd : pair_base >= a.n_tiles) return;
   // SYNCP: wave 0 announces the workgroup (one atomic add, no return value: older than every request the hand-counted waits look at) and
@@ -432,7 +440,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
   }
 
   for (int it = 0; MAPX == 3 || MAPX == 4 || MAPX == 5 || it < a.tpw; ++it) {
-    const int tile = (MAPX == 4 || MAPX == 5) ? base4 + 2 * cur_t + member4 : MAPX == 3 ? xcd_base + cur_t : pair_base + TS * it;
+    const int tile = (MAPX == 4 || MAPX == 5) ? base4 + 2 * remap4(cur_t) + member4 : MAPX == 3 ? xcd_base + cur_t : pair_base + TS * it;
     if ((MAPX == 4 || MAPX == 5) ? cur_t >= per_xcd4 : MAPX == 3 ? cur_t >= per_xcd : tile >= a.n_tiles) break;                  // workgroup-uniform
     const bool more = (MAPX == 4 || MAPX == 5) ? nxt_t < per_xcd4 : MAPX == 3 ? nxt_t < per_xcd : (it + 1 < a.tpw) && (tile + TS < a.n_tiles);
     coords();
@@ -451,7 +459,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
     const char* vb; char* ob; const float2* gp;
     tile_ptrs(tile, vb, ob, gp);
     const char* vbn = vb; char* obn = ob; const float2* gpn = gp;
-    if (more) tile_ptrs((MAPX == 4 || MAPX == 5) ? base4 + 2 * nxt_t + member4 : MAPX == 3 ? xcd_base + nxt_t : tile + TS, vbn, obn, gpn);
+    if (more) tile_ptrs((MAPX == 4 || MAPX == 5) ? base4 + 2 * remap4(nxt_t) + member4 : MAPX == 3 ? xcd_base + nxt_t : tile + TS, vbn, obn, gpn);
     const __amdgpu_buffer_rsrc_t rs_next = rsrc_in(vbn, v_sn, more), rs_out = rsrc_out(ob, out_sn);
     // PFL2: touch the half lines of the row groups that will be RELOADED behind this tile's stores (one dword per row, LDS-DMA into a dump
     // word area: no register, tracked by vmcnt like every other request) so that the reloads find their lines in the L2.  Wave w covers the
