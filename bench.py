@@ -203,6 +203,7 @@ def main():
     last_end, neg_first_start, wall_old, kern_ms = rdv.max_over_ranks([t_end, -t_start, wall_old, kern_ms_own])
     wall = last_end + neg_first_start                         # whole job: first rank's start -> last rank's finish
     per_rank = rdv.gather_over_ranks({"rank": rank, "kernel_ms": kern_ms_own, "wall_s": t_end - t_start,
+                                      "tile_order": kernel_timed.rsplit("order=", 1)[-1] if "order=" in kernel_timed else None,
                                       "start_after_first_us": (t_start + neg_first_start) * 1e6,
                                       "end_before_last_us": (last_end - t_end) * 1e6})
 
