@@ -60,6 +60,28 @@ int main(int argc, char** argv) {
   const size_t bytes = (size_t)(argc > 2 ? atoi(argv[2]) : 3) << 30;
   std::vector<char*> bufs;
   std::vector<const char*> kind;
+  if (argc > 3 && !strcmp(argv[3], "far")) {       // buffers whose 32-MiB chunks come alternately from two pools allocated ~D GiB apart in time
+    // (= far apart in the driver's physical space, if it hands memory out in order): does spanning two regions make a buffer fast?
+    const size_t chunk = (size_t)32 << 20, nchunk = bytes / chunk;
+    hipMemAllocationProp prop{}; prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = 0;
+    hipMemAccessDesc acc{}; acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
+    auto pool = [&](size_t n) { std::vector<hipMemGenericAllocationHandle_t> h(n); for (auto& x : h) CK(hipMemCreate(&x, chunk, &prop, 0)); return h; };
+    auto assemble = [&](const std::vector<hipMemGenericAllocationHandle_t>& a, const std::vector<hipMemGenericAllocationHandle_t>& b, size_t& ia, size_t& ib, bool mix) {
+      void* va = nullptr; CK(hipMemAddressReserve(&va, bytes, 0, nullptr, 0));
+      for (size_t i = 0; i < nchunk; ++i) { const bool fromb = mix && (i & 1); CK(hipMemMap((char*)va + i * chunk, chunk, 0, fromb ? b[ib++] : a[ia++], 0)); }
+      CK(hipMemSetAccess(va, bytes, &acc, 1)); return (char*)va; };
+    for (int gap : {8, 32, 64}) {
+      auto A = pool(nchunk * 3);                   // enough chunks for: one pure buffer + half of two mixed ones
+      char* dummy = nullptr; CK(hipMalloc(&dummy, (size_t)gap << 30));
+      auto Bp = pool(nchunk * 2);
+      size_t ia = 0, ib = 0;
+      static char names[16][64]; static int nn = 0;
+      bufs.push_back(assemble(A, Bp, ia, ib, false)); snprintf(names[nn], 64, "pure, pool A (gap %d GiB)", gap); kind.push_back(names[nn++]);
+      bufs.push_back(assemble(A, Bp, ia, ib, true)); snprintf(names[nn], 64, "A/B alternating, %d GiB apart", gap); kind.push_back(names[nn++]);
+      bufs.push_back(assemble(A, Bp, ia, ib, true)); snprintf(names[nn], 64, "A/B alternating, %d GiB apart", gap); kind.push_back(names[nn++]);
+      { size_t z = 0; std::vector<hipMemGenericAllocationHandle_t> rest(Bp.begin() + ib, Bp.end()); if (rest.size() >= nchunk) { bufs.push_back(assemble(rest, rest, z, z, false)); snprintf(names[nn], 64, "pure, pool B (gap %d GiB)", gap); kind.push_back(names[nn++]); } }
+    }
+  } else
   if (argc > 3 && !strcmp(argv[3], "flags")) {     // hipMalloc against hipExtMallocWithFlags: uncached / fine-grained / contiguous
     for (int rep = 0; rep < 5; ++rep) {
       char* p = nullptr; CK(hipMalloc(&p, bytes)); bufs.push_back(p); kind.push_back("hipMalloc");
