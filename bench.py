@@ -179,15 +179,9 @@ def main():
     for _ in range(a.warmup):
         step()
     launched += a.warmup
-    clock = lambda: time.clock_gettime(time.CLOCK_MONOTONIC)  # one clock for every process of the node
+    clock = rdv.node_clock                                    # CLOCK_MONOTONIC: one clock for every process of the node
     barrier()                                                 # the contract's opening barrier + synchronize
-    if world > 1:
-        # ... and a common start: the ranks leave a gloo barrier up to a millisecond apart (TCP on the loopback), which on a 26-ms timed
-        # region would read as scaling loss.  They agree on a start time a few milliseconds ahead (the MAX all-reduce is itself a barrier)
-        # and spin until the node's monotonic clock reaches it.
-        (t_go,) = rdv.max_over_ranks([clock() + 0.004])
-        while clock() < t_go:
-            pass
+    rdv.common_start()                                        # ... and a common start (fft_amd/rendezvous.py; tests/test_multigpu_gloo.py)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t_start = clock()
     ev0.record()                                              # same stream the kernels are launched on
@@ -200,12 +194,13 @@ def main():
     wall_old = clock() - t_start
     kern_ms_own = ev0.elapsed_time(ev1) / a.steps             # average launch duration over the timed region, this rank
     kernel_timed = describe(V, gate, None, N, out=out)        # (the tile order of the persistent kernels is measured per (V, out) pair during the prewarm)
-    last_end, neg_first_start, wall_old, kern_ms = rdv.max_over_ranks([t_end, -t_start, wall_old, kern_ms_own])
-    wall = last_end + neg_first_start                         # whole job: first rank's start -> last rank's finish
+    wall_old, kern_ms = rdv.max_over_ranks([wall_old, kern_ms_own])
+    window = rdv.job_window(t_start, t_end)
+    wall = window["wall_s"]                                   # whole job: first rank's start -> last rank's finish
     per_rank = rdv.gather_over_ranks({"rank": rank, "kernel_ms": kern_ms_own, "wall_s": t_end - t_start,
                                       "tile_order": kernel_timed.rsplit("order=", 1)[-1] if "order=" in kernel_timed else None,
-                                      "start_after_first_us": (t_start + neg_first_start) * 1e6,
-                                      "end_before_last_us": (last_end - t_end) * 1e6})
+                                      "start_after_first_us": window["start_after_first_us"],
+                                      "end_before_last_us": window["end_before_last_us"]})
 
     # other storage dtypes of the same workload, same run (informational; `value` above is the --io default).
     # BASELINE.json configs[2] words the headline shape as "bf16 in / fp32 compute": both readings are reported.

@@ -58,6 +58,31 @@ class Rendezvous:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return [float(x) for x in t.cpu()]
 
+    @staticmethod
+    def node_clock() -> float:
+        """CLOCK_MONOTONIC: one clock for every process of the node (the ranks of a single-node job can compare stamps directly)."""
+        import time
+        return time.clock_gettime(time.CLOCK_MONOTONIC)
+
+    def common_start(self, margin_s: float = 0.004) -> float:
+        """The ranks leave a gloo barrier up to a millisecond apart (TCP on the loopback); on a 26-ms timed region that reads as
+        scaling loss.  Agree on a start time `margin_s` ahead of the LATEST rank (the MAX all-reduce is itself a barrier) and spin
+        until the node clock reaches it.  Returns the agreed time; one rank: returns at once."""
+        if self.backend == "none":
+            return self.node_clock()
+        (t_go,) = self.max_over_ranks([self.node_clock() + margin_s])
+        while self.node_clock() < t_go:
+            pass
+        return t_go
+
+    def job_window(self, t_start: float, t_end: float) -> dict:
+        """Whole-job wall time from per-rank node-clock stamps: first rank's start -> last rank's finish (never less than the MAX of the
+        per-rank durations, the contract's figure, and it also counts a rank that started late).  Same dict on every rank except the
+        two offsets, which are this rank's own."""
+        last_end, neg_first_start, longest = self.max_over_ranks([t_end, -t_start, t_end - t_start])
+        return {"wall_s": last_end + neg_first_start, "max_rank_wall_s": longest,
+                "start_after_first_us": (t_start + neg_first_start) * 1e6, "end_before_last_us": (last_end - t_end) * 1e6}
+
     def gather_over_ranks(self, obj) -> list:
         """[obj of rank 0, obj of rank 1, ...] on every rank — always over the gloo control plane (small Python objects: per-rank timings
         for the attribution fields of the bench line), whatever transport the barrier uses."""

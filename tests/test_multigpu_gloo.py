@@ -1,7 +1,8 @@
 """The N>1 path on CPU: world_size-2 `gloo` processes shard the batch exactly as bench.py does on GPUs
 (contiguous runs of B per rank, memory_fft replicated, NO collective in the data path), each rank runs the
 mix on its shard (the oracle stands in for the kernel — there is no GPU here), and the concatenation of
-the shards must equal the unsharded result; timing is reduced with MAX over ranks as bench.py does."""
+the shards must equal the unsharded result; the timed region uses bench.py's own protocol (agreed start, node-clock stamps,
+first start -> last finish)."""
 import os
 import socket
 import sys
@@ -37,11 +38,23 @@ def _worker(rank, world, port, B, N, D, G, tmp):
     mem = torch.complex(torch.randn(F, D, generator=gen), torch.randn(F, D, generator=gen)) * 0.1
     s, e = batch_shard(B, world, rank)
     y_local = spectral_mix_torch(V[s:e], gate[s:e], mem, N)  # shard of V and gate, replicated mem
-    # bench.py timing convention: barrier, time, MAX over ranks
-    dist.barrier()
-    t = torch.tensor([0.01 * (rank + 1)], dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    assert abs(t.item() - 0.01 * world) < 1e-12
+    # bench.py's timing protocol (fft_amd/rendezvous.py): barrier, agreed start on the node clock, per-rank stamps, whole job =
+    # first rank's start -> last rank's finish.  Rank r "works" for 20 ms * (r + 1).
+    import time
+    from fft_amd.rendezvous import Rendezvous
+    rdv = Rendezvous(world=world, rank=rank, backend="gloo")
+    rdv.barrier()
+    t_go = rdv.common_start(margin_s=0.01)
+    t_start = rdv.node_clock()
+    assert 0.0 <= t_start - t_go < 0.005                     # every rank left the spin at the agreed instant
+    time.sleep(0.02 * (rank + 1))
+    t_end = rdv.node_clock()
+    w = rdv.job_window(t_start, t_end)
+    assert w["wall_s"] >= w["max_rank_wall_s"] >= 0.02 * world
+    assert w["wall_s"] - w["max_rank_wall_s"] < 0.005         # common start: the job window is the slowest rank's, not more
+    assert 0.0 <= w["start_after_first_us"] < 5000.0
+    ends = rdv.gather_over_ranks(w["end_before_last_us"])
+    assert min(ends) == 0.0 and (world == 1 or max(ends) > 15000.0)   # the last rank defines the end; rank 0 finished ~20 ms earlier
     # gather only to CHECK (outside any timed region); the data path itself needs no collective
     sizes = [batch_shard(B, world, r) for r in range(world)]
     outs = [torch.empty(se - ss, N, D) for ss, se in sizes]
