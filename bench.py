@@ -317,14 +317,15 @@ def main():
         from fft_amd import spectral_mix_backward
         dout = torch.randn(B, N, D, device=dev).to(dt)
         for name, kw in (("backward_dV", dict(need_dv=True, need_dgate=False)), ("backward_dgate", dict(need_dv=False, need_dgate=True))):
-            for _ in range(8):                                             # untimed: first call builds the plan, the rest ramp the power state
-                spectral_mix_backward(V, gate, dout, N, **kw)
+            for _ in range(VARIANT_WARMUP):                                # untimed: first call builds the plan, the rest ramp the power state
+                spectral_mix_backward(V, gate, dout, N, **kw)              # and let the (dOut, dV) pair's tile order settle (40 launches)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = max(3, a.steps // 2)
             e0.record()
-            for _ in range(3):
+            for _ in range(reps):
                 spectral_mix_backward(V, gate, dout, N, **kw)
             e1.record(); torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / 3
+            ms = e0.elapsed_time(e1) / reps
             byt = 2 * B * N * D * V.element_size()     # dV: read dOut, write dV; dgate: read V and dOut
             variants[name] = {"tokens_per_s": B * N / (ms * 1e-3), "kernel_ms": ms, "achieved_GBps": byt / ms / 1e6,
                               "roofline_frac": byt / ms / 1e6 / HBM_PEAK_GBS}

@@ -167,8 +167,13 @@ __device__ __forceinline__ void exchange_planes_b128(float2 (&z)[E], float* img,
 // wbase + t * TS + row * RWF; rows r and r + 2 are 2 * RWF * 4 bytes apart, a multiple of the instruction's 256-byte offset unit for
 // every image layout here (RWF = 8 (R + 4), R a multiple of 4).  Its 8-bit offsets reach WIN rows, hence one opaque base address per
 // (t, row parity, window) instead of a single base with 16-bit offsets.
-template <int E, int RA, int RB, bool LAST_BARRIER, int ROWS, int NT, int TS, int RWF, class POS, class RD4>
-__device__ __forceinline__ void exchange_planes_b128_w2(float2 (&z)[E], float* img, int wbase, POS pos, RD4 rd4) {
+// HOOK (optional): called with std::integral_constant<int, 0 / 1 / 2> behind the three inner barriers — a caller that keeps global loads
+// in flight across the exchange (kernel_regtile_grad.h, prefetch form) issues more of them there; such a caller passes LDS_BAR = true:
+// __syncthreads() is a fence + s_barrier, and hipcc implements the fence with s_waitcnt vmcnt(0), which would drain those loads.
+struct ExchangeNoHook { template <class T> __device__ __forceinline__ void operator()(T) const {} };
+template <int E, int RA, int RB, bool LAST_BARRIER, int ROWS, int NT, int TS, int RWF, bool LDS_BAR = false, class POS, class RD4, class HOOK = ExchangeNoHook>
+__device__ __forceinline__ void exchange_planes_b128_w2(float2 (&z)[E], float* img, int wbase, POS pos, RD4 rd4, HOOK hook = HOOK{}) {
+  auto bar = [] { if constexpr (LDS_BAR) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); else __syncthreads(); };
   static_assert(ROWS * NT == E && ROWS % 4 == 0 && (2 * RWF * 4) % 256 == 0, "row pairs (r, r + 2) must be whole offset units apart");
   constexpr int UNITS2 = 2 * RWF * 4 / 256;                     // offset units between rows r and r + 2
   constexpr int WIN = ((255 / UNITS2) * 2 + 2) / 4 * 4;         // rows per window (multiple of 4): last pair starts at row WIN - 4 + {0,1}
@@ -207,13 +212,16 @@ __device__ __forceinline__ void exchange_planes_b128_w2(float2 (&z)[E], float* i
     });
   };
   write_plane(std::false_type{});
-  __syncthreads();
+  bar();
+  hook(std::integral_constant<int, 0>{});
   read_plane(std::false_type{});
-  __syncthreads();
+  bar();
+  hook(std::integral_constant<int, 1>{});
   write_plane(std::true_type{});
-  __syncthreads();
+  bar();
+  hook(std::integral_constant<int, 2>{});
   read_plane(std::true_type{});
-  if constexpr (LAST_BARRIER) __syncthreads();
+  if constexpr (LAST_BARRIER) bar();
 }
 
 // MODE 0 (fast): N_in >= n_fft (no row predicates), no memory_fft, every tile inside one gate group (gate staged in LDS).

@@ -156,7 +156,7 @@ const char* tuning_env(const char* name) {
 }
 std::string tuning_overrides() {
   std::string r;
-  for (const char* n : {"SPECTRE_P64", "SPECTRE_P64_BF16", "SPECTRE_P64_BURST", "SPECTRE_P64_TICKETS", "SPECTRE_MIXEDP_TICKETS", "SPECTRE_TILE_ORDER", "SPECTRE_WIDE", "SPECTRE_WIDE_MAX", "SPECTRE_WIDE_NT", "SPECTRE_MIXEDP", "SPECTRE_STOCKHAM_PMAX", "SPECTRE_TPW", "SPECTRE_P64_TPW", "SPECTRE_GATE_GRAD"})
+  for (const char* n : {"SPECTRE_P64", "SPECTRE_P64_BF16", "SPECTRE_P64_BURST", "SPECTRE_P64_TICKETS", "SPECTRE_MIXEDP_TICKETS", "SPECTRE_TILE_ORDER", "SPECTRE_WIDE", "SPECTRE_WIDE_MAX", "SPECTRE_WIDE_NT", "SPECTRE_MIXEDP", "SPECTRE_STOCKHAM_PMAX", "SPECTRE_TPW", "SPECTRE_P64_TPW", "SPECTRE_GATE_GRAD", "SPECTRE_DGATE_PREFETCH", "SPECTRE_DGATE_GRID"})
     if (const char* e = tuning_env(n)) r += std::string(r.empty() ? "" : " ") + n + "=" + e;
   return r;
 }
@@ -171,6 +171,7 @@ int fail(int code, const char* fmt, ...) {
   return code;
 }
 
+constexpr int kDgatePrefetch = 1;          // 64 x 64 gate gradient: the persistent form with prefetch registers (kernel_regtile_grad.h, PN / EARLY)
 constexpr size_t kLdsBytes = 160 * 1024;   // gfx950: 160 KiB per CU, one workgroup may take all of it
 
 constexpr int kTicketSlices = 64;
@@ -938,6 +939,10 @@ int spectre_mix_bwd(const SpectreMixBwdArgs* a) {
       int S = std::min(k.T, gch == 4 ? 8 : 4);        // the tiles of one 128-byte line go to neighbouring workgroups
       while (a->B * a->G_tot * S < 1024 && 2 * S <= std::min(k.T, 8)) S *= 2;
       k.S = S; k.n_wg = (int)(a->B * a->G_tot * S);
+      k.prefetch = kDgatePrefetch;
+      k.grid = cu_count(a->device) / S * S;           // (persistent form: whole (batch, group) gangs)
+      if (const char* e = tuning_env("SPECTRE_DGATE_GRID")) k.grid = atoi(e);
+      if (const char* e = tuning_env("SPECTRE_DGATE_PREFETCH")) k.prefetch = atoi(e);
       k.v_sb = a->v_sb; k.v_sn = a->v_sn; k.dout_sb = a->dout_sb; k.dout_sn = a->dout_sn;
       const bool bf = a->io_dtype == SPECTRE_BF16, general = (a->N_in < n) || (d_g % gch != 0);
       hipError_t e = ts->grad(k, bf, general, stream);
