@@ -82,6 +82,95 @@ def launch_command(n_gpus: int, argv: list) -> list:
             "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
 
 
+PMC_CHILD_LAUNCHES = 8
+
+
+def pmc_child(a):
+    """`bench.py --pmc-child`: the headline launch PMC_CHILD_LAUNCHES times on tensors of the headline's shape and nothing else — the
+    target of the two rocprofv3 --pmc passes of live_traffic().  (Counters serialise the kernels and cost seconds per pass, so they are
+    never collected around the timed region itself.)"""
+    import torch
+    from fft_amd import spectral_mix
+    from fft_amd import _native
+    _native.load()
+    B, N, D = (int(x) for x in a.shape.split(","))
+    dev = torch.device("cuda:0")
+    dt = torch.float32 if a.io == "f32" else torch.bfloat16
+    F = N // 2 + 1
+    torch.manual_seed(0)
+    V = torch.randn(B, N, D, device=dev).to(dt)
+    gate = torch.randn(B, a.groups, F, dtype=torch.complex64, device=dev) * 0.3
+    gate = gate * (torch.rand(B, a.groups, F, device=dev) >= 0.18)
+    out = torch.empty_like(V)
+    for _ in range(PMC_CHILD_LAUNCHES):
+        spectral_mix(V, gate, None, N, out=out)
+    torch.cuda.synchronize()
+
+
+def parse_pmc_csv(root, counter, want="spectre_mix_"):
+    """Per-dispatch values of `counter` for the kernels whose name contains `want`, from rocprofv3's *counter_collection.csv."""
+    import csv
+    import glob
+    vals, names = [], set()
+    for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
+        with open(f, newline="") as fh:
+            for r in csv.DictReader(fh):
+                if want in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter:
+                    vals.append(float(r["Counter_Value"]))
+                    names.add(r["Kernel_Name"].split("(")[0][:96])
+    return vals, sorted(names)
+
+
+def live_traffic(a, timeout_s=150.0):
+    """HBM bytes per launch of the headline kernel, measured in THIS bench invocation (the line used to replay
+    profiles/pmc_latest.json): two separate `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE: they do not fit one pass,
+    MI355X_MICROARCH.md) over `bench.py --pmc-child`, after everything that is timed has been timed.  gfx950 correction as the guide
+    prescribes: FETCH_SIZE counts a 128-byte request as 64 bytes -> doubled; WRITE_SIZE as is.  Returns (record | None, reason)."""
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    if os.environ.get("SPECTRE_BENCH_PMC", "1") == "0":
+        return None, "SPECTRE_BENCH_PMC=0"
+    if any(k.startswith(("ROCPROF", "ROCPROFILER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this process already runs under rocprofv3 (no nested collection)"
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["TMPDIR"] = "/tmp"
+    got, names, t0 = {}, [], time.perf_counter()
+    with tempfile.TemporaryDirectory(prefix="spectre_pmc_", dir="/tmp") as td:
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = [exe, "--output-format", "csv", "--pmc", c, "-d", os.path.join(td, c), "-o", "pmc", "--", sys.executable,
+                   os.path.abspath(__file__), "--pmc-child", "--io", a.io, "--shape", a.shape, "--groups", str(a.groups)]
+            try:
+                p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, start_new_session=True)
+            except OSError as e:
+                return None, f"rocprofv3 could not be started: {e}"
+            try:
+                _, err = p.communicate(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)                  # our own session: rocprofv3 and the child it started
+                except OSError:
+                    pass
+                p.wait()
+                return None, f"the {c} pass did not finish within {timeout_s:.0f} s"
+            if p.returncode != 0:
+                return None, f"the {c} pass exited with {p.returncode}: {err.decode(errors='replace')[-200:]}"
+            vals, nm = parse_pmc_csv(os.path.join(td, c), c)
+            if not vals:
+                return None, f"the {c} pass recorded no dispatch of the headline kernel"
+            got[c] = vals
+            names = nm
+    fetch = sum(got["FETCH_SIZE"]) / len(got["FETCH_SIZE"])
+    write = sum(got["WRITE_SIZE"]) / len(got["WRITE_SIZE"])
+    return {"hbm_bytes_per_launch": fetch * 1024 * 2 + write * 1024, "FETCH_SIZE_kb": fetch, "WRITE_SIZE_kb": write,
+            "launches": [len(got["FETCH_SIZE"]), len(got["WRITE_SIZE"])], "kernels": names,
+            "seconds": time.perf_counter() - t0}, "ok"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -97,7 +186,13 @@ def main():
     ap.add_argument("--groups", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--print-launch", action="store_true", help="print the multi-process launch command for --gpus N and exit")
+    ap.add_argument("--no-pmc", action="store_true", help="do not collect roofline.traffic live (two rocprofv3 --pmc child passes, ~1 min); "
+                                                          "the line then replays profiles/pmc_latest.json and says so")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
+    if a.pmc_child:
+        pmc_child(a)
+        return
 
     # --gpus N without a launcher around us: become the launcher (one rank per GPU; rendezvous on 127.0.0.1: gloo control plane first,
     # then an RCCL group that has to prove itself — fft_amd/rendezvous.py)
@@ -341,15 +436,23 @@ def main():
         es = V.element_size()
         alg = algorithmic_bytes(B, N, N, D, G, es, es)
         achieved = alg / (kern_ms * 1e-3) / 1e9
-        traffic, traffic_source = None, None
+        traffic, traffic_source, traffic_live = None, None, None
+        pmc_why = "--no-pmc" if a.no_pmc else ("N > 1" if world != 1 else None)
+        if pmc_why is None:
+            traffic_live, pmc_why = live_traffic(a)               # behind every timed launch of this process
+        if traffic_live is not None:
+            traffic = traffic_live["hbm_bytes_per_launch"]
+            traffic_source = (f"measured in this run: two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over `bench.py --pmc-child` "
+                              f"({traffic_live['launches'][0]} + {traffic_live['launches'][1]} launches of {', '.join(traffic_live['kernels'])} on tensors of this shape, "
+                              f"{traffic_live['seconds']:.0f} s, after the timed region); FETCH_SIZE doubled (gfx950 counts a 128-byte request as 64 bytes), per-launch average")
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")  # written by tools/collect_pmc.py on the GPU box
-        if os.path.exists(pmc):
+        if traffic is None and os.path.exists(pmc):
             try:
                 rec = json.load(open(pmc))
                 if rec.get("io") == a.io and rec.get("shape") == [B, N, D]:
                     traffic = rec.get("hbm_bytes_per_launch")
                     traffic_source = ("profiles/pmc_latest.json: separate rocprofv3 --pmc passes of this command "
-                                      "(tools/collect_pmc.py), kernel " + str(rec.get("kernel", "?")) + "; not collected in this run")
+                                      "(tools/collect_pmc.py), kernel " + str(rec.get("kernel", "?")) + f"; not collected in this run ({pmc_why})")
             except Exception:
                 traffic = None
         res = {
@@ -372,6 +475,7 @@ def main():
                        "parallelism": f"batch-shard x{world} (no collective)", "kernel": kernel_timed, "kernel_before_first_launch": kernel},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "traffic_over_algorithmic": (traffic / alg if traffic else None),
                          "algorithmic_bytes_per_launch": alg, "kernel_ms": kern_ms},
             "prewarm_steps": max(0, a.prewarm),
             "launches_before_timed_region": launched,
