@@ -243,9 +243,25 @@ template <int SPLIT> constexpr int p64_younger_first() { return 4 * (8 - SPLIT) 
 //         A ticket whose tile this member did not get (claimed by a sweeper, or beyond the last tile) is a PHANTOM tile: the same
 //         instruction stream over empty buffer ranges, so that the gang stays in step.  Harness, same box, one process: -3.3 % with one
 //         counter per XCD (profiles/r05_p64v_ab_31_pair_tickets.log).
+#ifndef SPECTRE_P64_EARLY1
+#define SPECTRE_P64_EARLY1 1
+#endif
 template <int SPLIT, int PF, bool WITH_MEM = false, bool IN_BF16 = false, bool OUT_BF16 = false, bool BURST = false, bool SPREAD = false, int TICKETS = 0>
 __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileArgs a) {
   constexpr int ESI = IN_BF16 ? 2 : 4, ESO = OUT_BF16 ? 2 : 4;   // bytes per input / output element
+  // EARLY1 (round 5, last session): stage 1 of F1 for the DEFERRED groups of the next tile — their rows trade places with this tile's
+  // results inside the store burst — runs right behind the burst, in front of the reload / gate requests, instead of at the top of the
+  // next tile: arithmetic while the memory pipeline drains the stores.  Why it was tried: phase times of wave 0 (tools/p64v_phases.hip,
+  // profiles/r05_p64v_phases_shipped_forms.log) show the bf16 kernels bound by their own instruction stream (1.14 ms with 0.85 ms worth of
+  // traffic), and the burst, the request phases and the back edge are where a wave sits in the issue stage.  Same bits.  Harness, static map,
+  // three boxes: bf16 -> bf16 -2.2 ... -2.8 %, bf16 -> fp32 -1.9 ... -2.4 %, fp32 -0.2 ... -1.2 %; under the ticket order fp32 +1.4 ... +1.6 %.
+  // Through the library (tools/early1_ab.py, profiles/r05_early1_ab_library.log): bf16 -> bf16 static -1.1 %, tickets -0.4 %; bf16 -> fp32
+  // static -0.9 % but tickets +1.1 % (and the measured order IS tickets there).  So: bf16 -> bf16 only.
+  // SPECTRE_P64_EARLY1 (compile time, A/B through tools/build_variant.sh): bit 0 = bf16 -> bf16, bit 1 = fp32 rows static, bit 2 = fp32 rows
+  // tickets, bit 3 = bf16 -> fp32.
+  constexpr bool EARLY1 = BURST && SPREAD && !WITH_MEM && PF > 0 &&
+                          (IN_BF16 ? (OUT_BF16 ? (SPECTRE_P64_EARLY1 & 1) != 0 : (SPECTRE_P64_EARLY1 & 8) != 0)
+                                   : TICKETS ? (SPECTRE_P64_EARLY1 & 4) != 0 : (SPECTRE_P64_EARLY1 & 2) != 0);
   constexpr float inv_n = 1.0f / 4096.0f;
   constexpr int GROUP_SLOT = IN_BF16 ? 2 * 1024 : 4 * 1024;     // bytes of one row group in a wave's landing slots
   static_assert(SPLIT >= 1 && SPLIT <= 8 && SPLIT * GROUP_SLOT * 8 <= kP64ImageBytes, "staging lives in the exchange image");
@@ -605,9 +621,11 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
         else asm volatile("s_waitcnt vmcnt(%0) ; lint: steady" :: "n"(p64_younger<SPLIT, PF>()) : "memory");
         static_for<0, SPLIT>([&](auto gc) { read_group(gc); });
       }
-      swap_group(std::integral_constant<int, g>{});
-      bfly_plain<8, false, 8 * g, 1, 64>(z);       // over e -> ka at position 8g + ka (W_64^(g ka) is applied by the column butterflies below)
-      pin8<8 * g, 1>(z);
+      if (!EARLY1 || i >= PF || it == 0) {         // (EARLY1: done behind the previous tile's burst — except for the tile the prologue loaded)
+        swap_group(std::integral_constant<int, g>{});
+        bfly_plain<8, false, 8 * g, 1, 64>(z);     // over e -> ka at position 8g + ka (W_64^(g ka) is applied by the column butterflies below)
+        pin8<8 * g, 1>(z);
+      }
       __builtin_amdgcn_sched_barrier(0);
     });
     {
@@ -837,6 +855,17 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
           __builtin_amdgcn_sched_barrier(0);
         });
         p64_barrier();                                  // ... and the reloads start when every wave's stores are out
+        if constexpr (EARLY1) {
+          if (more) {                                   // the rows that have just traded places with the results: stage 1 of the next tile's F1
+            static_for<0, PF>([&](auto ic) {
+              constexpr int g = GP + decltype(ic)::value;
+              swap_group(std::integral_constant<int, g>{});
+              bfly_plain<8, false, 8 * g, 1, 64>(z);
+              pin8<8 * g, 1>(z);
+              __builtin_amdgcn_sched_barrier(0);
+            });
+          }
+        }
         static_for<SPLIT, GP>([&](auto gc) { load_group(rs_next, voff, v_sn, gc); });
         __builtin_amdgcn_sched_barrier(0);
       } else {

@@ -5,6 +5,9 @@
 //   MAPX   1 = compact window: tile = it * n_wg + wg (all workgroups in adjacent tiles at any time)
 //   SYNCP  the workgroups of a gang MEET once per tile through a device-scope counter (a.mem = counter buffer, one word per gang, zeroed before
 //          the launch): 1 = behind E2 (in front of the LDS-DMA burst and the stores of I2), 2 = at the end of F1 (in front of the deferred stores)
+//   EARLY1 (round 5) 1 = stage 1 of the DEFERRED groups of the next tile (their rows trade places with the results inside the store burst)
+//          right behind the burst, in front of the reload requests — arithmetic while the memory pipeline drains the stores — instead of at the
+//          top of the next tile; 2 = behind the reload requests (control: the same code motion without the drain)
 //   PRIO   0 none; 1 = s_setprio 1 for waves 4..7 (static); 2 = s_setprio 1 for waves 0..3; 3 = raised priority around the store / load bursts
 #pragma once
 #include "../fft_amd/csrc/kernel_regtile.h"
@@ -146,7 +149,7 @@ template <int SPLIT> constexpr int p64v_younger_first() { return 4 * (8 - SPLIT)
 //         right behind E2 of the previous one, none behind its stores (round 3: the fp32 kernel's late groups cost a memory latency
 //         per tile — same-box ablation: loads only 1.11 ms, stores only 0.90, neither 0.84).
 // OUT_BF16 = bf16 rows out (round to nearest even, like every other kernel here): a lane stores its 4 channels as 8 bytes.
-template <int SPLIT, int PF, bool WITH_MEM = false, bool IN_BF16 = false, bool OUT_BF16 = false, int GANGX = 0, int AUXD = 0, int AUXL = 0, int AUXS = 0, int PRIO = 0, int MAPX = 0, int DSPREAD = 0, int SYNCP = 0, int TSTAMP = 0, int PFL2 = 0, int STAG = 0, int PFSP = 0, int LATE = 0, int RLF = 0, int PARK = 0, int ESPREAD = 1>
+template <int SPLIT, int PF, bool WITH_MEM = false, bool IN_BF16 = false, bool OUT_BF16 = false, int GANGX = 0, int AUXD = 0, int AUXL = 0, int AUXS = 0, int PRIO = 0, int MAPX = 0, int DSPREAD = 0, int SYNCP = 0, int TSTAMP = 0, int PFL2 = 0, int STAG = 0, int PFSP = 0, int LATE = 0, int RLF = 0, int PARK = 0, int ESPREAD = 1, int EARLY1 = 0>
 __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) {
   constexpr int ESI = IN_BF16 ? 2 : 4, ESO = OUT_BF16 ? 2 : 4;   // bytes per input / output element
   constexpr float inv_n = 1.0f / 4096.0f;
@@ -534,9 +537,11 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
         __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr (i == PF + SPLIT && TSTAMP == 2) { vpin8<8 * ((PF + SPLIT - 1) < PF ? GP + PF + SPLIT - 1 : SPLIT - 1), 1>(z); mark(2); }   // staged groups read + stage 1
+      if (EARLY1 == 0 || i >= PF || it == 0) {      // (EARLY1: done at the end of the previous tile, except for the tile the prologue loaded)
       swap_group(std::integral_constant<int, g>{});
       bfly_plain<8, false, 8 * g, 1, 64>(z);       // over e -> ka at position 8g + ka (W_64^(g ka) is applied by the column butterflies below)
       vpin8<8 * g, 1>(z);
+      }
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (PFSP == 6 && i >= PF) { static_for<i * (4 * PF) / 16, (i + 1) * (4 * PF) / 16>([&](auto ic2) { pf_store(ic2); }); __builtin_amdgcn_sched_barrier(0); }
     });
@@ -931,8 +936,22 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
         mark(10);                                  // barrier behind the burst
         if constexpr (SYNCP == 15) __builtin_amdgcn_s_sleep(4);
         if constexpr (SYNCP == 16) __builtin_amdgcn_s_sleep(16);
+        if constexpr (EARLY1 == 1) { if (more) { static_for<0, PF>([&](auto ic) {
+            constexpr int g = GP + decltype(ic)::value;
+            swap_group(std::integral_constant<int, g>{});
+            bfly_plain<8, false, 8 * g, 1, 64>(z);
+            vpin8<8 * g, 1>(z);
+            __builtin_amdgcn_sched_barrier(0);
+          }); } }
         if constexpr (RLF == 0) static_for<SPLIT + (PARK != 0 ? 1 : 0), GP - LATE>([&](auto gc) { load_group(rs_next, voff, v_sn, gc); });
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (EARLY1 == 2) { if (more) { static_for<0, PF>([&](auto ic) {
+            constexpr int g = GP + decltype(ic)::value;
+            swap_group(std::integral_constant<int, g>{});
+            bfly_plain<8, false, 8 * g, 1, 64>(z);
+            vpin8<8 * g, 1>(z);
+            __builtin_amdgcn_sched_barrier(0);
+          }); } }
       } else {
       if constexpr (SYNCP == 8) p64v_barrier();
       static_for<0, 8>([&](auto ic) {
