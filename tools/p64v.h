@@ -8,6 +8,9 @@
 //   EARLY1 (round 5) 1 = stage 1 of the DEFERRED groups of the next tile (their rows trade places with the results inside the store burst)
 //          right behind the burst, in front of the reload requests — arithmetic while the memory pipeline drains the stores — instead of at the
 //          top of the next tile; 2 = behind the reload requests (control: the same code motion without the drain)
+//   SKEW   (round 5) wave w idles w * SKEW x `s_nop 7` at the start of the three phases that carry spread requests (behind the burst,
+//          in front of the middle phase, in front of I2): the eight waves reach every request slot at the same clock and meet at the CU's one
+//          memory path (16 clocks per 1-KiB request) — does a stagger of the whole instruction streams pay for itself?
 //   PRIO   0 none; 1 = s_setprio 1 for waves 4..7 (static); 2 = s_setprio 1 for waves 0..3; 3 = raised priority around the store / load bursts
 #pragma once
 #include "../fft_amd/csrc/kernel_regtile.h"
@@ -149,7 +152,7 @@ template <int SPLIT> constexpr int p64v_younger_first() { return 4 * (8 - SPLIT)
 //         right behind E2 of the previous one, none behind its stores (round 3: the fp32 kernel's late groups cost a memory latency
 //         per tile — same-box ablation: loads only 1.11 ms, stores only 0.90, neither 0.84).
 // OUT_BF16 = bf16 rows out (round to nearest even, like every other kernel here): a lane stores its 4 channels as 8 bytes.
-template <int SPLIT, int PF, bool WITH_MEM = false, bool IN_BF16 = false, bool OUT_BF16 = false, int GANGX = 0, int AUXD = 0, int AUXL = 0, int AUXS = 0, int PRIO = 0, int MAPX = 0, int DSPREAD = 0, int SYNCP = 0, int TSTAMP = 0, int PFL2 = 0, int STAG = 0, int PFSP = 0, int LATE = 0, int RLF = 0, int PARK = 0, int ESPREAD = 1, int EARLY1 = 0>
+template <int SPLIT, int PF, bool WITH_MEM = false, bool IN_BF16 = false, bool OUT_BF16 = false, int GANGX = 0, int AUXD = 0, int AUXL = 0, int AUXS = 0, int PRIO = 0, int MAPX = 0, int DSPREAD = 0, int SYNCP = 0, int TSTAMP = 0, int PFL2 = 0, int STAG = 0, int PFSP = 0, int LATE = 0, int RLF = 0, int PARK = 0, int ESPREAD = 1, int EARLY1 = 0, int SKEW = 0>
 __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) {
   constexpr int ESI = IN_BF16 ? 2 : 4, ESO = OUT_BF16 ? 2 : 4;   // bytes per input / output element
   constexpr float inv_n = 1.0f / 4096.0f;
@@ -190,6 +193,13 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
     slot = smem + __builtin_amdgcn_readfirstlane(t >> 6) * (SPLIT * GROUP_SLOT);   // this wave's landing slots
   };
   coords();
+  [[maybe_unused]] auto wskew = [&]() {
+    if constexpr (SKEW > 0) {
+      const int n = __builtin_amdgcn_readfirstlane(tid0 >> 6) * SKEW;
+      for (int i = 0; i < n; ++i) asm volatile("s_nop 7");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
   if constexpr (PRIO == 1) { if (__builtin_amdgcn_readfirstlane(tid0 >> 6) >= 4) __builtin_amdgcn_s_setprio(1); }
   if constexpr (PRIO == 2) { if (__builtin_amdgcn_readfirstlane(tid0 >> 6) < 4) __builtin_amdgcn_s_setprio(1); }
 
@@ -655,6 +665,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
     // ---- middle: F2 -> gate -> I1 (kernel_regtile.h; bin of register (ka, kb): k = k1 + 64 k2, k2 = ka + 8 kb) -------------
     {
       const int k1 = u;
+      wskew();
       p64v_stageA1<false>(z);
       auto fetch_gate = [&](int k2, bool upper) -> float2 {
         float2 g = glds[upper ? 64 * (64 - k2) - k1 : k1 + 64 * k2];      // scaled by 1/N, edges fixed, conj applied
@@ -773,6 +784,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
                                                  voff + (uint32_t)((64 * g + 1024 * m) * v_sn * 4), 0, 0, AUXD);
       }
     };
+    wskew();
     constexpr int NDMA = (IN_BF16 ? 2 : 4) * SPLIT, NSLOT = DSPREAD == 3 ? 24 : DSPREAD == 2 ? 16 : 8;   // (3: ... and over the eight groups of I2's last stage)
     if constexpr (PFL2 == 1) static_for<SPLIT, GP>([&](auto gc) { l2_touch(gc); });
     if constexpr (PFL2 == 2) static_for<SPLIT, GP>([&](auto gc) { const uint32_t t = tch[decltype(gc)::value]; asm volatile("" :: "v"(t)); });
@@ -934,6 +946,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
         mark(9);                                   // store issue (+ the wait for the prefetched rows that trade places)
         if constexpr (SYNCP >= 11) p64v_barrier();
         mark(10);                                  // barrier behind the burst
+        wskew();
         if constexpr (SYNCP == 15) __builtin_amdgcn_s_sleep(4);
         if constexpr (SYNCP == 16) __builtin_amdgcn_s_sleep(16);
         if constexpr (EARLY1 == 1) { if (more) { static_for<0, PF>([&](auto ic) {

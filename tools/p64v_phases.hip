@@ -102,6 +102,11 @@ int main(int argc, char** argv) {
       auto k0 = spectre_mix_p64v<3, 3, false, false, false, 2, 0, 0, 0, 0, 0, 3, 12, 0, 0, 0, 4>;
       auto k2 = spectre_mix_p64v<3, 3, false, false, false, 2, 0, 0, 0, 0, 0, 3, 12, 2, 0, 0, 4>;
       snprintf(nm, sizeof nm, "f32 (3,3) shipped, tpw %d", tpw); add(nm, mkt(k0, la, 2, tpw));
+      if (tpw == 48) {
+        add("f32 (3,3) SKEW 1", mkt(spectre_mix_p64v<3, 3, false, false, false, 2, 0, 0, 0, 0, 0, 3, 12, 0, 0, 0, 4, 0, 0, 0, 1, 0, 1>, la, 2, tpw));
+        add("f32 (3,3) SKEW 2", mkt(spectre_mix_p64v<3, 3, false, false, false, 2, 0, 0, 0, 0, 0, 3, 12, 0, 0, 0, 4, 0, 0, 0, 1, 0, 2>, la, 2, tpw));
+        add("f32 (3,3) SKEW 4", mkt(spectre_mix_p64v<3, 3, false, false, false, 2, 0, 0, 0, 0, 0, 3, 12, 0, 0, 0, 4, 0, 0, 0, 1, 0, 4>, la, 2, tpw));
+      }
       snprintf(nm, sizeof nm, "f32 (3,3) EARLY1 = 1, tpw %d", tpw); add(nm, mkt(spectre_mix_p64v<3, 3, false, false, false, 2, 0, 0, 0, 0, 0, 3, 12, 0, 0, 0, 4, 0, 0, 0, 1, 1>, la, 2, tpw));
       snprintf(nm, sizeof nm, "f32 (3,3) EARLY1 = 2 (control), tpw %d", tpw); add(nm, mkt(spectre_mix_p64v<3, 3, false, false, false, 2, 0, 0, 0, 0, 0, 3, 12, 0, 0, 0, 4, 0, 0, 0, 1, 2>, la, 2, tpw));
       { RegtileArgs x = ls; snprintf(nm, sizeof nm, "TSTAMP PHASES f32 (3,3) EARLY1 = 1 tpw %d", tpw); add(nm, synced(mkt(spectre_mix_p64v<3, 3, false, false, false, 2, 0, 0, 0, 0, 0, 3, 12, 2, 0, 0, 4, 0, 0, 0, 1, 1>, x, 2, tpw))); }
@@ -124,6 +129,12 @@ int main(int argc, char** argv) {
       auto k0 = spectre_mix_p64v<5, 3, false, true, true, 4, 0, 0, 0, 0, 0, 3, 12, 0, 0, 0, 2>;
       auto k2 = spectre_mix_p64v<5, 3, false, true, true, 4, 0, 0, 0, 0, 0, 3, 12, 2, 0, 0, 2>;
       snprintf(nm, sizeof nm, "bf16->bf16 (5,3) shipped, tpw %d", tpw); add(nm, mkt(k0, lb, 4, tpw));
+      if (tpw == 48) {
+        add("bf16->bf16 (5,3) SKEW 1", mkt(spectre_mix_p64v<5, 3, false, true, true, 4, 0, 0, 0, 0, 0, 3, 12, 0, 0, 0, 2, 0, 0, 0, 1, 0, 1>, lb, 4, tpw));
+        add("bf16->bf16 (5,3) SKEW 2", mkt(spectre_mix_p64v<5, 3, false, true, true, 4, 0, 0, 0, 0, 0, 3, 12, 0, 0, 0, 2, 0, 0, 0, 1, 0, 2>, lb, 4, tpw));
+        add("bf16->bf16 (5,3) SKEW 4", mkt(spectre_mix_p64v<5, 3, false, true, true, 4, 0, 0, 0, 0, 0, 3, 12, 0, 0, 0, 2, 0, 0, 0, 1, 0, 4>, lb, 4, tpw));
+        add("bf16->bf16 (5,3) EARLY1 + SKEW 2", mkt(spectre_mix_p64v<5, 3, false, true, true, 4, 0, 0, 0, 0, 0, 3, 12, 0, 0, 0, 2, 0, 0, 0, 1, 1, 2>, lb, 4, tpw));
+      }
       snprintf(nm, sizeof nm, "bf16->bf16 (5,3) EARLY1 = 1, tpw %d", tpw); add(nm, mkt(spectre_mix_p64v<5, 3, false, true, true, 4, 0, 0, 0, 0, 0, 3, 12, 0, 0, 0, 2, 0, 0, 0, 1, 1>, lb, 4, tpw));
       { RegtileArgs x = lb; x.mem = reinterpret_cast<const float*>(cnt_buf); snprintf(nm, sizeof nm, "TSTAMP PHASES bf16->bf16 (5,3) EARLY1 = 1 tpw %d", tpw); add(nm, synced(mkt(spectre_mix_p64v<5, 3, false, true, true, 4, 0, 0, 0, 0, 0, 3, 12, 2, 0, 0, 2, 0, 0, 0, 1, 1>, x, 4, tpw))); }
       for (int m = 0; m < 4; ++m) {
