@@ -22,6 +22,10 @@
 #include "kernel_regtile.h"
 #include <cstdlib>
 
+#ifndef SPECTRE_WIDE_MAP
+#define SPECTRE_WIDE_MAP 0
+#endif
+
 namespace sfft {
 
 typedef float wide_f32x2 __attribute__((ext_vector_type(2)));
@@ -56,7 +60,13 @@ spectre_mix_regtile_wide(const RegtileArgs a) {
   const int p = lane & (kPCW - 1);
   const int u = (lane / kPCW) + (64 / kPCW) * wave;   // team index: n2 in F1/I2, k1 mod RS in F2/I1
 
-  const int tile = xcd_contiguous(blockIdx.x, a.n_wg);
+  // tile of this workgroup.  The hardware hands workgroups to the XCDs round-robin in blockIdx order; nobody shares a line here, so any map is
+  // correct.  SPECTRE_WIDE_MAP (compile time, A/B through tools/build_variant.sh): 0 = XCD-contiguous (every XCD walks through its own eighth
+  // of the tensor), 1 = blockIdx order (the whole chip inside one window of ~21 batch elements, in address order), 2 = batch-major
+  // (consecutive workgroups in different batch elements).
+  const int tile = SPECTRE_WIDE_MAP == 1 ? (int)blockIdx.x
+                 : SPECTRE_WIDE_MAP == 2 ? (int)((blockIdx.x % (unsigned)a.B) * a.tiles_per_row + blockIdx.x / (unsigned)a.B)
+                                         : xcd_contiguous(blockIdx.x, a.n_wg);
   if (tile >= a.n_tiles) return;
   const long long v_sn = a.v_sn, out_sn = a.out_sn;
   const int b = tile / a.tiles_per_row;
