@@ -244,7 +244,7 @@ template <int SPLIT> constexpr int p64_younger_first() { return 4 * (8 - SPLIT) 
 //         instruction stream over empty buffer ranges, so that the gang stays in step.  Harness, same box, one process: -3.3 % with one
 //         counter per XCD (profiles/r05_p64v_ab_31_pair_tickets.log).
 #ifndef SPECTRE_P64_EARLY1
-#define SPECTRE_P64_EARLY1 1
+#define SPECTRE_P64_EARLY1 11
 #endif
 template <int SPLIT, int PF, bool WITH_MEM = false, bool IN_BF16 = false, bool OUT_BF16 = false, bool BURST = false, bool SPREAD = false, int TICKETS = 0>
 __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileArgs a) {
@@ -256,11 +256,13 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_regtile64p(const RegtileAr
   // traffic), and the burst, the request phases and the back edge are where a wave sits in the issue stage.  Same bits.  Harness, static map,
   // three boxes: bf16 -> bf16 -2.2 ... -2.8 %, bf16 -> fp32 -1.9 ... -2.4 %, fp32 -0.2 ... -1.2 %; under the ticket order fp32 +1.4 ... +1.6 %.
   // Through the library (tools/early1_ab.py, profiles/r05_early1_ab_library.log): bf16 -> bf16 static -1.1 %, tickets -0.4 %; bf16 -> fp32
-  // static -0.9 % but tickets +1.1 % (and the measured order IS tickets there).  So: bf16 -> bf16 only.
-  // SPECTRE_P64_EARLY1 (compile time, A/B through tools/build_variant.sh): bit 0 = bf16 -> bf16, bit 1 = fp32 rows static, bit 2 = fp32 rows
-  // tickets, bit 3 = bf16 -> fp32.
+  // static -0.9 % but tickets +1.1 %.  So: bf16 -> bf16 in both orders, fp32 rows out only on the static map.
+  // SPECTRE_P64_EARLY1 (compile time, A/B through tools/build_variant.sh): bit 0 = bf16 -> bf16 (both orders), bit 1 = fp32 rows on the static
+  // map, bit 2 = fp32 rows on tickets, bit 3 = bf16 -> fp32 on the static map, bit 4 = bf16 -> fp32 on tickets.  Default 11: the static forms
+  // take it (whichever order measures faster on a tensor pair still wins, choose_tile_order in spectre_hip.hip), the ticket forms with fp32
+  // rows out do not.
   constexpr bool EARLY1 = BURST && SPREAD && !WITH_MEM && PF > 0 &&
-                          (IN_BF16 ? (OUT_BF16 ? (SPECTRE_P64_EARLY1 & 1) != 0 : (SPECTRE_P64_EARLY1 & 8) != 0)
+                          (IN_BF16 ? (OUT_BF16 ? (SPECTRE_P64_EARLY1 & 1) != 0 : TICKETS ? (SPECTRE_P64_EARLY1 & 16) != 0 : (SPECTRE_P64_EARLY1 & 8) != 0)
                                    : TICKETS ? (SPECTRE_P64_EARLY1 & 4) != 0 : (SPECTRE_P64_EARLY1 & 2) != 0);
   constexpr float inv_n = 1.0f / 4096.0f;
   constexpr int GROUP_SLOT = IN_BF16 ? 2 * 1024 : 4 * 1024;     // bytes of one row group in a wave's landing slots

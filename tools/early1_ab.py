@@ -1,6 +1,7 @@
-"""bf16 rows at n_fft = 4096: stage 1 of the deferred groups behind the store burst (SPECTRE_P64_EARLY1 = 1, shipped) against the previous
-form (fft_amd/lib/libspectre_hip_e0.so = tools/build_variant.sh e0 regtile_n4096p.hip -DSPECTRE_P64_EARLY1=0), through the LIBRARY, one
-process each, interleaved; per process three (V, out) pairs, tile order pinned (static / tickets) or measured (auto)."""
+"""n_fft = 4096: stage 1 of the deferred groups behind the store burst (SPECTRE_P64_EARLY1, kernel_regtile64p.h) — the shipped mask against
+another one (SPECTRE_EARLY1_OLD_LIB, default fft_amd/lib/libspectre_hip_e0.so = tools/build_variant.sh e0 regtile_n4096p.hip
+-DSPECTRE_P64_EARLY1=0), through the LIBRARY, one process each, interleaved; per process three (V, out) pairs, tile order pinned (static /
+tickets) or measured (auto).    python tools/early1_ab.py [bf16out bf16 f32]"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
@@ -11,8 +12,9 @@ from fft_amd import time_kernel, spectral_mix, describe
 dev = "cuda:0"
 B, N, D = 256, 4096, 768
 odt = torch.bfloat16 if sys.argv[1] == "bf16out" else torch.float32
+idt = torch.float32 if sys.argv[1] == "f32" else torch.bfloat16
 torch.manual_seed(0)
-V = torch.randn(B, N, D, device=dev).to(torch.bfloat16); g = torch.randn(B, 4, N // 2 + 1, dtype=torch.complex64, device=dev) * 0.3
+V = torch.randn(B, N, D, device=dev).to(idt); g = torch.randn(B, 4, N // 2 + 1, dtype=torch.complex64, device=dev) * 0.3
 res = []
 for k in range(3):
     Vv = V.clone(); out = torch.empty(B, N, D, device=dev, dtype=odt)
@@ -23,11 +25,11 @@ for k in range(3):
 import hashlib
 print("MS " + "  ".join(res) + "  sha " + hashlib.sha1(out.view(torch.int16 if odt == torch.bfloat16 else torch.int32).cpu().numpy().tobytes()).hexdigest()[:10] + "  " + describe(Vv, g, None, N, out=out)[-60:])
 ''' % ROOT
-old = os.path.join(ROOT, "fft_amd", "lib", "libspectre_hip_e0.so")
-for io in ("bf16out", "bf16"):
+old = os.environ.get("SPECTRE_EARLY1_OLD_LIB") or os.path.join(ROOT, "fft_amd", "lib", "libspectre_hip_e0.so")
+for io in (sys.argv[1:] or ["bf16out", "bf16"]):
     for order in ("static", "tickets", None):
         for r in range(2):
-            for name, env in (("early1", {}), ("before", {"SPECTRE_HIP_LIB": old})):
+            for name, env in (("shipped", {}), ("other", {"SPECTRE_HIP_LIB": old})):
                 e = dict(os.environ, **env)
                 if order: e.update(SPECTRE_TUNING="1", SPECTRE_TILE_ORDER=order)
                 out = subprocess.run([sys.executable, "-c", CHILD, io], env=e, capture_output=True, text=True)
