@@ -147,7 +147,7 @@ __device__ __forceinline__ void bfly(float2 (&z)[NTOT]) {
 // butterfly that follows becomes a +- rho * b with rho = the ratio of the two operands' pending scales, a compile-time constant, i.e. the
 // same number of instructions as the plain additions.  The first input of every such butterfly has m = 0, so the result carries no
 // scale.  The (1 +- i) / sqrt 2 inside a radix-8 butterfly is treated the same way (two additions, 1 / sqrt 2 pending).
-// A 64-point transform: 768 additions + 160 other instructions instead of 768 + ~290 (profiles/r03_isa_census.txt).
+// A 64-point transform: 768 additions + 160 other instructions instead of 768 + ~290 (profiles/r05_isa_census.txt: tools/isa_census.py).
 template <int M, bool INV>
 struct TwSplit {
   static constexpr int m = INV ? ((64 - (((M % 64) + 64) % 64)) % 64) : (((M % 64) + 64) % 64);   // conj(W^M) = W^(64 - M)

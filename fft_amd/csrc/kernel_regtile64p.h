@@ -26,7 +26,7 @@
 //    b128 read groups distinct: SQ_LDS_BANK_CONFLICT = 0);
 //  * (round 3) the exchanges move one float plane at a time through the 136-KiB image: write re | barrier | read re | barrier |
 //    write im | barrier | read im.  The LDS accepts ~80 B/clk of scattered writes, so the two write phases are ~1700 cycles each during
-//    which no wave computes (per-wave s_memtime stamps, profiles/r03_p64x_timeline.log).  The REAL plane is now written by the producer,
+//    which no wave computes (per-wave s_memtime stamps, profiles/r03_p64x_timeline_loads_stores.log).  The REAL plane is now written by the producer,
 //    column by column, while it computes the next column (the last butterfly stage of F1 / of the middle phase yields 8 finished
 //    positions at a time), and the barrier that frees the image sits in front of that stage instead of behind the previous read:
 //    1.62 -> 1.45 ms on one box;
