@@ -120,6 +120,11 @@ int main(int argc, char** argv) {
           CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
           return synced_uc(std::function<void()>([=] { hipLaunchKernelGGL(kern, dim3(a2.n_wg), dim3(512), lds, 0, a2); })); };
         add("f32 (3,3) shipped, pair tickets", mku(spectre_mix_p64v<3, 3, false, false, false, 2, 0, 0, 0, 0, 5, 3, 12, 0, 0, 0, 4>));
+        // the phased I/O (round 4: barriers around the store burst, -4 ... -6 % on the static map) under the TICKET order: still worth its barriers?
+        add("f32 (3,3) pair tickets, SYNCP 0 (stores interleaved with the reloads)", mku(spectre_mix_p64v<3, 3, false, false, false, 2, 0, 0, 0, 0, 5, 3, 0, 0, 0, 0, 4>));
+        add("f32 (3,3) pair tickets, SYNCP 4 (burst, no barrier)", mku(spectre_mix_p64v<3, 3, false, false, false, 2, 0, 0, 0, 0, 5, 3, 4, 0, 0, 0, 4>));
+        add("f32 (3,3) pair tickets, SYNCP 9 (barrier in front of the burst)", mku(spectre_mix_p64v<3, 3, false, false, false, 2, 0, 0, 0, 0, 5, 3, 9, 0, 0, 0, 4>));
+        add("f32 (3,3) pair tickets, SYNCP 11 (barriers around the burst)", mku(spectre_mix_p64v<3, 3, false, false, false, 2, 0, 0, 0, 0, 5, 3, 11, 0, 0, 0, 4>));
         add("f32 (3,3) EARLY1 = 1, pair tickets", mku(spectre_mix_p64v<3, 3, false, false, false, 2, 0, 0, 0, 0, 5, 3, 12, 0, 0, 0, 4, 0, 0, 0, 1, 1>));
       }
     } else if (!bfo) {
