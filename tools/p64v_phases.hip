@@ -125,6 +125,13 @@ int main(int argc, char** argv) {
         add("f32 (3,3) pair tickets, SYNCP 4 (burst, no barrier)", mku(spectre_mix_p64v<3, 3, false, false, false, 2, 0, 0, 0, 0, 5, 3, 4, 0, 0, 0, 4>));
         add("f32 (3,3) pair tickets, SYNCP 9 (barrier in front of the burst)", mku(spectre_mix_p64v<3, 3, false, false, false, 2, 0, 0, 0, 0, 5, 3, 9, 0, 0, 0, 4>));
         add("f32 (3,3) pair tickets, SYNCP 11 (barriers around the burst)", mku(spectre_mix_p64v<3, 3, false, false, false, 2, 0, 0, 0, 0, 5, 3, 11, 0, 0, 0, 4>));
+        // where the spread requests sit, re-measured under the ticket order (round 4 chose DSPREAD = 3, PFSP = 4 on the static map)
+        add("f32 (3,3) pair tickets, DSPREAD 2", mku(spectre_mix_p64v<3, 3, false, false, false, 2, 0, 0, 0, 0, 5, 2, 12, 0, 0, 0, 4>));
+        add("f32 (3,3) pair tickets, DSPREAD 1", mku(spectre_mix_p64v<3, 3, false, false, false, 2, 0, 0, 0, 0, 5, 1, 12, 0, 0, 0, 4>));
+        add("f32 (3,3) pair tickets, PFSP 1", mku(spectre_mix_p64v<3, 3, false, false, false, 2, 0, 0, 0, 0, 5, 3, 12, 0, 0, 0, 1>));
+        add("f32 (3,3) pair tickets, PFSP 5", mku(spectre_mix_p64v<3, 3, false, false, false, 2, 0, 0, 0, 0, 5, 3, 12, 0, 0, 0, 5>));
+        add("f32 (3,3) pair tickets, PFSP 8", mku(spectre_mix_p64v<3, 3, false, false, false, 2, 0, 0, 0, 0, 5, 3, 12, 0, 0, 0, 8>));
+        add("f32 (3,3) pair tickets, PFSP 11", mku(spectre_mix_p64v<3, 3, false, false, false, 2, 0, 0, 0, 0, 5, 3, 12, 0, 0, 0, 11>));
         add("f32 (3,3) EARLY1 = 1, pair tickets", mku(spectre_mix_p64v<3, 3, false, false, false, 2, 0, 0, 0, 0, 5, 3, 12, 0, 0, 0, 4, 0, 0, 0, 1, 1>));
       }
     } else if (!bfo) {
