@@ -1,0 +1,59 @@
+"""BASELINE.json's full sizes against the float64 ORACLE, one column of EVERY tile of the launch.
+
+The property tests of test_parity_gpu.py hold for any linear shift-equivariant map and spot-check 15 columns; the whole-tensor test of
+test_fullsize_crosscheck_gpu.py compares two kernels of this repo with each other.  Here the persistent kernels at the benchmark shapes —
+48 tiles per workgroup, measured tile order (static map or tickets), deferred / staged / reloaded row groups, the stage-1 hoist of the bf16
+kernels — meet the oracle itself where it is affordable: for every (batch element, 16-channel column tile) one channel drawn at random, all
+n_fft rows of it, against oracle.spectral_mix_numpy (float64 DFT of spectre.py:506, :542-553).  12 288 columns = 50 M output points per case.
+Tolerance: SURVEY.md §8(c), |y - e| <= 1e-4 |e| + 1e-4 RMS(e) (fp32 rows out); bf16 rows out: one bf16 ulp of the oracle on top."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.spectral_mix_oracle import assert_close, spectral_mix_numpy
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+CASES = [(256, 4096, 768, 4, torch.float32, "regtile-pipelined 64x64"), (256, 4096, 768, 4, torch.bfloat16, "regtile-pipelined 64x64 in=bf16 out=bf16"),
+         (256, 3000, 768, 4, torch.float32, "regtile-mixed-pipelined 60x50"), (256, 1024, 768, 4, torch.float32, "regtile-wide 32x32")]
+
+
+@pytest.mark.parametrize("B,N,D,G,dt,kernel", CASES, ids=["C2_f32", "C2_bf16_bf16", "C4_n3000", "C1_n1024"])
+def test_one_column_of_every_tile_against_the_float64_oracle(B, N, D, G, dt, kernel):
+    from fft_amd import describe, spectral_mix
+    g = torch.Generator(device=DEV).manual_seed(4242 + N)
+    F = N // 2 + 1
+    V = torch.randn(B, N, D, device=DEV, generator=g).to(dt)
+    gate = torch.randn(B, G, F, dtype=torch.complex64, device=DEV, generator=g) * 0.3
+    gate = gate * (torch.rand(B, G, F, device=DEV, generator=g) >= 0.18)           # exact zeros (modReLU)
+    out = torch.empty_like(V)
+    assert describe(V, gate, None, N, out=out).startswith(kernel)
+    for _ in range(45):                               # past the tile-order measurement: the launch that is checked runs the order that stays
+        spectral_mix(V, gate, None, N, out=out)
+    out.fill_(float("nan"))
+    spectral_mix(V, gate, None, N, out=out)
+    torch.cuda.synchronize()
+    tiles = D // 16
+    rng = np.random.default_rng(N)
+    ch = 16 * np.arange(tiles)[None, :] + rng.integers(0, 16, size=(B, tiles))      # (B, tiles): one channel per tile
+    bi = torch.arange(B, device=DEV)[:, None].expand(B, tiles)
+    ci = torch.from_numpy(ch).to(DEV)
+    y = out[bi, :, ci].float().cpu().numpy()                                         # (B, tiles, N)
+    v = V[bi, :, ci].float().cpu().numpy()
+    gh = gate.cpu().numpy()
+    d_g = D // G
+    worst = 0.0
+    for b in range(B):
+        for grp in range(G):
+            sel = np.nonzero(ch[b] // d_g == grp)[0]
+            ref = spectral_mix_numpy(np.ascontiguousarray(v[b, sel].T[None]), gh[b:b + 1, grp:grp + 1], None, N)[0].T       # (len(sel), N)
+            got = y[b, sel]
+            if dt == torch.bfloat16:
+                rms = float(np.sqrt(np.mean(ref * ref)))
+                tol = (1e-4 + 2.0 ** -8) * np.abs(ref) + 1e-4 * rms
+                err = np.abs(got - ref)
+                assert np.isfinite(got).all() and (err <= tol).all(), f"batch {b} group {grp}: {int((err > tol).sum())} elements beyond one bf16 ulp of the oracle"
+            else:
+                worst = max(worst, assert_close(got, ref, what=f"batch {b} group {grp}"))
+    assert bool(torch.isfinite(out.float()).all())    # and nothing left untouched anywhere
