@@ -15,19 +15,27 @@ from oracle.spectral_mix_oracle import assert_close, spectral_mix_numpy
 pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda:0")
 
-CASES = [(256, 4096, 768, 4, torch.float32, "regtile-pipelined 64x64"), (256, 4096, 768, 4, torch.bfloat16, "regtile-pipelined 64x64 in=bf16 out=bf16"),
-         (256, 3000, 768, 4, torch.float32, "regtile-mixed-pipelined 60x50"), (256, 1024, 768, 4, torch.float32, "regtile-wide 32x32")]
+#        B, N_in, n_fft, D, G, rows in, rows out, kernel the launch must take
+CASES = [(256, 4096, 4096, 768, 4, torch.float32, torch.float32, "regtile-pipelined 64x64"),
+         (256, 4096, 4096, 768, 4, torch.bfloat16, torch.bfloat16, "regtile-pipelined 64x64 in=bf16 out=bf16"),
+         (256, 4096, 4096, 768, 4, torch.bfloat16, torch.float32, "regtile-pipelined 64x64 in=bf16 out=f32"),      # BASELINE configs[2] read literally
+         (256, 3000, 3000, 768, 4, torch.float32, torch.float32, "regtile-mixed-pipelined 60x50"),
+         (256, 1024, 1024, 768, 4, torch.float32, torch.float32, "regtile-wide 32x32"),
+         (192, 3000, 4096, 768, 4, torch.float32, torch.float32, "regtile-pipelined 64x64"),     # zero-padded to n_fft (spectre.py:506), first N rows kept (:553)
+         (128, 5000, 4096, 768, 4, torch.float32, torch.float32, "regtile-pipelined 64x64")]     # truncated to n_fft
+IDS = ["C2_f32", "C2_bf16_bf16", "C2_bf16_f32", "C4_n3000", "C1_n1024", "padded_3000_of_4096", "truncated_5000_to_4096"]
 
 
-@pytest.mark.parametrize("B,N,D,G,dt,kernel", CASES, ids=["C2_f32", "C2_bf16_bf16", "C4_n3000", "C1_n1024"])
-def test_one_column_of_every_tile_against_the_float64_oracle(B, N, D, G, dt, kernel):
+@pytest.mark.parametrize("B,N_in,N,D,G,dt,odt,kernel", CASES, ids=IDS)
+def test_one_column_of_every_tile_against_the_float64_oracle(B, N_in, N, D, G, dt, odt, kernel):
     from fft_amd import describe, spectral_mix
     g = torch.Generator(device=DEV).manual_seed(4242 + N)
     F = N // 2 + 1
-    V = torch.randn(B, N, D, device=DEV, generator=g).to(dt)
+    V = torch.randn(B, N_in, D, device=DEV, generator=g).to(dt)
     gate = torch.randn(B, G, F, dtype=torch.complex64, device=DEV, generator=g) * 0.3
     gate = gate * (torch.rand(B, G, F, device=DEV, generator=g) >= 0.18)           # exact zeros (modReLU)
-    out = torch.empty_like(V)
+    n_out = min(N_in, N)
+    out = torch.empty(B, n_out, D, device=DEV, dtype=odt)
     assert describe(V, gate, None, N, out=out).startswith(kernel)
     for _ in range(45):                               # past the tile-order measurement: the launch that is checked runs the order that stays
         spectral_mix(V, gate, None, N, out=out)
@@ -39,7 +47,7 @@ def test_one_column_of_every_tile_against_the_float64_oracle(B, N, D, G, dt, ker
     ch = 16 * np.arange(tiles)[None, :] + rng.integers(0, 16, size=(B, tiles))      # (B, tiles): one channel per tile
     bi = torch.arange(B, device=DEV)[:, None].expand(B, tiles)
     ci = torch.from_numpy(ch).to(DEV)
-    y = out[bi, :, ci].float().cpu().numpy()                                         # (B, tiles, N)
+    y = out[bi, :, ci].float().cpu().numpy()                                         # (B, tiles, rows out)
     v = V[bi, :, ci].float().cpu().numpy()
     gh = gate.cpu().numpy()
     d_g = D // G
@@ -49,7 +57,7 @@ def test_one_column_of_every_tile_against_the_float64_oracle(B, N, D, G, dt, ker
             sel = np.nonzero(ch[b] // d_g == grp)[0]
             ref = spectral_mix_numpy(np.ascontiguousarray(v[b, sel].T[None]), gh[b:b + 1, grp:grp + 1], None, N)[0].T       # (len(sel), N)
             got = y[b, sel]
-            if dt == torch.bfloat16:
+            if odt == torch.bfloat16:
                 rms = float(np.sqrt(np.mean(ref * ref)))
                 tol = (1e-4 + 2.0 ** -8) * np.abs(ref) + 1e-4 * rms
                 err = np.abs(got - ref)
