@@ -65,3 +65,60 @@ def test_one_column_of_every_tile_against_the_float64_oracle(B, N_in, N, D, G, d
             else:
                 worst = max(worst, assert_close(got, ref, what=f"batch {b} group {grp}"))
     assert bool(torch.isfinite(out.float()).all())    # and nothing left untouched anywhere
+
+
+def test_memory_fft_at_full_size_one_column_of_every_tile():
+    """(256, 4096, 768) fp32 + memory_fft (spectre.py:548-549): the <4, 1, true, ...> instantiation, 48 tiles per workgroup."""
+    from fft_amd import describe, spectral_mix
+    B, N, D, G = 256, 4096, 768, 4
+    g = torch.Generator(device=DEV).manual_seed(99)
+    F = N // 2 + 1
+    V = torch.randn(B, N, D, device=DEV, generator=g)
+    gate = torch.randn(B, G, F, dtype=torch.complex64, device=DEV, generator=g) * 0.3
+    gate = gate * (torch.rand(B, G, F, device=DEV, generator=g) >= 0.18)
+    mem = torch.randn(F, D, dtype=torch.complex64, device=DEV, generator=g) * 0.2
+    out = torch.full((B, N, D), float("nan"), device=DEV)
+    assert describe(V, gate, mem, N, out=out).startswith("regtile-pipelined 64x64")
+    spectral_mix(V, gate, mem, N, out=out)
+    torch.cuda.synchronize()
+    tiles, d_g = D // 16, D // G
+    rng = np.random.default_rng(7)
+    ch = 16 * np.arange(tiles)[None, :] + rng.integers(0, 16, size=(B, tiles))
+    bi = torch.arange(B, device=DEV)[:, None].expand(B, tiles)
+    ci = torch.from_numpy(ch).to(DEV)
+    y = out[bi, :, ci].cpu().numpy()
+    v = V[bi, :, ci].cpu().numpy()
+    gh, mh = gate.cpu().numpy(), mem.cpu().numpy()
+    for b in range(B):
+        for grp in range(G):
+            sel = np.nonzero(ch[b] // d_g == grp)[0]
+            ref = spectral_mix_numpy(np.ascontiguousarray(v[b, sel].T[None]), gh[b:b + 1, grp:grp + 1], np.ascontiguousarray(mh[:, ch[b, sel]]), N)[0].T
+            assert_close(y[b, sel], ref, what=f"batch {b} group {grp}")
+    assert bool(torch.isfinite(out).all())
+
+
+@pytest.mark.parametrize("N", [4096, 3000])
+def test_gate_gradient_at_full_size_64_rows_against_the_float64_closed_form(N):
+    """dgate[b, g, :] for 64 (batch, group) pairs spread over the batch — every workgroup position of the persistent gate-gradient kernel
+    (kernel_regtile_grad.h: grid = CUs, 16 work items per workgroup at this shape) — and one dV column of every tile of those batch elements,
+    against oracle.spectral_mix_backward_numpy (float64)."""
+    from fft_amd import spectral_mix_backward
+    from oracle.spectral_mix_oracle import spectral_mix_backward_numpy
+    B, D, G = 256, 768, 4
+    g = torch.Generator(device=DEV).manual_seed(N)
+    F = N // 2 + 1
+    V = torch.randn(B, N, D, device=DEV, generator=g)
+    dY = torch.randn(B, N, D, device=DEV, generator=g)
+    gate = torch.randn(B, G, F, dtype=torch.complex64, device=DEV, generator=g) * 0.3
+    gate = gate * (torch.rand(B, G, F, device=DEV, generator=g) >= 0.18)
+    dV, dG = spectral_mix_backward(V, gate, dY, N)
+    torch.cuda.synchronize()
+    d_g = D // G
+    for b in range(1, B, 4):
+        grp = (b // 4) % G
+        sl = slice(grp * d_g, (grp + 1) * d_g)
+        rV, rG = spectral_mix_backward_numpy(V[b:b + 1, :, sl].cpu().numpy(), gate[b:b + 1, grp:grp + 1].cpu().numpy(), dY[b:b + 1, :, sl].cpu().numpy(), N)
+        got = torch.view_as_real(dG[b:b + 1, grp:grp + 1]).cpu().numpy()
+        assert_close(got, np.stack([rG.real, rG.imag], -1), what=f"dgate row ({b},{grp})")
+        assert_close(dV[b:b + 1, :, sl].cpu().numpy(), rV, what=f"dV of batch {b}, group {grp}")        # 12 whole tiles of this batch element
+    assert bool(torch.isfinite(dV).all()) and bool(torch.isfinite(torch.view_as_real(dG)).all())
