@@ -6,6 +6,10 @@ test_fullsize_crosscheck_gpu.py compares two kernels of this repo with each othe
 kernels — meet the oracle itself where it is affordable: for every (batch element, 16-channel column tile) one channel drawn at random, all
 n_fft rows of it, against oracle.spectral_mix_numpy (float64 DFT of spectre.py:506, :542-553).  12 288 columns = 50 M output points per case.
 Tolerance: SURVEY.md §8(c), |y - e| <= 1e-4 |e| + 1e-4 RMS(e) (fp32 rows out); bf16 rows out: one bf16 ulp of the oracle on top."""
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -39,6 +43,9 @@ def test_one_column_of_every_tile_against_the_float64_oracle(B, N_in, N, D, G, d
     assert describe(V, gate, None, N, out=out).startswith(kernel)
     for _ in range(45):                               # past the tile-order measurement: the launch that is checked runs the order that stays
         spectral_mix(V, gate, None, N, out=out)
+    want_order = os.environ.get("SPECTRE_EXPECT_ORDER")            # set by test_every_tile_check_under_both_pinned_orders for its child runs
+    if want_order and "pipelined" in kernel:
+        assert f"order={want_order}" in describe(V, gate, None, N, out=out), describe(V, gate, None, N, out=out)
     out.fill_(float("nan"))
     spectral_mix(V, gate, None, N, out=out)
     torch.cuda.synchronize()
@@ -122,3 +129,14 @@ def test_gate_gradient_at_full_size_64_rows_against_the_float64_closed_form(N):
         assert_close(got, np.stack([rG.real, rG.imag], -1), what=f"dgate row ({b},{grp})")
         assert_close(dV[b:b + 1, :, sl].cpu().numpy(), rV, what=f"dV of batch {b}, group {grp}")        # 12 whole tiles of this batch element
     assert bool(torch.isfinite(dV).all()) and bool(torch.isfinite(torch.view_as_real(dG)).all())
+
+
+@pytest.mark.parametrize("order", ["static", "tickets"])
+def test_every_tile_check_under_both_pinned_orders(order):
+    """The library MEASURES which tile order a (V, out) pair takes, so which one the test above has checked depends on the box.  Here both are
+    pinned in turn (SPECTRE_TILE_ORDER is read once per process: child runs) and the persistent kernels' cases are checked again."""
+    env = dict(os.environ, SPECTRE_TUNING="1", SPECTRE_TILE_ORDER=order, SPECTRE_EXPECT_ORDER=order)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider",
+                        "-k", "one_column_of_every_tile and (C2 or C4 or padded or truncated)"], env=env, capture_output=True, text=True, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "6 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-1000:]
