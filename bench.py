@@ -351,7 +351,7 @@ def main():
             ms = time_kernel(Vv, gate, None, N, out=ov, warmup=VARIANT_WARMUP, iters=max(3, a.steps // 2))
             byt = algorithmic_bytes(B, N, N, D, G, Vv.element_size(), ov.element_size())
             variants[name] = {"tokens_per_s": B * N / (ms * 1e-3), "kernel_ms": ms, "achieved_GBps": byt / ms / 1e6,
-                              "roofline_frac": byt / ms / 1e6 / HBM_PEAK_GBS}
+                              "roofline_frac": byt / ms / 1e6 / HBM_PEAK_GBS, "kernel": describe(Vv, gate, None, N, out=ov)}
             # the variant's OWN pattern ceiling: bf16 rows are 32-byte segments, four neighbouring workgroups per
             # 128-byte line (spectre_probe_copy seg 32, gang of 4), measured on the variant's own tensors
             if tin == tout and tin != dt and Vv.is_contiguous() and (B * N * D * Vv.element_size()) % (256 * 1024) == 0 and N % 4096 == 0:
@@ -398,7 +398,7 @@ def main():
             ms = time_kernel(Vc, gc, None, Nc, out=oc, warmup=VARIANT_WARMUP, iters=max(3, a.steps // 2))
             byt = algorithmic_bytes(Bc, Nc, Nc, Dc, G, 4, 4)
             variants[name] = {"tokens_per_s": Bc * Nc / (ms * 1e-3), "kernel_ms": ms, "achieved_GBps": byt / ms / 1e6,
-                              "roofline_frac": byt / ms / 1e6 / HBM_PEAK_GBS, "kernel": describe(Vc, gc, None, Nc)}
+                              "roofline_frac": byt / ms / 1e6 / HBM_PEAK_GBS, "kernel": describe(Vc, gc, None, Nc, out=oc)}
             # this configuration's own pattern ceiling: a pure copy in the kernel's tile shape on its own tensors — whole 128-byte lines
             # of all Nc rows for the whole-line tiles of n_fft <= 1024 (kernel_regtile_wide.h), 64-byte halves in pairs otherwise
             if (Bc * Nc * Dc * 4) % (256 * 1024) == 0:
