@@ -11,7 +11,9 @@
 //   SKEW   (round 5) wave w idles w * SKEW x `s_nop 7` at the start of the three phases that carry spread requests (behind the burst,
 //          in front of the middle phase, in front of I2): the eight waves reach every request slot at the same clock and meet at the CU's one
 //          memory path (16 clocks per 1-KiB request) — does a stagger of the whole instruction streams pay for itself?
-//   PRIO   0 none; 1 = s_setprio 1 for waves 4..7 (static); 2 = s_setprio 1 for waves 0..3; 3 = raised priority around the store / load bursts
+//   PRIO   0 none; 1 = s_setprio 1 for waves 4..7 (static); 2 = s_setprio 1 for waves 0..3; 3 = (round 6) s_setprio 3 around every SPREAD request
+//          (deferred stores / loads, LDS-DMA), 0 for the butterflies; 4 = (round 6) s_setprio 3 from the barrier in front of the store burst to the
+//          back edge (burst, reloads, gate fetch), 0 elsewhere
 #pragma once
 #include "../fft_amd/csrc/kernel_regtile.h"
 
@@ -458,6 +460,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
     const bool more = (MAPX == 4 || MAPX == 5) ? nxt_t < per_xcd4 : MAPX == 3 ? nxt_t < per_xcd : (it + 1 < a.tpw) && (tile + TS < a.n_tiles);
     coords();
     if constexpr (TSTAMP == 2) { if (it == 0) ph_last = __builtin_amdgcn_s_memrealtime(); }
+    if constexpr (PRIO == 4) __builtin_amdgcn_s_setprio(0);
     mark(0);                                       // (gate fetch of the previous iteration .. here)
     [[maybe_unused]] unsigned fut = 1;
     if constexpr (MAPX == 3) {                     // the ticket of the tile after next: requested now, in the LDS word behind F1's barrier
@@ -489,10 +492,13 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
     [[maybe_unused]] const uint32_t pf_voff = (uint32_t)(((long long)(u + 512 * h) * v_sn + 4 * pp) * ESI);
     [[maybe_unused]] auto pf_store = [&](auto ic) {
       constexpr int g = GP + decltype(ic)::value / 4, m = decltype(ic)::value % 4;
+      if constexpr (PRIO == 3) __builtin_amdgcn_s_setprio(3);
       store16(rsrc_out(obp, out_sn, it > 0), pf_ooff + (uint32_t)((64 * g + 1024 * m) * out_sn * ESO), dfr[decltype(ic)::value]);
+      if constexpr (PRIO == 3) __builtin_amdgcn_s_setprio(0);
     };
     [[maybe_unused]] auto pf_load = [&](auto ic) {
       constexpr int g = GP + decltype(ic)::value / 4, m = decltype(ic)::value % 4;
+      if constexpr (PRIO == 3) __builtin_amdgcn_s_setprio(3);
       if constexpr (IN_BF16) {                       // stays packed (two dwords) until it trades places with the results in I2
         const rt_u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs_next, pf_voff + (uint32_t)((64 * g + 1024 * m) * v_sn * ESI), 0, 0);
         dfr[decltype(ic)::value].x = __uint_as_float(t.x); dfr[decltype(ic)::value].y = __uint_as_float(t.y);
@@ -500,6 +506,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
         const pv_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_next, pf_voff + (uint32_t)((64 * g + 1024 * m) * v_sn * 4), 0, AUXL);
         dfr[decltype(ic)::value] = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
       }
+      if constexpr (PRIO == 3) __builtin_amdgcn_s_setprio(0);
     };
     [[maybe_unused]] auto lat_load = [&](auto ic) {
       constexpr int g = GP - LATE + decltype(ic)::value / 4, m = decltype(ic)::value % 4;
@@ -774,6 +781,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
     [[maybe_unused]] const uint32_t dvo = dma_voff(voff, v_sn);
     auto dma_one = [&](auto qc) {
       constexpr int q = decltype(qc)::value;
+      if constexpr (PRIO == 3) __builtin_amdgcn_s_setprio(3);
       if constexpr (IN_BF16) {                       // two requests per group (dma_group)
         constexpr int g = q / 2, mh = q % 2;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_next, (__attribute__((address_space(3))) void*)(slot + (2 * g + mh) * 1024), 16,
@@ -783,6 +791,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_next, (__attribute__((address_space(3))) void*)(slot + (4 * g + m) * 1024), 16,
                                                  voff + (uint32_t)((64 * g + 1024 * m) * v_sn * 4), 0, 0, AUXD);
       }
+      if constexpr (PRIO == 3) __builtin_amdgcn_s_setprio(0);
     };
     wskew();
     constexpr int NDMA = (IN_BF16 ? 2 : 4) * SPLIT, NSLOT = DSPREAD == 3 ? 24 : DSPREAD == 2 ? 16 : 8;   // (3: ... and over the eight groups of I2's last stage)
@@ -910,6 +919,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
         mark(7);                                   // DMA issue, twiddles, I2 (wave 0's own)
         if constexpr (SYNCP >= 9) p64v_barrier();
         mark(8);                                   // barrier in front of the burst (the slowest wave's I2)
+        if constexpr (PRIO == 4) __builtin_amdgcn_s_setprio(3);
         if constexpr (SYNCP == 10) static_for<0, NDMA>([&](auto qc) { dma_one(qc); });
         static_for<0, 8>([&](auto ic) {
           constexpr int g = (decltype(ic)::value + SPLIT) % 8;
