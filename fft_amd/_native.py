@@ -14,7 +14,7 @@ import torch  # noqa: F401  — must be imported first: the library binds to the
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPECTRE_HIP_LIB") or os.path.join(_HERE, "lib", "libspectre_hip.so")   # env: A/B builds
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 F32, BF16 = 0, 1
 ALGO = {"auto": 0, "stockham": 1, "regtile": 2}
 
@@ -22,7 +22,8 @@ ALGO = {"auto": 0, "stockham": 1, "regtile": 2}
 EXPORTS = ("spectre_version", "spectre_last_error", "spectre_mix_fwd", "spectre_mix_describe",
            "spectre_plan_create", "spectre_plan_destroy", "spectre_mix_time", "spectre_mix_bwd",
            "spectre_mix_bwd_workspace_bytes", "spectre_gate_fwd", "spectre_gate_bwd", "spectre_rfft_fwd", "spectre_decode_workspace_bytes",
-           "spectre_decode_step", "spectre_decode_head_workspace_bytes", "spectre_decode_head_step", "spectre_probe_copy", "spectre_plans_release_retired")
+           "spectre_decode_step", "spectre_decode_head_workspace_bytes", "spectre_decode_head_step", "spectre_probe_copy", "spectre_plans_release_retired",
+           "spectre_plan_set_tile_order", "spectre_plan_get_tile_order")
 
 
 class SpectreMixArgs(ctypes.Structure):
@@ -139,6 +140,10 @@ def load():
         lib.spectre_plan_destroy.restype = ctypes.c_int
         lib.spectre_plans_release_retired.argtypes = [ctypes.c_int]
         lib.spectre_plans_release_retired.restype = ctypes.c_int
+        lib.spectre_plan_set_tile_order.argtypes = [ctypes.c_int, ctypes.c_int64, ctypes.c_int]
+        lib.spectre_plan_set_tile_order.restype = ctypes.c_int
+        lib.spectre_plan_get_tile_order.argtypes = [ctypes.c_int, ctypes.c_int64, ctypes.POINTER(ctypes.c_int)]
+        lib.spectre_plan_get_tile_order.restype = ctypes.c_int
         lib.spectre_mix_time.argtypes = [ctypes.POINTER(SpectreMixArgs), ctypes.c_int, ctypes.c_int,
                                          ctypes.POINTER(ctypes.c_float)]
         lib.spectre_mix_time.restype = ctypes.c_int

@@ -16,6 +16,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/spectre_hip.h"
@@ -174,8 +175,12 @@ int fail(int code, const char* fmt, ...) {
 constexpr int kDgatePrefetch = 1;          // 64 x 64 gate gradient: the persistent form with prefetch registers (kernel_regtile_grad.h, PN / EARLY)
 constexpr size_t kLdsBytes = 160 * 1024;   // gfx950: 160 KiB per CU, one workgroup may take all of it
 
-constexpr int kTicketSlices = 64;
+constexpr int kTicketSlices = 128;
 constexpr int kOrderWarmLaunches = 24;
+constexpr int kOrderClasses = 32;          // shape classes a plan keeps a decision for (SPECTRE_ORDER_AUTO)
+constexpr int kOrderPairs = 64;            // (V, out) pairs it keeps one for (SPECTRE_ORDER_AUTO_PAIR)
+constexpr int kOrderExploreCap = 1024;     // event-timed launches a plan may spend on measuring, all classes / pairs together
+constexpr float kOrderMargin = 0.99f;      // the static map replaces the default (tickets) only where it measures at least 1 % faster
 
 struct Plan {
   int device = 0;
@@ -191,28 +196,44 @@ struct Plan {
   float2* tw_m = nullptr;
   float2* chirp = nullptr;
   float2* bhat = nullptr;
-  // n_fft = 4096, round 5: ring of ticket slices for the dynamic tile order of kernel_regtile64p.h (TICKETS): UNCACHED device memory
-  // (scalar atomics carry no scope bits, so only memory the L2 does not keep is coherent between XCDs for them).  Every launch takes the
-  // next slice and zeroes the part it uses on its own stream, so launches in flight on different streams never share one (up to
-  // kTicketSlices of them).  nullptr (allocation refused): the static tile map.
+  // n_fft = 4096 / 3000 / 3600 / 3840: ticket slices for the dynamic tile order of kernel_regtile64p.h / kernel_tickets.h (TICKETS): UNCACHED
+  // device memory (scalar atomics carry no scope bits, so only memory the L2 does not keep is coherent between XCDs for them).
+  // WHO MAY USE A SLICE (round 6): a slice belongs to ONE stream for the life of the plan (slice_of_stream) — launches on
+  // one stream execute in order, and every ticket launch is preceded on its stream by the reset of its slice, so a slice is never
+  // zeroed under a running kernel and two kernels never draw from one counter, whatever the other streams do.  (Round 5 handed the
+  // slices out round-robin: a stream that stalled behind an event while another issued 64 launches, or a graph replay beside eager
+  // launches, could wrap the ring onto a slice still in use — missing tiles.)  A launch on a CAPTURING stream gets a slice of its own,
+  // for good: the graph replays it on whatever stream it is launched into, beside anything.  (One hipGraphExec never overlaps itself;
+  // two execs instantiated from ONE captured graph share its kernel arguments and must not be launched concurrently — or pin the
+  // static order for the capture.)  No free slice left, or no ring (allocation refused): the static tile map.
   unsigned* tk_ring = nullptr;
-  mutable std::atomic<unsigned> tk_next{0};
-  // ... and WHICH order a launch takes is measured, per (V, out) pair: the static map wins by 2-6 % where the driver has placed the two tensors
-  // in memory of the fast class and loses by 3-5 % elsewhere (allocation classes) — nothing a library can see from a
-  // pointer.  So behind the first 24 launches on a pair (tickets: the chip needs ~25 launches to leave its idle power state, and a measurement
-  // taken while the clock ramps up picked the wrong order in bench.py) sixteen launches take the two orders in the pattern T S S T (what is
-  // left of a drift cancels out) with a HIP event pair around each (recorded on the caller's stream, looked at later with hipEventQuery:
-  // nothing ever waits), and once all sixteen have finished the order with the smaller median (behind the first sample of each) stays.
-  // Same bits either way.  Not under stream capture (no event calls there: the order the pair has settled on, or tickets).
+  mutable std::unordered_map<hipStream_t, int> slice_of_stream;
+  mutable int slices_used = 0;
+  // WHICH order a launch takes (SPECTRE_ORDER_*, spectre_plan_set_tile_order; default AUTO).  The static map wins by 2-6 % where the
+  // driver has placed the two tensors in memory of the fast class and loses by 3-5 % elsewhere — nothing a library
+  // can see from a pointer, so it is measured: behind the first 24 launches of a CLASS (n_fft, shape, dtypes, strides — round 6: no
+  // pointers, so the decision survives an allocator that hands out a fresh `out` every call; tickets meanwhile: the chip needs ~25
+  // launches to leave its idle power state, and a measurement taken while the clock ramps up picked the wrong order in bench.py)
+  // sixteen launches take the two orders in the pattern T S S T (what is left of a drift cancels out) with a HIP event pair around
+  // each (recorded on the caller's stream, looked at later with hipEventQuery: nothing ever waits), and once all sixteen have finished
+  // the class takes the static map if its median (behind the first sample of each) is at least 1 % below the ticket order's, tickets
+  // otherwise — a decision inside the noise (round 5: bf16 -> bf16 at 1.1275 against 1.1278 ms) stays with the default.  One decision
+  // per class, for good (spectre_plan_set_tile_order starts over).  SPECTRE_ORDER_AUTO_PAIR keys the same procedure on the (V, out)
+  // pointer pair as well (round 5's behaviour: worth 2-6 % where a process reuses a few buffers of different allocation classes; an
+  // LRU of 64 pairs; a plan stops measuring behind 1024 timed launches in all).  Same bits either way.  Nothing is measured under
+  // stream capture (the decision so far, or tickets).
+  mutable std::atomic<int> order_policy{SPECTRE_ORDER_AUTO};
+  mutable int explore_spent = 0;
   struct OrderPending { hipEvent_t e0, e1; int mode; };
   struct OrderEntry {
     uint64_t key[6] = {0, 0, 0, 0, 0, 0};
     int decided = -1;                              // -1 exploring, 0 static, 1 tickets
-    int launches = 0;                              // on this pair so far (the measurement starts behind kOrderWarmLaunches of them)
+    int launches = 0;                              // of this class / pair so far (the measurement starts behind kOrderWarmLaunches of them)
     int issued[2] = {0, 0}, samples[2] = {0, 0};
     float ms[2][8] = {{0}, {0}};                   // the samples of each order, in issue order
     float med[2] = {0.f, 0.f};                     // medians behind the first sample of each (what the decision was taken on)
-    char name[64] = "auto";
+    char name[72] = "auto";
+    bool pair = false;                             // keyed on the (V, out) pointers as well (SPECTRE_ORDER_AUTO_PAIR)
     std::vector<OrderPending> pending;
     uint64_t last_use = 0;
   };
@@ -540,40 +561,87 @@ hipError_t ticket_reset(unsigned* slice, size_t bytes, hipStream_t stream) {
   return hipGetLastError();
 }
 
-// SPECTRE_TILE_ORDER = auto (default: measured per tensor pair) | tickets | static   (under SPECTRE_TUNING=1)
-int tile_order_policy() {
-  static const int pol = [] { const char* e = tuning_env("SPECTRE_TILE_ORDER"); return !e ? 2 : !strcmp(e, "static") ? 0 : !strcmp(e, "tickets") ? 1 : 2; }();
-  return pol;
+// Event and capture-status calls of the order measurement and of the slice hand-out are made with this thread's capture mode RELAXED:
+// while ANOTHER stream is being captured in the (default) global mode, hipEventQuery / hipEventCreate from any thread would otherwise
+// invalidate that capture.  Nothing here touches the capturing stream itself.
+struct RelaxedCapture {
+  hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+  bool ok;
+  RelaxedCapture() { ok = hipThreadExchangeStreamCaptureMode(&mode) == hipSuccess; if (!ok) (void)hipGetLastError(); }
+  ~RelaxedCapture() { if (ok) (void)hipThreadExchangeStreamCaptureMode(&mode); }
+};
+// a status we cannot read counts as "capturing": no event calls, no measuring
+bool stream_capturing(hipStream_t stream) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cs) != hipSuccess) { (void)hipGetLastError(); return true; }
+  return cs != hipStreamCaptureStatusNone;
 }
 
-Plan::OrderEntry* order_entry(const SpectreMixArgs* a, const Plan* plan, bool create) {     // (plan->order_mu held)
-  const uint64_t key[6] = {(uint64_t)(uintptr_t)a->v, (uint64_t)(uintptr_t)a->out, (uint64_t)a->B, (uint64_t)a->D,
+// The ticket slice of this launch (Plan: who may use a slice), or nullptr = take the static map.
+unsigned* take_slice(const Plan* plan, hipStream_t stream, bool capturing, size_t slice_words) {
+  std::lock_guard<std::mutex> lk(plan->order_mu);
+  int idx = -1;
+  if (!capturing) {
+    auto it = plan->slice_of_stream.find(stream);
+    if (it != plan->slice_of_stream.end()) idx = it->second;
+  }
+  if (idx < 0) {
+    if (plan->slices_used >= kTicketSlices) return nullptr;
+    idx = plan->slices_used++;
+    if (!capturing) plan->slice_of_stream.emplace(stream, idx);
+  }
+  return plan->tk_ring + (size_t)idx * slice_words;
+}
+
+// The order policy in force: SPECTRE_TILE_ORDER = auto | pair | tickets | static under SPECTRE_TUNING=1 (tests, A/B) overrides the plan's
+// (spectre_plan_set_tile_order; default SPECTRE_ORDER_AUTO)
+int tile_order_policy(const Plan* plan) {
+  static const int env = [] { const char* e = tuning_env("SPECTRE_TILE_ORDER");
+                              return !e ? -1 : !strcmp(e, "static") ? SPECTRE_ORDER_STATIC : !strcmp(e, "tickets") ? SPECTRE_ORDER_TICKETS
+                                         : !strcmp(e, "pair") ? SPECTRE_ORDER_AUTO_PAIR : !strcmp(e, "auto") ? SPECTRE_ORDER_AUTO : -1; }();
+  return env >= 0 ? env : plan->order_policy.load(std::memory_order_relaxed);
+}
+
+void order_entry_drop(Plan::OrderEntry& en) { for (auto& pd : en.pending) { (void)hipEventDestroy(pd.e0); (void)hipEventDestroy(pd.e1); } en.pending.clear(); }
+
+Plan::OrderEntry* order_entry(const SpectreMixArgs* a, const Plan* plan, bool per_pair, bool create) {     // (plan->order_mu held)
+  const uint64_t key[6] = {per_pair ? (uint64_t)(uintptr_t)a->v : 0, per_pair ? (uint64_t)(uintptr_t)a->out : 0, (uint64_t)a->B, (uint64_t)a->D,
                            (uint64_t)a->N_in * 4 + (uint64_t)a->in_dtype * 2 + (uint64_t)a->out_dtype, (uint64_t)a->v_sn ^ ((uint64_t)a->out_sn << 32)};
-  for (auto& en : plan->orders) if (!memcmp(en.key, key, sizeof key)) { en.last_use = ++plan->order_clock; return &en; }
+  for (auto& en : plan->orders) if (en.pair == per_pair && !memcmp(en.key, key, sizeof key)) { en.last_use = ++plan->order_clock; return &en; }
   if (!create) return nullptr;
-  if (plan->orders.size() >= 64) {                 // forget the pair that has not been used for the longest time (its events with it)
-    size_t old = 0;
-    for (size_t i = 1; i < plan->orders.size(); ++i) if (plan->orders[i].last_use < plan->orders[old].last_use) old = i;
-    for (auto& pd : plan->orders[old].pending) { (void)hipEventDestroy(pd.e0); (void)hipEventDestroy(pd.e1); }
+  // full: forget the entry of the same kind that has not been used for the longest time (its events with it)
+  size_t kind = 0, old = plan->orders.size();
+  for (size_t i = 0; i < plan->orders.size(); ++i) {
+    if (plan->orders[i].pair != per_pair) continue;
+    ++kind;
+    if (old == plan->orders.size() || plan->orders[i].last_use < plan->orders[old].last_use) old = i;
+  }
+  if (kind >= (size_t)(per_pair ? kOrderPairs : kOrderClasses)) {
+    order_entry_drop(plan->orders[old]);
     plan->orders.erase(plan->orders.begin() + (long)old);
   }
   plan->orders.emplace_back();
   memcpy(plan->orders.back().key, key, sizeof key);
+  plan->orders.back().pair = per_pair;
+  if (per_pair) snprintf(plan->orders.back().name, sizeof plan->orders.back().name, "pair");
   plan->orders.back().last_use = ++plan->order_clock;
   return &plan->orders.back();
 }
 
 // Which order does THIS launch take (1 = tickets), and does it carry an event pair (returned in *ev, recorded by the caller around the launch)?
-int choose_tile_order(const SpectreMixArgs* a, const Plan* plan, hipStream_t stream, Plan::OrderPending* ev, bool* timed) {
+int choose_tile_order(const SpectreMixArgs* a, const Plan* plan, bool capturing, Plan::OrderPending* ev, bool* timed) {
   *timed = false;
-  const int pol = tile_order_policy();
-  if (pol != 2) return pol;
+  const int pol = tile_order_policy(plan);
+  if (pol == SPECTRE_ORDER_STATIC) return 0;
+  if (pol == SPECTRE_ORDER_TICKETS) return 1;
+  const bool per_pair = pol == SPECTRE_ORDER_AUTO_PAIR;
   std::lock_guard<std::mutex> lk(plan->order_mu);
-  Plan::OrderEntry* en = order_entry(a, plan, true);
-  // a stream that is being captured: no event calls at all (they are not capture-safe — a query of an outside event during the capture
-  // left the captured launch without its slice reset on replay); the order this pair has settled on, or tickets
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return en->decided >= 0 ? en->decided : 1;
+  Plan::OrderEntry* en = order_entry(a, plan, per_pair, true);
+  // a stream that is being captured: no event calls at all (a query of an outside event during the capture left the captured launch
+  // without its slice reset on replay); the decision so far, or tickets
+  if (capturing) return en->decided >= 0 ? en->decided : 1;
+  if (en->decided >= 0) return en->decided;
+  RelaxedCapture rc;
   // harvest what has finished (in issue order; nothing waits)
   while (!en->pending.empty() && hipEventQuery(en->pending.front().e1) == hipSuccess) {
     Plan::OrderPending pd = en->pending.front();
@@ -585,40 +653,73 @@ int choose_tile_order(const SpectreMixArgs* a, const Plan* plan, hipStream_t str
     (void)hipEventDestroy(pd.e0); (void)hipEventDestroy(pd.e1);
   }
   (void)hipGetLastError();                         // (hipEventQuery's hipErrorNotReady is not an error of ours)
-  if (en->decided < 0 && en->samples[0] >= 8 && en->samples[1] >= 8) {
+  if (en->samples[0] >= 8 && en->samples[1] >= 8) {
     for (int m = 0; m < 2; ++m) { float t[7]; memcpy(t, en->ms[m] + 1, sizeof t); std::sort(t, t + 7); en->med[m] = t[3]; }
-    en->decided = en->med[1] <= en->med[0] ? 1 : 0;
-    snprintf(en->name, sizeof en->name, "auto:%s (%.4f ms against %.4f)", en->decided ? "tickets" : "static", en->med[en->decided], en->med[1 - en->decided]);
+    en->decided = en->med[0] < kOrderMargin * en->med[1] ? 0 : 1;
+    snprintf(en->name, sizeof en->name, "%s:%s (%.4f ms against %.4f)", per_pair ? "pair" : "auto", en->decided ? "tickets" : "static", en->med[en->decided], en->med[1 - en->decided]);
+    return en->decided;
   }
-  if (en->decided >= 0) return en->decided;
   if (++en->launches <= kOrderWarmLaunches) return 1;
   // measuring: T S S T T S S T T S S T T S S T, eight timed launches per order
   const int k = en->issued[0] + en->issued[1];
   const int mode = (k & 3) == 0 || (k & 3) == 3 ? 1 : 0;
-  if (k >= 16) return 1;
+  if (k >= 16) {
+    // every sample is issued; if they do not all come back (a failed event: fewer than 8 samples an order) the class keeps the default
+    if (en->pending.empty()) { en->decided = 1; snprintf(en->name, sizeof en->name, "%s:tickets (default: %d + %d samples)", per_pair ? "pair" : "auto", en->samples[1], en->samples[0]); }
+    return 1;
+  }
+  if (plan->explore_spent >= kOrderExploreCap) {   // this plan has measured enough: the default for whatever is still undecided
+    en->decided = 1; snprintf(en->name, sizeof en->name, "%s:tickets (default: measuring budget spent)", per_pair ? "pair" : "auto");
+    order_entry_drop(*en);
+    return 1;
+  }
   if (hipEventCreate(&ev->e0) != hipSuccess) { (void)hipGetLastError(); return 1; }
   if (hipEventCreate(&ev->e1) != hipSuccess) { (void)hipEventDestroy(ev->e0); (void)hipGetLastError(); return 1; }
   ev->mode = mode;
   ++en->issued[mode];
+  ++plan->explore_spent;
   *timed = true;
   return mode;
 }
 
 void tile_order_timed(const SpectreMixArgs* a, const Plan* plan, const Plan::OrderPending& ev) {     // the event pair is on the stream: remember it
   std::lock_guard<std::mutex> lk(plan->order_mu);
-  if (Plan::OrderEntry* en = order_entry(a, plan, false)) en->pending.push_back(ev);
+  const int pol = tile_order_policy(plan);
+  Plan::OrderEntry* en = pol == SPECTRE_ORDER_AUTO || pol == SPECTRE_ORDER_AUTO_PAIR ? order_entry(a, plan, pol == SPECTRE_ORDER_AUTO_PAIR, false) : nullptr;
+  if (en && en->decided < 0) en->pending.push_back(ev);
   else { (void)hipEventDestroy(ev.e0); (void)hipEventDestroy(ev.e1); }
 }
 
 const char* tile_order_name(const SpectreMixArgs* a, const Plan* plan) {
-  const int pol = tile_order_policy();
-  if (pol == 0) return "static";
-  if (pol == 1) return "tickets";
+  const int pol = tile_order_policy(plan);
+  if (pol == SPECTRE_ORDER_STATIC) return "static";
+  if (pol == SPECTRE_ORDER_TICKETS) return "tickets";
   std::lock_guard<std::mutex> lk(plan->order_mu);
-  const Plan::OrderEntry* en = order_entry(a, plan, false);
-  static thread_local char buf[64];
-  snprintf(buf, sizeof buf, "%s", en ? en->name : "auto");
+  const Plan::OrderEntry* en = order_entry(a, plan, pol == SPECTRE_ORDER_AUTO_PAIR, false);
+  static thread_local char buf[80];
+  snprintf(buf, sizeof buf, "%s", en ? en->name : pol == SPECTRE_ORDER_AUTO_PAIR ? "pair" : "auto");
   return buf;
+}
+
+// One ticket launch's bookkeeping, shared by the 4096 kernel and the persistent mixed-radix kernels: the order of this launch, its slice
+// (reset on the launch's own stream), the event pair of a measured launch.  Returns the slice (nullptr: static map).
+int ticket_launch_begin(const SpectreMixArgs* a, const Plan* plan, hipStream_t stream, size_t slice_words, size_t used_bytes, Plan::OrderPending* ev, bool* timed, unsigned** slice) {
+  *slice = nullptr;
+  bool capturing;
+  { RelaxedCapture rc; capturing = stream_capturing(stream); }
+  {                                                // no slice to be had for this stream: the static map, and nothing to measure
+    std::lock_guard<std::mutex> lk(plan->order_mu);
+    if (plan->slices_used >= kTicketSlices && (capturing || !plan->slice_of_stream.count(stream))) return SPECTRE_OK;
+  }
+  const int tickets = choose_tile_order(a, plan, capturing, ev, timed);
+  if (*timed) (void)hipEventRecord(ev->e0, stream);
+  if (!tickets) return SPECTRE_OK;
+  unsigned* sl = take_slice(plan, stream, capturing, slice_words);
+  if (!sl) return SPECTRE_OK;                      // (another thread took the last one in between)
+  const hipError_t e = ticket_reset(sl, used_bytes, stream);
+  if (e != hipSuccess) return fail(SPECTRE_E_HIP, "ticket slice reset: %s", hipGetErrorString(e));
+  *slice = sl;
+  return SPECTRE_OK;
 }
 
 int launch(const SpectreMixArgs* a, const Plan* plan, const Choice& c, bool conj_gate = false) {
@@ -657,14 +758,11 @@ int launch(const SpectreMixArgs* a, const Plan* plan, const Choice& c, bool conj
       k.n_wg = gang * ((k.n_tiles + gang * k.tpw - 1) / (gang * k.tpw));
       // round 5: dynamic tile order (one ticket per gang from a chip-wide counter) where the ring exists and the launch fits a slice
       Plan::OrderPending ev{}; bool timed = false;
-      if (p64_tickets(a, plan, k.n_tiles, k.n_wg, gang) && choose_tile_order(a, plan, stream, &ev, &timed)) {
-        if (timed) (void)hipEventRecord(ev.e0, stream);
-        unsigned* slice = plan->tk_ring + (size_t)(plan->tk_next.fetch_add(1, std::memory_order_relaxed) % kTicketSlices) * sfft::kP64TkSliceWords;
-        const size_t used = ((size_t)sfft::kP64TkClaim + (size_t)(k.n_tiles + 31) / 32) * 4;
-        if ((e = ticket_reset(slice, used, stream)) != hipSuccess) return fail(SPECTRE_E_HIP, "ticket slice reset: %s", hipGetErrorString(e));
+      if (p64_tickets(a, plan, k.n_tiles, k.n_wg, gang)) {
+        unsigned* slice = nullptr;
+        if (int rc = ticket_launch_begin(a, plan, stream, sfft::kP64TkSliceWords, ((size_t)sfft::kP64TkClaim + (size_t)(k.n_tiles + 31) / 32) * 4, &ev, &timed, &slice)) return rc;
         k.tickets = slice;
       }
-      else if (timed) (void)hipEventRecord(ev.e0, stream);
       e = sfft::launch_regtile64p(k, ib, ob, !burst_off, stream);
       if (timed) { (void)hipEventRecord(ev.e1, stream); tile_order_timed(a, plan, ev); }
     } else if (c.mixedp) {   // one workgroup per CU, pairs of workgroups on adjacent tiles (kernel_regtile_mixedp.h)
@@ -674,14 +772,11 @@ int launch(const SpectreMixArgs* a, const Plan* plan, const Choice& c, bool conj
       k.n_wg = 2 * ((k.n_tiles + 2 * k.tpw - 1) / (2 * k.tpw));
       const int64_t n = a->n_fft;
       Plan::OrderPending ev{}; bool timed = false;
-      if (mixedp_tickets(a, plan, k.n_tiles, k.n_wg) && choose_tile_order(a, plan, stream, &ev, &timed)) {      // round 5: dynamic tile order, as at 4096
-        if (timed) (void)hipEventRecord(ev.e0, stream);
-        unsigned* slice = plan->tk_ring + (size_t)(plan->tk_next.fetch_add(1, std::memory_order_relaxed) % kTicketSlices) * sfft::kTkSliceWords;
-        const size_t used = ((size_t)sfft::kTkClaim + (size_t)(k.n_tiles + 31) / 32) * 4;
-        if ((e = ticket_reset(slice, used, stream)) != hipSuccess) return fail(SPECTRE_E_HIP, "ticket slice reset: %s", hipGetErrorString(e));
+      if (mixedp_tickets(a, plan, k.n_tiles, k.n_wg)) {      // round 5: dynamic tile order, as at 4096
+        unsigned* slice = nullptr;
+        if (int rc = ticket_launch_begin(a, plan, stream, sfft::kTkSliceWords, ((size_t)sfft::kTkClaim + (size_t)(k.n_tiles + 31) / 32) * 4, &ev, &timed, &slice)) return rc;
         k.tickets = slice;
       }
-      else if (timed) (void)hipEventRecord(ev.e0, stream);
       e = n == 3000 ? sfft::launch_regtile_mixedp<60, 50>(k, stream) : n == 2560 ? sfft::launch_regtile_mixedp<64, 40>(k, stream)
         : n == 2400 ? sfft::launch_regtile_mixedp<60, 40>(k, stream) : n == 3072 ? sfft::launch_regtile_mixedp<64, 48>(k, stream)
         : n == 3600 ? sfft::launch_regtile_mixedp<60, 60>(k, stream) : sfft::launch_regtile_mixedp<64, 60>(k, stream);
@@ -761,6 +856,32 @@ int spectre_plan_destroy(int device, int64_t n_fft) {
   if (it == g_plans.end()) return fail(SPECTRE_E_INVALID, "no plan for device %d n_fft %lld", device, (long long)n_fft);
   g_retired[{device, n_fft}] = std::move(it->second);   // out of service, not freed (see g_retired): safe against launches in flight
   g_plans.erase(it);
+  return SPECTRE_OK;
+}
+
+int spectre_plan_set_tile_order(int device, int64_t n_fft, int order) {
+  if (order < SPECTRE_ORDER_AUTO || order > SPECTRE_ORDER_AUTO_PAIR) return fail(SPECTRE_E_INVALID, "bad tile order %d", order);
+  if (n_fft < 1) return fail(SPECTRE_E_INVALID, "n_fft must be >= 1");
+  DeviceGuard g(device);
+  if (!g.ok) return fail(SPECTRE_E_HIP, "cannot select device %d", device);
+  Plan* p = nullptr;
+  if (int rc = get_plan(device, n_fft, &p)) return rc;
+  std::lock_guard<std::mutex> lk(p->order_mu);
+  p->order_policy.store(order, std::memory_order_relaxed);
+  // start over: what has been measured belongs to the old policy (events of launches still in flight are destroyed, which HIP allows)
+  RelaxedCapture rc;
+  for (auto& en : p->orders) order_entry_drop(en);
+  p->orders.clear();
+  p->explore_spent = 0;
+  return SPECTRE_OK;
+}
+
+int spectre_plan_get_tile_order(int device, int64_t n_fft, int* order) {
+  if (!order) return fail(SPECTRE_E_INVALID, "order is NULL");
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_plans.find({device, n_fft});
+  if (it == g_plans.end()) return fail(SPECTRE_E_INVALID, "no plan for device %d n_fft %lld", device, (long long)n_fft);
+  *order = tile_order_policy(it->second.get());
   return SPECTRE_OK;
 }
 

@@ -144,9 +144,32 @@ def spectral_mix_backward(V: torch.Tensor, gate: torch.Tensor, grad_out: torch.T
     return dv, dgate
 
 
+TILE_ORDERS = {"auto": 0, "static": 1, "tickets": 2, "pair": 3}       # SPECTRE_ORDER_* of include/spectre_hip.h
+
+
+def set_tile_order(n_fft: int, order: str = "auto", device=None) -> None:
+    """Tile order of the persistent kernels (n_fft = 4096, 3000, 3600, 3840) on `device` (C ABI `spectre_plan_set_tile_order`):
+    "auto" (default: tickets, measured once per shape class, the static map only where it is at least 1 % faster), "static", "tickets"
+    (pinned: no event calls on the launch path) or "pair" (measured per (V, out) pointer pair as well).  Forgets every decision so far."""
+    lib = _native.load()
+    if order not in TILE_ORDERS:
+        raise ValueError(f"order must be one of {sorted(TILE_ORDERS)}")
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    _native.check(lib.spectre_plan_set_tile_order(int(dev), int(n_fft), TILE_ORDERS[order]), "spectre_plan_set_tile_order")
+
+
+def get_tile_order(n_fft: int, device=None) -> str:
+    lib = _native.load()
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    o = ctypes.c_int(-1)
+    _native.check(lib.spectre_plan_get_tile_order(int(dev), int(n_fft), ctypes.byref(o)), "spectre_plan_get_tile_order")
+    return {v: k for k, v in TILE_ORDERS.items()}[o.value]
+
+
 def describe(V, gate, memory_fft=None, n_fft=None, *, out_dtype=None, algo="auto", out=None) -> str:
     """Name of the kernel `spectral_mix` would launch for these arguments.  `out`: the output tensor of the launch in question (the tile
-    order of the persistent kernels is measured per (V, out) pair: `order=auto` until it has been, then `auto:tickets` / `auto:static`)."""
+    order of the persistent kernels is measured per shape class — under set_tile_order(..., "pair") per (V, out) pair: `order=auto` until
+    it has been, then `auto:tickets (...)` / `auto:static (...)`)."""
     lib = _native.load()
     if n_fft is None:
         n_fft = V.shape[1]

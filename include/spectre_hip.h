@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SPECTRE_ABI_VERSION 8
+#define SPECTRE_ABI_VERSION 9
 
 enum {
   SPECTRE_OK = 0,
@@ -101,6 +101,24 @@ int spectre_plan_destroy(int device, int64_t n_fft);
  * Bluestein lengths carry about 1 MiB of tables each) uses this to keep device memory bounded.  No counterpart in the reference (torch.fft
  * keeps its own plan cache: spectre.py:506, :551). */
 int spectre_plans_release_retired(int device);
+
+/* Tile order of the persistent kernels (n_fft = 4096, 3000, 3600, 3840; ignored by every other length).  The workgroups of those kernels
+ * walk through the (batch element, channel tile) grid either by a STATIC map or by drawing TICKETS from a chip-wide counter (adjacent
+ * tiles in address order: the chip then works on a few neighbouring batch elements at a time).  Same bits either way; which one is faster
+ * depends on where the driver has placed the two tensors: tickets by 3-5 % on typical buffers, the static map by
+ * 2-6 % on some.
+ *   SPECTRE_ORDER_AUTO       (default) tickets from the first launch; behind 24 launches of a shape class (B, N_in, D, dtypes, strides — no
+ *                            pointers) sixteen launches are timed with HIP events on the caller's stream (nothing waits, nothing under
+ *                            stream capture), and the class moves to the static map only if that measures at least 1 % faster.  One
+ *                            decision per class; spectre_mix_describe ends in `order=auto`, later `order=auto:tickets (...)` / `auto:static (...)`
+ *   SPECTRE_ORDER_STATIC / SPECTRE_ORDER_TICKETS   pinned: no event calls at all on the launch path
+ *   SPECTRE_ORDER_AUTO_PAIR  the same measurement per (v, out) POINTER pair as well (worth it where a process keeps a few long-lived
+ *                            buffers; an LRU of 64 pairs, at most 1024 timed launches per plan)
+ * Setting the order (also to its current value) forgets every decision of the plan.  Creates the plan if it does not exist (not under
+ * stream capture).  No counterpart in the reference (spectre.py:506, :551 go through torch.fft's plan cache). */
+enum { SPECTRE_ORDER_AUTO = 0, SPECTRE_ORDER_STATIC = 1, SPECTRE_ORDER_TICKETS = 2, SPECTRE_ORDER_AUTO_PAIR = 3 };
+int spectre_plan_set_tile_order(int device, int64_t n_fft, int order);
+int spectre_plan_get_tile_order(int device, int64_t n_fft, int* order);
 
 /* Backward of spectre_mix_fwd (autograd through spectre.py:506, :542-553):
  *   dv    (B, N_in, D)   = mix(dout, conj(gate))  zero-padded back to N_in rows   — same kernels as the forward
