@@ -10,6 +10,12 @@
 //   wl_tile<DYNG, S>        dynamic, one ticket per GANG (the 128 / S workgroups that share a line): the leader draws, the others read
 //                           the ticket from a mailbox — the halves of a line stay with workgroups that walk in step
 //   wl_tile<DYNX, S>        as DYNG with one counter per XCD (XCD x owns the x-th eighth of the tensor)
+//   wl_pairx<XCH>           (round 6) the TWO-CU form of the 4096-row tile in copy form: a pair of workgroups (neighbours on one
+//                           XCD) owns a 128-byte column of 4096 rows = the two 64-byte tiles of the product; member m requests WHOLE 128-byte
+//                           lines of rows [2048 m, 2048 m + 2048) and, as the product would have to, hands the half that belongs to its partner's
+//                           tile over through an L2-resident scratch ring (XCH >= 1: input side; XCH = 2: the output side as well, so that the
+//                           stores are whole lines too).  Traffic emulation, UPPER BOUND: no flags, no waiting for the partner (a real hand-off
+//                           needs both), sc1 loads so that the scratch is read from the L2 and not from a stale L1 line; one ticket per pair
 // usage: window_lab [reps] [only]     (only = substring of a variant name)
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/window_lab.hip -o tools/window_lab
 #include <hip/hip_runtime.h>
@@ -103,6 +109,73 @@ __global__ void __launch_bounds__(512) wl_tile(const LabArgs a) {
   }
 }
 
+// XCH: 0 = whole lines of half the rows, no exchange (what the memory side sees: 128-byte tiles of 2048 rows); 1 = + the input-side
+// exchange (32 KiB of every 64-KiB chunk out to the scratch, the partner's 32 KiB in); 2 = + the output-side exchange
+template <int XCH>
+__global__ void __launch_bounds__(512) wl_pairx(const LabArgs a, char* scratch) {
+  constexpr int U = 8, THREADS = 512, RPI = THREADS / 8;       // 8 lanes per 128-byte line, 64 rows per instruction, 512 rows per chunk
+  const int tid = threadIdx.x;
+  const long long lane_off = (long long)(tid / 8) * a.row_bytes + (tid % 8) * 16;
+  const long long step = (long long)RPI * a.row_bytes;
+  const int wg = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int member = wg & 1, g = wg >> 1;
+  __shared__ unsigned next_s;
+  unsigned* cnt = a.counter;
+  unsigned* mbox = a.counter + 256 + 16 * g;
+  char* mine_in = scratch + (size_t)wg * 65536, *mine_out = mine_in + 32768;
+  const char* theirs_in = scratch + (size_t)(wg ^ 1) * 65536, *theirs_out = theirs_in + 32768;
+  f4 v[U];
+#pragma unroll
+  for (int q = 0; q < U; ++q) v[q] = f4{1.f, 2.f, 3.f, 4.f};
+  for (int it = 0;; ++it) {
+    if (tid == 0) {
+      unsigned tk;
+      if (member == 0) {
+        tk = atomicAdd(cnt, 1u);
+        __hip_atomic_store(mbox + (it & 15), ((unsigned)(it + 1) << 16) | tk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        tk = 0xffffu;
+        for (int sp = 0; sp < (1 << 20); ++sp) {
+          const unsigned w = __hip_atomic_load(mbox + (it & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((w >> 16) == (unsigned)(it + 1)) { tk = w & 0xffffu; break; }
+          __builtin_amdgcn_s_sleep(2);
+        }
+      }
+      next_s = tk;
+    }
+    __syncthreads(); const int t = (int)next_s; __syncthreads();
+    if (t >= a.n_tiles) break;                  // n_tiles = 128-byte columns x batch elements
+    const long long base = ((long long)(t / a.cols) * a.tile_rows + (long long)member * (a.tile_rows / 2)) * a.row_bytes + (long long)(t % a.cols) * 128;
+    const int chunks = a.tile_rows / 2 / (RPI * U);
+    for (int c = 0; c < chunks; ++c) {
+      const long long off = base + lane_off + (long long)c * U * step;
+      if (a.mode != 2) {
+#pragma unroll
+        for (int q = 0; q < U; ++q) v[q] = *reinterpret_cast<const f4*>(a.src + off + q * step);
+      }
+      if constexpr (XCH >= 1) {                 // half of what was loaded belongs to the partner's tile: out to the scratch, the partner's half in
+#pragma unroll
+        for (int q = 0; q < U / 2; ++q) *reinterpret_cast<f4*>(mine_in + q * 8192 + tid * 16) = v[q];
+#pragma unroll
+        for (int q = 0; q < U / 2; ++q) v[q] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(theirs_in + q * 8192 + tid * 16));
+      }
+      if constexpr (XCH >= 2) {                 // ... and half of the results go back the same way, so that whole lines can be stored
+#pragma unroll
+        for (int q = 0; q < U / 2; ++q) *reinterpret_cast<f4*>(mine_out + q * 8192 + tid * 16) = v[U / 2 + q];
+#pragma unroll
+        for (int q = 0; q < U / 2; ++q) v[U / 2 + q] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(theirs_out + q * 8192 + tid * 16));
+      }
+      if (a.mode != 1) {
+#pragma unroll
+        for (int q = 0; q < U; ++q) *reinterpret_cast<f4*>(a.dst + off + q * step) = v[q];
+      } else {
+#pragma unroll
+        for (int q = 0; q < U; ++q) if (v[q].x == 1.2345e-30f) *reinterpret_cast<f4*>(a.dst + off + q * step) = v[q];
+      }
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) wl_flat(const f4* __restrict__ src, f4* __restrict__ dst) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   dst[i] = src[i];
@@ -168,6 +241,24 @@ int main(int argc, char** argv) {
     };
     report(full, time(go), (mode == 0 ? 2.0 : 1.0) * bytes);
   };
+  char* scratch; CK(hipMalloc(&scratch, (size_t)1024 * 65536)); CK(hipMemset(scratch, 0, (size_t)1024 * 65536));
+  auto runx = [&](auto kern, const char* name, int mode) {
+    char full[96];
+    static const char* moden[3] = {"copy", "load", "store"};
+    snprintf(full, sizeof full, "two-CU  %-26s %s", name, moden[mode]);
+    if (!wanted(full)) return;
+    LabArgs x{};
+    x.src = a; x.dst = b; x.row_bytes = row_bytes; x.tile_rows = 4096; x.mode = mode;
+    x.cols = (int)(row_bytes / 128); x.n_tiles = (int)(rows / 4096) * x.cols;      // tickets = 128-byte columns
+    x.n_wg = cus / 2 * 2; x.tpw = 0; x.counter = counter;
+    auto go = [&] { CK(hipMemsetAsync(counter, 0, 65536, 0)); hipLaunchKernelGGL(kern, dim3(x.n_wg), dim3(512), 0, 0, x, scratch); };
+    report(full, time(go), (mode == 0 ? 2.0 : 1.0) * bytes);
+  };
+  for (int mode : {0, 1, 2}) {
+    runx(wl_pairx<0>, "whole lines, half the rows", mode);
+    runx(wl_pairx<1>, "+ input-side exchange", mode);
+    runx(wl_pairx<2>, "+ both exchanges", mode);
+  }
   for (int mode : {0, 1, 2}) {
     run(wl_tile<FAR, 128>, "static far", 128, false, mode);
     run(wl_tile<COMPACT, 128>, "static compact", 128, false, mode);
