@@ -66,7 +66,7 @@ def _newest(paths):
 def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS] + [os.path.join(HERE, "isa_lint.py")]
     return _newest(deps) > os.path.getmtime(LIB)
 
 
@@ -76,7 +76,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJDIR, exist_ok=True)
     cc = hipcc()
 
-    hdr_time = _newest([os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS] + [os.path.abspath(__file__)])
+    hdr_time = _newest([os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS] + [os.path.abspath(__file__), os.path.join(HERE, "isa_lint.py")])
 
     def compile_one(src: str) -> str:
         obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))

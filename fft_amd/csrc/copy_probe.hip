@@ -59,14 +59,28 @@ __global__ void __launch_bounds__(kProbeThreads) spectre_probe_copy_kernel(const
     for (int c = 0; c < chunks; ++c) {
       const long long off = base + lane_off + (long long)c * kProbeInFlight * step;
       if constexpr (RAGGED) {
-        const int r0 = c * kProbeInFlight * rpi + row0;
+        // The product's own mechanism (kernel_regtile64p.h): raw buffer resources whose range ends with the tile's last row — a request
+        // beyond it costs no memory traffic (loads return 0, stores are dropped) and EVERY request is issued unconditionally.  Written as
+        // `if (row < tile_rows) v[q] = load`, hipcc gives each load a branch of its own with an `s_waitcnt vmcnt(0)` in front — one
+        // request in flight per wave: that is what rounds 4-5 measured as C4's "pattern copy" (found by fft_amd/isa_lint.py, round 6).
+        typedef unsigned int probe_u32x4 __attribute__((ext_vector_type(4)));
+        const int extent = (int)((long long)a.tile_rows * a.row_bytes);        // (bytes from the tile's first row; < 2^31 for every shape bench.py uses)
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.src) + base, 0, extent, kRsrcFlags);
+        const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(a.dst + base, 0, extent, kRsrcFlags);
+        const uint32_t o32 = (uint32_t)(lane_off + (long long)c * kProbeInFlight * step);
         if (a.mode != 2) {
 #pragma unroll
-          for (int q = 0; q < kProbeInFlight; ++q) if (r0 + q * rpi < a.tile_rows) v[q] = *reinterpret_cast<const probe_f32x4*>(a.src + off + q * step);
+          for (int q = 0; q < kProbeInFlight; ++q) {
+            const probe_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, o32 + (uint32_t)(q * step), 0, 0);
+            v[q] = probe_f32x4{__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w)};
+          }
         }
         if (a.mode != 1) {
 #pragma unroll
-          for (int q = 0; q < kProbeInFlight; ++q) if (r0 + q * rpi < a.tile_rows) *reinterpret_cast<probe_f32x4*>(a.dst + off + q * step) = v[q];
+          for (int q = 0; q < kProbeInFlight; ++q) {
+            probe_u32x4 t; t.x = __float_as_uint(v[q].x); t.y = __float_as_uint(v[q].y); t.z = __float_as_uint(v[q].z); t.w = __float_as_uint(v[q].w);
+            __builtin_amdgcn_raw_buffer_store_b128(t, rd, o32 + (uint32_t)(q * step), 0, 0);
+          }
         } else {
 #pragma unroll
           for (int q = 0; q < kProbeInFlight; ++q)

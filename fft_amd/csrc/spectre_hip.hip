@@ -534,7 +534,11 @@ struct DeviceGuard {
 // Built for fp32 rows without memory_fft; the mailboxes of n_wg / gang gangs and one claim bit per tile have to fit the slice.
 bool p64_tickets(const SpectreMixArgs* a, const Plan* plan, int n_tiles, int n_wg, int gang) {
   static const bool off = [] { const char* e = tuning_env("SPECTRE_P64_TICKETS"); return e && atoi(e) == 0; }();
+#ifdef SPECTRE_P64_LEGACY
   static const bool burst_off = [] { const char* e2 = tuning_env("SPECTRE_P64_BURST"); return e2 && atoi(e2) == 0; }();
+#else
+  constexpr bool burst_off = false;
+#endif
   // (whether an eligible launch then TAKES the ticket order is measured per tensor pair: choose_tile_order.  fp32 rows -3 ... -5 % on slow-class
   //  pairs, +2 ... +6 % on fast ones; bf16 rows in / fp32 out -0.2 ... -3.5 %; bf16 rows out +-0.8 %)
   return plan->tk_ring && !off && !burst_off && !a->mem && n_tiles <= sfft::p64_ticket_capacity() &&
@@ -629,7 +633,10 @@ Plan::OrderEntry* order_entry(const SpectreMixArgs* a, const Plan* plan, bool pe
 }
 
 // Which order does THIS launch take (1 = tickets), and does it carry an event pair (returned in *ev, recorded by the caller around the launch)?
-int choose_tile_order(const SpectreMixArgs* a, const Plan* plan, bool capturing, Plan::OrderPending* ev, bool* timed) {
+// dflt = the order this kernel takes until (and unless) the other one has measured at least 1 % faster: tickets at n_fft = 4096 (-3 ... -5 % on
+// typical buffers, fp32 rows; bf16 rows in -0.2 ... -4.4 %), the static map for the persistent mixed-radix lengths (3000: tickets -4.5 % on one box
+// of six, +1.4 ... +5.3 % on the others)
+int choose_tile_order(const SpectreMixArgs* a, const Plan* plan, bool capturing, int dflt, Plan::OrderPending* ev, bool* timed) {
   *timed = false;
   const int pol = tile_order_policy(plan);
   if (pol == SPECTRE_ORDER_STATIC) return 0;
@@ -639,7 +646,7 @@ int choose_tile_order(const SpectreMixArgs* a, const Plan* plan, bool capturing,
   Plan::OrderEntry* en = order_entry(a, plan, per_pair, true);
   // a stream that is being captured: no event calls at all (a query of an outside event during the capture left the captured launch
   // without its slice reset on replay); the decision so far, or tickets
-  if (capturing) return en->decided >= 0 ? en->decided : 1;
+  if (capturing) return en->decided >= 0 ? en->decided : dflt;
   if (en->decided >= 0) return en->decided;
   RelaxedCapture rc;
   // harvest what has finished (in issue order; nothing waits)
@@ -655,26 +662,26 @@ int choose_tile_order(const SpectreMixArgs* a, const Plan* plan, bool capturing,
   (void)hipGetLastError();                         // (hipEventQuery's hipErrorNotReady is not an error of ours)
   if (en->samples[0] >= 8 && en->samples[1] >= 8) {
     for (int m = 0; m < 2; ++m) { float t[7]; memcpy(t, en->ms[m] + 1, sizeof t); std::sort(t, t + 7); en->med[m] = t[3]; }
-    en->decided = en->med[0] < kOrderMargin * en->med[1] ? 0 : 1;
+    en->decided = en->med[1 - dflt] < kOrderMargin * en->med[dflt] ? 1 - dflt : dflt;
     snprintf(en->name, sizeof en->name, "%s:%s (%.4f ms against %.4f)", per_pair ? "pair" : "auto", en->decided ? "tickets" : "static", en->med[en->decided], en->med[1 - en->decided]);
     return en->decided;
   }
-  if (++en->launches <= kOrderWarmLaunches) return 1;
+  if (++en->launches <= kOrderWarmLaunches) return dflt;
   // measuring: T S S T T S S T T S S T T S S T, eight timed launches per order
   const int k = en->issued[0] + en->issued[1];
   const int mode = (k & 3) == 0 || (k & 3) == 3 ? 1 : 0;
   if (k >= 16) {
     // every sample is issued; if they do not all come back (a failed event: fewer than 8 samples an order) the class keeps the default
-    if (en->pending.empty()) { en->decided = 1; snprintf(en->name, sizeof en->name, "%s:tickets (default: %d + %d samples)", per_pair ? "pair" : "auto", en->samples[1], en->samples[0]); }
-    return 1;
+    if (en->pending.empty()) { en->decided = dflt; snprintf(en->name, sizeof en->name, "%s:%s (default: %d + %d samples)", per_pair ? "pair" : "auto", dflt ? "tickets" : "static", en->samples[1], en->samples[0]); }
+    return dflt;
   }
   if (plan->explore_spent >= kOrderExploreCap) {   // this plan has measured enough: the default for whatever is still undecided
-    en->decided = 1; snprintf(en->name, sizeof en->name, "%s:tickets (default: measuring budget spent)", per_pair ? "pair" : "auto");
+    en->decided = dflt; snprintf(en->name, sizeof en->name, "%s:%s (default: measuring budget spent)", per_pair ? "pair" : "auto", dflt ? "tickets" : "static");
     order_entry_drop(*en);
-    return 1;
+    return dflt;
   }
-  if (hipEventCreate(&ev->e0) != hipSuccess) { (void)hipGetLastError(); return 1; }
-  if (hipEventCreate(&ev->e1) != hipSuccess) { (void)hipEventDestroy(ev->e0); (void)hipGetLastError(); return 1; }
+  if (hipEventCreate(&ev->e0) != hipSuccess) { (void)hipGetLastError(); return dflt; }
+  if (hipEventCreate(&ev->e1) != hipSuccess) { (void)hipEventDestroy(ev->e0); (void)hipGetLastError(); return dflt; }
   ev->mode = mode;
   ++en->issued[mode];
   ++plan->explore_spent;
@@ -703,7 +710,7 @@ const char* tile_order_name(const SpectreMixArgs* a, const Plan* plan) {
 
 // One ticket launch's bookkeeping, shared by the 4096 kernel and the persistent mixed-radix kernels: the order of this launch, its slice
 // (reset on the launch's own stream), the event pair of a measured launch.  Returns the slice (nullptr: static map).
-int ticket_launch_begin(const SpectreMixArgs* a, const Plan* plan, hipStream_t stream, size_t slice_words, size_t used_bytes, Plan::OrderPending* ev, bool* timed, unsigned** slice) {
+int ticket_launch_begin(const SpectreMixArgs* a, const Plan* plan, hipStream_t stream, int dflt, size_t slice_words, size_t used_bytes, Plan::OrderPending* ev, bool* timed, unsigned** slice) {
   *slice = nullptr;
   bool capturing;
   { RelaxedCapture rc; capturing = stream_capturing(stream); }
@@ -711,7 +718,7 @@ int ticket_launch_begin(const SpectreMixArgs* a, const Plan* plan, hipStream_t s
     std::lock_guard<std::mutex> lk(plan->order_mu);
     if (plan->slices_used >= kTicketSlices && (capturing || !plan->slice_of_stream.count(stream))) return SPECTRE_OK;
   }
-  const int tickets = choose_tile_order(a, plan, capturing, ev, timed);
+  const int tickets = choose_tile_order(a, plan, capturing, dflt, ev, timed);
   if (*timed) (void)hipEventRecord(ev->e0, stream);
   if (!tickets) return SPECTRE_OK;
   unsigned* sl = take_slice(plan, stream, capturing, slice_words);
@@ -751,7 +758,11 @@ int launch(const SpectreMixArgs* a, const Plan* plan, const Choice& c, bool conj
       static const int forced = [] { const char* e = tuning_env("SPECTRE_P64_TPW"); return e ? atoi(e) : 0; }();
       // round 4: store burst behind a workgroup barrier + phased I/O + requests spread over the arithmetic — every variant (fp32 rows,
       // bf16 rows in and / or out, memory_fft).  SPECTRE_P64_BURST=0: the round-3 order (tuning aid)
+#ifdef SPECTRE_P64_LEGACY
       static const bool burst_off = [] { const char* e2 = tuning_env("SPECTRE_P64_BURST"); return e2 && atoi(e2) == 0; }();
+#else
+      constexpr bool burst_off = false;   // (the round-3 order is built only with -DSPECTRE_P64_LEGACY: regtile_n4096p.hip)
+#endif
       const int gang = (ib || ob) ? 4 : 2;   // = p64_gang() of kernel_regtile64p.h: workgroups that walk in step
       const int slots = std::max(gang, ncu / gang * gang);
       k.tpw = forced > 0 ? forced : std::max(1, (k.n_tiles + slots - 1) / slots);
@@ -760,7 +771,7 @@ int launch(const SpectreMixArgs* a, const Plan* plan, const Choice& c, bool conj
       Plan::OrderPending ev{}; bool timed = false;
       if (p64_tickets(a, plan, k.n_tiles, k.n_wg, gang)) {
         unsigned* slice = nullptr;
-        if (int rc = ticket_launch_begin(a, plan, stream, sfft::kP64TkSliceWords, ((size_t)sfft::kP64TkClaim + (size_t)(k.n_tiles + 31) / 32) * 4, &ev, &timed, &slice)) return rc;
+        if (int rc = ticket_launch_begin(a, plan, stream, 1, sfft::kP64TkSliceWords, ((size_t)sfft::kP64TkClaim + (size_t)(k.n_tiles + 31) / 32) * 4, &ev, &timed, &slice)) return rc;
         k.tickets = slice;
       }
       e = sfft::launch_regtile64p(k, ib, ob, !burst_off, stream);
@@ -774,7 +785,7 @@ int launch(const SpectreMixArgs* a, const Plan* plan, const Choice& c, bool conj
       Plan::OrderPending ev{}; bool timed = false;
       if (mixedp_tickets(a, plan, k.n_tiles, k.n_wg)) {      // round 5: dynamic tile order, as at 4096
         unsigned* slice = nullptr;
-        if (int rc = ticket_launch_begin(a, plan, stream, sfft::kTkSliceWords, ((size_t)sfft::kTkClaim + (size_t)(k.n_tiles + 31) / 32) * 4, &ev, &timed, &slice)) return rc;
+        if (int rc = ticket_launch_begin(a, plan, stream, 0, sfft::kTkSliceWords, ((size_t)sfft::kTkClaim + (size_t)(k.n_tiles + 31) / 32) * 4, &ev, &timed, &slice)) return rc;
         k.tickets = slice;
       }
       e = n == 3000 ? sfft::launch_regtile_mixedp<60, 50>(k, stream) : n == 2560 ? sfft::launch_regtile_mixedp<64, 40>(k, stream)

@@ -274,13 +274,88 @@ def lint_addtid(name, blocks):
     return errors, [f"{name}: {n} ds_write_addtid_b32, each behind its own s_mov_b32 m0; no other use of M0"]
 
 
+# ---- serialised global loads -------------------------------------------------------------------------------------------------------
+# hipcc sometimes turns a run of independent loads (each unpacked or range-checked right behind it) into `load ; s_waitcnt vmcnt(0)`
+# pairs: one memory request in flight per wave, a 2 x slowdown that no parity test can see (round 3: the bf16 loads of five mixed-radix
+# lengths and of the bf16 gate gradient).  Rounds 3-5 guarded against it with a TIMING test on the GPU (bf16 rows must not take 1.4 x the
+# fp32 rows' time); since round 6 the listing itself is checked at build time: the longest run of loads that are each followed by a full
+# vmcnt(0) wait before the next load, per kernel.  KNOWN_SERIAL_RUNS = what the shipped listings contain today (secondary kernels: padded
+# N = 2000, bf16 memory_fft mode at 640, the sweep of the mixed-radix ticket forms); a run of 8 or more anywhere else fails the build.
+_LOAD = re.compile(r"^\s*(global_load|buffer_load|flat_load)_\w+\s")
+_IS_LDS_DMA = re.compile(r"\blds\s*$")
+_WAIT0 = re.compile(r"^\s*s_waitcnt\b.*vmcnt\(0\)")
+_KERNEL = re.compile(r"^(_Z\w+):\s*;\s*@")
+SERIAL_MIN_RUN = 8
+SERIAL_EXEMPT = ("stockham",)                          # the general LDS fallback (kernel_stockham.h, the two-pass gate gradient): its global loads
+                                                       # are twiddle / chirp look-ups inside unrolled radix loops, consumed where they are requested
+KNOWN_SERIAL_RUNS = {                                  # mangled-name substring -> longest run accepted
+    # the ticket protocol's own loads (first two tickets of a gang, the sweep: each depends on the one before; not on the data path)
+    "spectre_mix_regtile64pILi3ELi3ELb0ELb0ELb0ELb1ELb1ELi1E": 10,
+    "spectre_mix_regtile64pILi5ELi3ELb0ELb1ELb0ELb1ELb1ELi1E": 10,
+    "spectre_mix_regtile64pILi5ELi3ELb0ELb1ELb1ELb1ELb1ELi1E": 13,
+    "spectre_mix_regtile_mixedpILi64ELi60ELi22ELb0ELi16ELi8ELb1E": 13,
+    "spectre_mix_regtile_mixedpILi64ELi48ELi22ELb0ELi16ELi8ELb1E": 13,
+    "spectre_mix_regtile_mixedpILi60ELi60ELi28ELb0ELi16ELi8ELb1E": 13,
+    "spectre_mix_regtile_mixedpILi60ELi50ELi28ELb0ELi16ELi8ELb1E": 13,
+    # secondary kernels (performance debt, not correctness): padded rows at n_fft = 2000, bf16 rows + memory_fft at 640
+    "spectre_mix_regtile_mixedILi50ELi40ELb0ELb0ELi3E": 26,
+    "spectre_mix_regtile_mixedILi32ELi20ELb1ELb1ELi2E": 22,
+}
+
+
+def serial_load_runs(asm_path):
+    """{kernel: longest run of `load ; s_waitcnt vmcnt(0)` pairs} for every kernel of a listing (LDS-DMA requests are not loads here)."""
+    out, cur, run, best, pending = {}, None, 0, 0, False
+    for line in open(asm_path):
+        m = _KERNEL.match(line)
+        if m:
+            if cur:
+                out[cur] = best
+            cur, run, best, pending = m.group(1), 0, 0, False
+            continue
+        if cur is None:
+            continue
+        if line.startswith(".Lfunc_end"):
+            out[cur] = best
+            cur = None
+            continue
+        if _LOAD.match(line) and not _IS_LDS_DMA.search(line.split(";")[0]):
+            if pending:                                # two loads without a full wait in between: the run is broken
+                run = 0
+            pending = True
+        elif _WAIT0.match(line):
+            if pending:
+                run += 1
+                best = max(best, run)
+                pending = False
+    if cur:
+        out[cur] = best
+    return out
+
+
+def lint_serial_loads(asm_path, min_run=SERIAL_MIN_RUN, known=None):
+    known = KNOWN_SERIAL_RUNS if known is None else known
+    errors, notes = [], []
+    for name, best in serial_load_runs(asm_path).items():
+        if best < min_run or any(x in name for x in SERIAL_EXEMPT):
+            continue
+        allowed = max([v for k, v in known.items() if k in name] or [0])
+        if best > allowed:
+            errors.append(f"{name}: {best} global loads each behind its own s_waitcnt vmcnt(0) (one request in flight per wave)"
+                          + (f"; the known run of this kernel is {allowed}" if allowed else ""))
+        else:
+            notes.append(f"{name}: known serialised run of {best} loads (accepted: {allowed})")
+    return errors, notes
+
+
 def lint_listing(asm_path, vmcnt_kernel=None, lds_kernel=None):
     """Every check that applies to one gfx950 listing (hipcc -S, or the .s that -save-temps leaves behind) -> (errors, notes).
 
     * every kernel that contains a `ds_write_addtid_b32` gets the M0 check (no name filter: all mixed-radix forward and gate-gradient
       kernels use those asm statements, ADVICE r03);
-    * kernels whose name contains `vmcnt_kernel` get the hand-counted-guard check, those containing `lds_kernel` the untracked-read check."""
-    errors, notes = [], []
+    * kernels whose name contains `vmcnt_kernel` get the hand-counted-guard check, those containing `lds_kernel` the untracked-read check;
+    * every kernel: no run of SERIAL_MIN_RUN or more serialised global loads beyond KNOWN_SERIAL_RUNS."""
+    errors, notes = lint_serial_loads(asm_path)
     for name, blocks in parse_kernels(asm_path).items():
         if any(x.op == "ds_write_addtid_b32" for b in blocks for x in b["ins"]):
             e, n = lint_addtid(name, blocks)

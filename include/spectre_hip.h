@@ -107,10 +107,11 @@ int spectre_plans_release_retired(int device);
  * tiles in address order: the chip then works on a few neighbouring batch elements at a time).  Same bits either way; which one is faster
  * depends on where the driver has placed the two tensors: tickets by 3-5 % on typical buffers, the static map by
  * 2-6 % on some.
- *   SPECTRE_ORDER_AUTO       (default) tickets from the first launch; behind 24 launches of a shape class (B, N_in, D, dtypes, strides — no
- *                            pointers) sixteen launches are timed with HIP events on the caller's stream (nothing waits, nothing under
- *                            stream capture), and the class moves to the static map only if that measures at least 1 % faster.  One
- *                            decision per class; spectre_mix_describe ends in `order=auto`, later `order=auto:tickets (...)` / `auto:static (...)`
+ *   SPECTRE_ORDER_AUTO       (default) the kernel's own default from the first launch (tickets at n_fft = 4096, the static map at 3000 /
+ *                            3600 / 3840); behind 24 launches of a shape class (B, N_in, D, dtypes, strides — no pointers) sixteen launches
+ *                            are timed with HIP events on the caller's stream (nothing waits, nothing under stream capture), and the class
+ *                            moves to the other order only if that measures at least 1 % faster.  One decision per class;
+ *                            spectre_mix_describe ends in `order=auto`, later `order=auto:tickets (...)` / `auto:static (...)`
  *   SPECTRE_ORDER_STATIC / SPECTRE_ORDER_TICKETS   pinned: no event calls at all on the launch path
  *   SPECTRE_ORDER_AUTO_PAIR  the same measurement per (v, out) POINTER pair as well (worth it where a process keeps a few long-lived
  *                            buffers; an LRU of 64 pairs, at most 1024 timed launches per plan)

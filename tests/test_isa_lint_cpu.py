@@ -208,3 +208,52 @@ def test_compiler_setting_m0_for_an_lds_dma_next_to_addtid_passes(tmp_path):
 def test_compiler_reading_m0_next_to_addtid_fails(tmp_path):
     errors, _ = run_addtid(tmp_path, addtid_listing(compiler_reads_m0=True))
     assert errors and "uses M0" in errors[0]
+
+
+# ---- serialised global loads (round 6: replaces the timing asserts of tests/test_perf_sanity_gpu.py) ----------------------------------
+def _serial_listing(n_pairs, name="_ZN4sfft9some_kernILi1EEEvNS_11RegtileArgsE", lds_dma=False):
+    body = []
+    for i in range(n_pairs):
+        body.append(f"\tglobal_load_dword v{i}, v[100:101], off" + (" lds" if lds_dma else ""))
+        body.append("\ts_waitcnt vmcnt(0)")
+        body.append(f"\tv_lshlrev_b32_e32 v{i}, 16, v{i}")
+    return f"{name}:                     ; @{name}\n" + "\n".join(body) + "\n\ts_endpgm\n.Lfunc_end0:\n"
+
+
+def test_serialised_loads_fail_and_overlapped_loads_pass(tmp_path):
+    bad = tmp_path / "bad.s"
+    bad.write_text(_serial_listing(9))
+    assert isa_lint.serial_load_runs(str(bad)) == {"_ZN4sfft9some_kernILi1EEEvNS_11RegtileArgsE": 9}
+    errors, _ = isa_lint.lint_serial_loads(str(bad))
+    assert errors and "one request in flight" in errors[0]
+    ok = tmp_path / "ok.s"
+    ok.write_text(_serial_listing(7))                                     # below the threshold
+    assert isa_lint.lint_serial_loads(str(ok)) == ([], [])
+    # sixteen loads in flight, ONE wait: not a run
+    name = "_ZN4sfft9some_kernILi2EEEvNS_11RegtileArgsE"
+    flight = f"{name}:                     ; @{name}\n" + "\n".join(f"\tglobal_load_dword v{i}, v[100:101], off" for i in range(16)) + "\n\ts_waitcnt vmcnt(0)\n\ts_endpgm\n.Lfunc_end1:\n"
+    fl = tmp_path / "flight.s"
+    fl.write_text(flight)
+    assert isa_lint.serial_load_runs(str(fl))[name] == 1
+    dma = tmp_path / "dma.s"
+    dma.write_text(_serial_listing(12, lds_dma=True))                     # LDS-DMA requests are not loads into registers
+    assert isa_lint.lint_serial_loads(str(dma)) == ([], [])
+
+
+def test_known_serial_runs_are_accepted_up_to_their_length(tmp_path):
+    known = next(iter(isa_lint.KNOWN_SERIAL_RUNS.items()))
+    name = "_ZN4sfft22" + known[0] + "EEvNS_11RegtileArgsE"
+    f = tmp_path / "k.s"
+    f.write_text(_serial_listing(known[1], name=name))
+    errors, notes = isa_lint.lint_serial_loads(str(f))
+    assert not errors and notes
+    f.write_text(_serial_listing(known[1] + 1, name=name))
+    errors, _ = isa_lint.lint_serial_loads(str(f))
+    assert errors and "known run" in errors[0]
+
+
+def test_lint_listing_runs_the_serial_check_on_every_kernel(tmp_path):
+    f = tmp_path / "unit.s"
+    f.write_text(_serial_listing(20))
+    errors, _ = isa_lint.lint_listing(str(f))
+    assert any("one request in flight" in e for e in errors)

@@ -167,8 +167,8 @@ def test_stalled_stream_busy_stream_and_graph_replay_never_share_a_slice():
             sa.wait_event(gate_ev)
             for _ in range(6):
                 outs_a.append(spectral_mix(Va, ga, None, 4096))
-        out_g.zero_()
         with torch.cuda.stream(sg):
+            out_g.zero_()                                        # (on the replay's stream: ordered in front of it)
             sg.wait_event(gate_ev)
             graph.replay()
         with torch.cuda.stream(sb):                              # far more launches than there are slices, before / while A and the graph run

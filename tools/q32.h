@@ -82,7 +82,9 @@ __device__ __forceinline__ void q32_fftB(float2 (&z)[32]) {
   static_for<0, 8>([&](auto nc) { constexpr int nlo = decltype(nc)::value; fftB_stage2_group<4, 8, INV, nlo>(z); q32_pin<nlo, 8, 4>(z); __builtin_amdgcn_sched_barrier(0); });
 }
 
-// VARIANT 0: DPP through __builtin_amdgcn_update_dpp (version 0's code);  1: the cross-lane steps as single v_fmac_f32_dpp
+// VARIANT bit 0: the cross-lane steps as single v_fmac_f32_dpp (0: through __builtin_amdgcn_update_dpp, version 0's code);
+// ablations (wrong results, timing only): bit 1 = no LDS exchange traffic (the barriers stay), bit 2 = no in-register transforms / twiddles /
+// gate (the exchanges, the cross-lane steps' data flow and every request stay)
 // Persistent: workgroup w (XCD-contiguous, pairs on adjacent tiles like kernel_regtile64p.h) walks through a.tpw tiles; NOT pipelined:
 // every tile is loaded, transformed and stored before the next one is requested (the next tile's gate bins travel in 3 registers).
 template <int VARIANT = 0>
@@ -215,8 +217,8 @@ __global__ void __launch_bounds__(1024) spectre_mix_q32(const RegtileArgs a) {
     });
 
     // ---- F1: 32-point forward over n1 (type A: k1 = ka + 4 kb at position 8 ka + kb), then W_N^(n2 k1)
-    q32_fftA<false>(z);
-    {
+    if constexpr (!(VARIANT & 4)) q32_fftA<false>(z);
+    if constexpr (!(VARIANT & 4)) {
       float2 wa[4], wb[8];
       static_for<1, 4>([&](auto jc) { wa[decltype(jc)::value] = twl[n2 * 10 + decltype(jc)::value - 1]; });
       static_for<1, 8>([&](auto jc) { wb[decltype(jc)::value] = twl[n2 * 10 + 2 + decltype(jc)::value]; });
@@ -230,32 +232,32 @@ __global__ void __launch_bounds__(1024) spectre_mix_q32(const RegtileArgs a) {
     }
     // ---- E1
     q32_barrier();                                   // the image is free (E2 of the previous tile has been read), the gate is in place
-    write_rows(std::false_type{});
+    if constexpr (!(VARIANT & 2)) write_rows(std::false_type{});
     q32_barrier();
-    read_run(std::false_type{});
+    if constexpr (!(VARIANT & 2)) read_run(std::false_type{});
     q32_barrier();
-    write_rows(std::true_type{});
+    if constexpr (!(VARIANT & 2)) write_rows(std::true_type{});
     q32_barrier();
-    read_run(std::true_type{});
+    if constexpr (!(VARIANT & 2)) read_run(std::true_type{});
     // (the image stays busy until the barrier in front of E2's first write)
 
     // ---- F2: radix-4 across the quad (input lane L holds n2 = m + 32 L), per-lane twiddle, 32-point forward over m
     static_for<0, 32>([&](auto mc) {
       constexpr int m = decltype(mc)::value;
       float x = z[m].x, y = z[m].y;
-      if constexpr (VARIANT == 0) {
+      if constexpr ((VARIANT & 1) == 0) {
         x = __builtin_fmaf(q32_dpp<kQuadX2>(x), tA, x);               // L0: s0, L1: s1, L2: -d0, L3: -d1
         y = __builtin_fmaf(q32_dpp<kQuadX2>(y), tA, y);
       } else { x = q32_fmac_x2(x, tA); y = q32_fmac_x2(y, tA); }
       float rx = l3 ? y : x, ry = l3 ? -x : y;                        // lane 3: * (-i)
-      if constexpr (VARIANT == 0) {
+      if constexpr ((VARIANT & 1) == 0) {
         x = __builtin_fmaf(q32_dpp<kQuadX1>(rx), tB, rx);             // L0: C0, L1: -C2, L2: -C1, L3: C3
         y = __builtin_fmaf(q32_dpp<kQuadX1>(ry), tB, ry);
       } else { x = q32_fmac_x1(rx, tB); y = q32_fmac_x1(ry, tB); }
       z[m] = cmul(make_float2(x, y), ltw[L * 34 + m]);                // (signs included in the table)
       if constexpr (m % 8 == 7) __builtin_amdgcn_sched_barrier(0);
     });
-    q32_fftA<false>(z);                                             // bins k2 = 4 k2'' + q_L, k2'' = ka + 4 kb at position 8 ka + kb
+    if constexpr (!(VARIANT & 4)) q32_fftA<false>(z);                      // bins k2 = 4 k2'' + q_L, k2'' = ka + 4 kb at position 8 ka + kb
 
     // ---- gate (spectre.py:545): k = k1 + 32 q_L + 128 k2''; above N/2 the Hermitian extension
     {
@@ -275,17 +277,17 @@ __global__ void __launch_bounds__(1024) spectre_mix_q32(const RegtileArgs a) {
     }
 
     // ---- I1: 32-point inverse over k2'' (type B: m at position m), conj twiddle, radix-4 across the quad -> lane L holds n2 = m + 32 L
-    q32_fftB<true>(z);
+    if constexpr (!(VARIANT & 4)) q32_fftB<true>(z);
     static_for<0, 32>([&](auto mc) {
       constexpr int m = decltype(mc)::value;
       const float2 t = cmulc(z[m], ltw[L * 34 + m]);                // L0: P0, L1: -P2, L2: -P1, L3: P3
       float x = t.x, y = t.y;
-      if constexpr (VARIANT == 0) {
+      if constexpr ((VARIANT & 1) == 0) {
         x = __builtin_fmaf(q32_dpp<kQuadX1>(x), -tB, x);              // L0: a, L1: b, L2: -c, L3: -e
         y = __builtin_fmaf(q32_dpp<kQuadX1>(y), -tB, y);
       } else { x = q32_fmac_x1(x, -tB); y = q32_fmac_x1(y, -tB); }
       float rx = l3 ? -y : x, ry = l3 ? x : y;                        // lane 3: * (+i)
-      if constexpr (VARIANT == 0) {
+      if constexpr ((VARIANT & 1) == 0) {
         x = __builtin_fmaf(q32_dpp<kQuadX2>(rx), -tA, rx);            // y[m + 32 L]
         y = __builtin_fmaf(q32_dpp<kQuadX2>(ry), -tA, ry);
       } else { x = q32_fmac_x2(rx, -tA); y = q32_fmac_x2(ry, -tA); }
@@ -295,13 +297,13 @@ __global__ void __launch_bounds__(1024) spectre_mix_q32(const RegtileArgs a) {
 
     // ---- E2: the same image addresses the other way round
     q32_barrier();                                                   // every wave has finished E1's reads
-    write_run(std::false_type{});
+    if constexpr (!(VARIANT & 2)) write_run(std::false_type{});
     q32_barrier();
-    read_rows(std::false_type{});
+    if constexpr (!(VARIANT & 2)) read_rows(std::false_type{});
     q32_barrier();
-    write_run(std::true_type{});
+    if constexpr (!(VARIANT & 2)) write_run(std::true_type{});
     q32_barrier();
-    read_rows(std::true_type{});
+    if constexpr (!(VARIANT & 2)) read_rows(std::true_type{});
 
     // ---- conj twiddle, I2 (type B inverse: n1 at position n1), stores (spectre.py:553)
     {
@@ -316,7 +318,7 @@ __global__ void __launch_bounds__(1024) spectre_mix_q32(const RegtileArgs a) {
         });
       });
     }
-    q32_fftB<true>(z);
+    if constexpr (!(VARIANT & 4)) q32_fftB<true>(z);
     const uint32_t ooff = (uint32_t)(((long long)(n2 + 128 * h) * out_sn + 4 * pp) * 4);
     static_for<0, 16>([&](auto rc) {
       constexpr int r = decltype(rc)::value;

@@ -92,6 +92,9 @@ int main(int argc, char** argv) {
   add("16 waves: persistent, NOT pipelined, builtin DPP, NO TRAFFIC", q32(dry, spectre_mix_q32<0>, 48), false);
   add("16 waves: persistent, NOT pipelined, fmac_dpp", q32(la, spectre_mix_q32<1>, 48));
   add("16 waves: persistent, NOT pipelined, fmac_dpp, NO TRAFFIC", q32(dry, spectre_mix_q32<1>, 48), false);
+  add("16 waves: ... NO TRAFFIC, no LDS exchange traffic (arithmetic + barriers)", q32(dry, spectre_mix_q32<3>, 48), false);
+  add("16 waves: ... NO TRAFFIC, no transforms (exchanges + cross-lane + gate)", q32(dry, spectre_mix_q32<5>, 48), false);
+  add("16 waves: ... NO TRAFFIC, neither (barriers, cross-lane steps, gate)", q32(dry, spectre_mix_q32<7>, 48), false);
 #ifdef Q32P
 #include "q32p_variants.inc"
 #endif
