@@ -17,6 +17,6 @@ timeout 600 rocprofv3 --output-format csv --pmc TCC_NORMAL_WRITEBACK_sum TCC_HIT
 timeout 600 rocprofv3 --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT -d $OUT/pmc_sq -o pmc -- $RUN > $OUT/pmc_sq.log 2>&1
 cd $REPO
 python tools/summarize_prof.py $OUT > $OUT/summary/summary.txt 2>&1
-python tools/collect_pmc.py $OUT f32 256,4096,768 "spectre_mix_regtile64p<3, 3, false, false, false, true, true" > $OUT/summary/pmc_latest.log 2>&1
+python tools/collect_pmc.py $OUT f32 256,4096,768 "spectre_mix_regtile64p<3, 3, false, false, false, true, true, 1>" > $OUT/summary/pmc_latest.log 2>&1
 tail -3 $OUT/summary/pmc_latest.log
 head -40 $OUT/summary/summary.txt

@@ -44,9 +44,9 @@ struct LabArgs {
   unsigned* counter;            // [0..7] counters (16 words apart), mailbox from word 256: [gang][slot 0..15]
 };
 
-template <int MAP, int SEG, int U = 8>
+template <int MAP, int SEG, int U = 8, int GX = 0>
 __global__ void __launch_bounds__(512) wl_tile(const LabArgs a) {
-  constexpr int THREADS = 512, GANG = 128 / SEG, LPS = SEG / 16, RPI = THREADS / LPS;
+  constexpr int THREADS = 512, GANG = GX ? GX : 128 / SEG, LPS = SEG / 16, RPI = THREADS / LPS;
   const int tid = threadIdx.x;
   const long long lane_off = (long long)(tid / LPS) * a.row_bytes + (tid % LPS) * 16;
   const long long step = (long long)RPI * a.row_bytes;
@@ -222,14 +222,14 @@ int main(int argc, char** argv) {
   if (wanted("flat load")) report("flat load", time([&] { hipLaunchKernelGGL(wl_flat_load, fg, dim3(256), 0, 0, (const f4*)a, (f4*)b); }), 1.0 * bytes);
   if (wanted("flat store")) report("flat store", time([&] { hipLaunchKernelGGL(wl_flat_store, fg, dim3(256), 0, 0, (f4*)b); }), 1.0 * bytes);
 
-  auto run = [&](auto kern, const char* name, int seg, bool dyn, int mode) {
+  auto run = [&](auto kern, const char* name, int seg, bool dyn, int mode, int gx = 0) {
     char full[96];
     static const char* moden[3] = {"copy", "load", "store"};
     snprintf(full, sizeof full, "seg %3d %-26s %s", seg, name, moden[mode]);
     if (!wanted(full)) return;
     LabArgs x{};
     x.src = a; x.dst = b; x.row_bytes = row_bytes; x.tile_rows = 4096; x.mode = mode;
-    const int gang = 128 / seg;
+    const int gang = gx ? gx : 128 / seg;
     x.cols = (int)(row_bytes / seg); x.n_tiles = (int)(rows / 4096) * x.cols;
     const int slots = cus / gang * gang;
     x.tpw = (x.n_tiles + slots - 1) / slots;
@@ -261,6 +261,12 @@ int main(int argc, char** argv) {
   }
   // round 6: how many requests should a lane keep in flight?  (the masked C4 probe of rounds 4-5 had ONE per wave — hipcc had serialised its
   // predicated loads — and was 25 % FASTER than the same copy with sixteen)
+  // round 6: one ticket per FOUR / EIGHT workgroups = 2 / 4 adjacent lines of a row (64-byte tiles)
+  for (int mode : {0, 1, 2}) {
+    run(wl_tile<DYNG, 64, 8, 4>, "ticket per 4 wgs (2 lines)", 64, true, mode, 4);
+    run(wl_tile<DYNG, 64, 8, 8>, "ticket per 8 wgs (4 lines)", 64, true, mode, 8);
+    run(wl_tile<DYNG, 64, 4, 4>, "ticket per 4 wgs, 4 in flight", 64, true, mode, 4);
+  }
   for (int mode : {0, 1, 2}) {
     run(wl_tile<FAR, 64, 1>, "static far, 1 in flight", 64, false, mode);
     run(wl_tile<FAR, 64, 2>, "static far, 2 in flight", 64, false, mode);
