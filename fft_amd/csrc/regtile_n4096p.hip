@@ -31,8 +31,9 @@ hipError_t launch_regtile64p(const RegtileArgs& a, bool in_bf16, bool out_bf16, 
 
   // round 5: DYNAMIC tile tickets per gang (a.tickets = this launch's zeroed slice of the plan's ticket ring; spectre_hip.hip decides):
   // the chip-wide window of open rows shrinks from every batch element to a few (kernel_regtile64p.h, TICKETS)
-  const bool tickets = a.tickets != nullptr && burst && !with_mem;
+  const bool tickets = a.tickets != nullptr && burst && !(with_mem && in_bf16);
   if (tickets && !in_bf16) kern = spectre_mix_regtile64p<3, 3, false, false, false, true, true, true>;
+  if (tickets && !in_bf16 && with_mem) kern = spectre_mix_regtile64p<4, 1, true, false, false, true, true, true>;   // (round 6: memory_fft on the ticket order as well)
   if (tickets && in_bf16 && !out_bf16) kern = spectre_mix_regtile64p<5, 3, false, true, false, true, true, true>;
   if (tickets && in_bf16 && out_bf16) kern = spectre_mix_regtile64p<5, 3, false, true, true, true, true, true>;
 

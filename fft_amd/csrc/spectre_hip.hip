@@ -531,7 +531,7 @@ struct DeviceGuard {
 };
 
 // n_fft = 4096 pipelined kernel: does this launch take the dynamic tile order?  (SPECTRE_P64_TICKETS=0: the static map, tuning aid.)
-// Built for fp32 rows without memory_fft; the mailboxes of n_wg / gang gangs and one claim bit per tile have to fit the slice.
+// Built for every shipped form (round 6: memory_fft too); the mailboxes of n_wg / gang gangs and one claim bit per tile have to fit the slice.
 bool p64_tickets(const SpectreMixArgs* a, const Plan* plan, int n_tiles, int n_wg, int gang) {
   static const bool off = [] { const char* e = tuning_env("SPECTRE_P64_TICKETS"); return e && atoi(e) == 0; }();
 #ifdef SPECTRE_P64_LEGACY
@@ -541,7 +541,7 @@ bool p64_tickets(const SpectreMixArgs* a, const Plan* plan, int n_tiles, int n_w
 #endif
   // (whether an eligible launch then TAKES the ticket order is measured per tensor pair: choose_tile_order.  fp32 rows -3 ... -5 % on slow-class
   //  pairs, +2 ... +6 % on fast ones; bf16 rows in / fp32 out -0.2 ... -3.5 %; bf16 rows out +-0.8 %)
-  return plan->tk_ring && !off && !burst_off && !a->mem && n_tiles <= sfft::p64_ticket_capacity() &&
+  return plan->tk_ring && !off && !burst_off && !(a->mem && a->in_dtype == SPECTRE_BF16) && n_tiles <= sfft::p64_ticket_capacity() &&
          n_wg / gang <= (sfft::kP64TkClaim - sfft::kP64TkBox) / 8 && n_wg >= gang;
 }
 
@@ -610,7 +610,7 @@ void order_entry_drop(Plan::OrderEntry& en) { for (auto& pd : en.pending) { (voi
 
 Plan::OrderEntry* order_entry(const SpectreMixArgs* a, const Plan* plan, bool per_pair, bool create) {     // (plan->order_mu held)
   const uint64_t key[6] = {per_pair ? (uint64_t)(uintptr_t)a->v : 0, per_pair ? (uint64_t)(uintptr_t)a->out : 0, (uint64_t)a->B, (uint64_t)a->D,
-                           (uint64_t)a->N_in * 4 + (uint64_t)a->in_dtype * 2 + (uint64_t)a->out_dtype, (uint64_t)a->v_sn ^ ((uint64_t)a->out_sn << 32)};
+                           (uint64_t)a->N_in * 8 + (a->mem ? 4u : 0u) + (uint64_t)a->in_dtype * 2 + (uint64_t)a->out_dtype, (uint64_t)a->v_sn ^ ((uint64_t)a->out_sn << 32)};
   for (auto& en : plan->orders) if (en.pair == per_pair && !memcmp(en.key, key, sizeof key)) { en.last_use = ++plan->order_clock; return &en; }
   if (!create) return nullptr;
   // full: forget the entry of the same kind that has not been used for the longest time (its events with it)

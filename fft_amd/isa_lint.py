@@ -293,6 +293,7 @@ KNOWN_SERIAL_RUNS = {                                  # mangled-name substring 
     "spectre_mix_regtile64pILi3ELi3ELb0ELb0ELb0ELb1ELb1ELi1E": 10,
     "spectre_mix_regtile64pILi5ELi3ELb0ELb1ELb0ELb1ELb1ELi1E": 10,
     "spectre_mix_regtile64pILi5ELi3ELb0ELb1ELb1ELb1ELb1ELi1E": 13,
+    "spectre_mix_regtile64pILi4ELi1ELb1ELb0ELb0ELb1ELb1ELi1E": 13,
     "spectre_mix_regtile_mixedpILi64ELi60ELi22ELb0ELi16ELi8ELb1E": 13,
     "spectre_mix_regtile_mixedpILi64ELi48ELi22ELb0ELi16ELi8ELb1E": 13,
     "spectre_mix_regtile_mixedpILi60ELi60ELi28ELb0ELi16ELi8ELb1E": 13,

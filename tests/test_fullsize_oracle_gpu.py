@@ -86,6 +86,9 @@ def test_memory_fft_at_full_size_one_column_of_every_tile():
     mem = torch.randn(F, D, dtype=torch.complex64, device=DEV, generator=g) * 0.2
     out = torch.full((B, N, D), float("nan"), device=DEV)
     assert describe(V, gate, mem, N, out=out).startswith("regtile-pipelined 64x64")
+    want_order = os.environ.get("SPECTRE_EXPECT_ORDER")            # (round 6: memory_fft takes the ticket order too; pinned by the child runs below)
+    if want_order:
+        assert f"order={want_order}" in describe(V, gate, mem, N, out=out), describe(V, gate, mem, N, out=out)
     spectral_mix(V, gate, mem, N, out=out)
     torch.cuda.synchronize()
     tiles, d_g = D // 16, D // G
@@ -137,6 +140,6 @@ def test_every_tile_check_under_both_pinned_orders(order):
     pinned in turn (SPECTRE_TILE_ORDER is read once per process: child runs) and the persistent kernels' cases are checked again."""
     env = dict(os.environ, SPECTRE_TUNING="1", SPECTRE_TILE_ORDER=order, SPECTRE_EXPECT_ORDER=order)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider",
-                        "-k", "one_column_of_every_tile and (C2 or C4 or padded or truncated)"], env=env, capture_output=True, text=True, timeout=600,
+                        "-k", "one_column_of_every_tile and (C2 or C4 or padded or truncated or memory_fft)"], env=env, capture_output=True, text=True, timeout=600,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert r.returncode == 0 and "6 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-1000:]
+    assert r.returncode == 0 and "7 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-1000:]

@@ -41,6 +41,6 @@ def test_headline_shapes_name_their_shipped_instantiations():
     V = torch.zeros(2, 4096, 768, device=DEV)
     assert "order=" in describe(V, g, None, 4096)                    # the persistent kernel with a tile order
     mem = torch.zeros(2049, 768, dtype=torch.complex64, device=DEV)
-    assert describe(V, g, mem, 4096).endswith("order=static")        # memory_fft: static map
+    assert "order=" in describe(V, g, mem, 4096)                     # memory_fft: the same persistent kernel family (round 6: on tickets too)
     assert describe(V[:, :3000], g, None, 4096).startswith("regtile-pipelined")     # a padded sequence costs what a full one costs
     assert describe(V.to(torch.bfloat16), g, None, 4096, out_dtype=torch.float32).startswith("regtile-pipelined")

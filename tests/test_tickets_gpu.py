@@ -44,7 +44,7 @@ def test_describe_names_the_tile_order_and_the_order_is_measured_per_tensor_pair
     out = torch.empty_like(V)
     assert describe(V, gate, None, 4096, out=out).endswith("order=auto")                              # fp32 rows, fast mode: not measured yet
     mem = torch.randn(2049, 192, dtype=torch.complex64, device=DEV)
-    assert describe(V, gate, mem, 4096).endswith("order=static")                                     # memory_fft keeps the static map
+    assert describe(V, gate, mem, 4096).endswith("order=auto")                                       # memory_fft: its own class (round 6: eligible too)
     first = spectral_mix(V, gate, None, 4096).clone()
     seen = set()
     for i in range(60):
