@@ -484,6 +484,9 @@ def main():
                       "barrier (finish); roofline.kernel_ms = MAX over ranks of the HIP-event average of the K launches",
             "wall_s": wall,
             "wall_incl_closing_barrier_s": wall_old,
+            # rounds 1-4 defined `value` over the wall time INCLUDING the closing barrier: reported next to `value` so that round-over-round and
+            # N-GPU comparisons with those rounds stay like for like
+            "value_incl_closing_barrier": world * B * N * a.steps / wall_old,
             "per_rank": sorted(per_rank, key=lambda r: r["rank"]),
             **rdv.describe(),
         }

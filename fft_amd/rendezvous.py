@@ -18,6 +18,7 @@ Everything here runs without a GPU (the CPU-tier test drives a world of 2 over g
 from __future__ import annotations
 
 import datetime
+import socket
 import os
 import threading
 from dataclasses import dataclass, field
@@ -80,7 +81,10 @@ class Rendezvous:
         per-rank durations, the contract's figure, and it also counts a rank that started late).  Same dict on every rank except the
         two offsets, which are this rank's own."""
         last_end, neg_first_start, longest = self.max_over_ranks([t_end, -t_start, t_end - t_start])
-        return {"wall_s": last_end + neg_first_start, "max_rank_wall_s": longest,
+        # CLOCK_MONOTONIC is one clock for the processes of ONE node only: across nodes the stamps are not comparable and the window is the
+        # contract's MAX over ranks of the per-rank duration (ADVICE r05)
+        one_node = len({r.get("host") for r in self.ranks_seen}) <= 1
+        return {"wall_s": (last_end + neg_first_start) if one_node else longest, "max_rank_wall_s": longest, "single_node": one_node,
                 "start_after_first_us": (t_start + neg_first_start) * 1e6, "end_before_last_us": (last_end - t_end) * 1e6}
 
     def gather_over_ranks(self, obj) -> list:
@@ -130,10 +134,17 @@ def _prove_nccl(device, timeout_s: float):
     # own watchdog must not get there first: with the default TORCH_NCCL_ASYNC_ERROR_HANDLING a collective that exceeds the GROUP's timeout
     # makes the watchdog abort the whole PROCESS (SIGABRT) — before the "agree and fall back" step could run.  So: no
     # process-level handling (read when the group is constructed), no heartbeat monitor, and a group timeout far beyond the box.
-    os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
-    os.environ.setdefault("TORCH_NCCL_ENABLE_MONITORING", "0")
-    os.environ.setdefault("TORCH_NCCL_DUMP_ON_TIMEOUT", "0")
-    group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=max(1800.0, 20.0 * timeout_s)))
+    # The variables are read when the group is CONSTRUCTED, so they are set around new_group() only and put back afterwards:
+    # NCCL groups the host application creates later keep their watchdog.  (A caller-set value is respected: setdefault semantics.)
+    disarm = {"TORCH_NCCL_ASYNC_ERROR_HANDLING": "0", "TORCH_NCCL_ENABLE_MONITORING": "0", "TORCH_NCCL_DUMP_ON_TIMEOUT": "0"}
+    ours = [k for k in disarm if k not in os.environ]
+    for k in ours:
+        os.environ[k] = disarm[k]
+    try:
+        group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=max(1800.0, 20.0 * timeout_s)))
+    finally:
+        for k in ours:
+            os.environ.pop(k, None)
     dist.barrier(group=group, device_ids=[device.index])
     t = torch.tensor([float(dist.get_rank())], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
@@ -153,7 +164,7 @@ def rendezvous(world: int, rank: int, local_rank: int, *, prefer: str = "nccl", 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if not dist.is_initialized():
         dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=max(30.0, 2 * timeout_s)))
-    me = {"rank": rank, "local_rank": local_rank, "pid": os.getpid(), **_device_identity(device)}
+    me = {"rank": rank, "local_rank": local_rank, "pid": os.getpid(), "host": socket.gethostname(), **_device_identity(device)}
     seen: List[Optional[dict]] = [None] * world
     dist.all_gather_object(seen, me)
     seen = sorted(seen, key=lambda r: r["rank"])
