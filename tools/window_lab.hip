@@ -176,6 +176,66 @@ __global__ void __launch_bounds__(512) wl_pairx(const LabArgs a, char* scratch) 
   }
 }
 
+// wl_mixed<OVF>  (round 6) the I/O of the bf16-rows-in / fp32-rows-out kernel in copy form: a tile = 16 channels x 4096 rows = 32 bytes per row of
+// the bf16 source (row stride 1536) and 64 bytes per row of the fp32 destination (row stride 3072).  OVF = 0: what the product does — one ticket
+// per QUAD of workgroups, 32-byte load segments.  OVF = 1: one ticket per PAIR, every workgroup requests the whole 64-byte segment its 32 bytes
+// lie in (its partner requests the same segment: an L2 hit) — half of what arrives is not used.
+template <int OVF>
+__global__ void __launch_bounds__(512) wl_mixed(const LabArgs a) {
+  constexpr int GANG = OVF ? 2 : 4, LSEG = OVF ? 64 : 32, LLPS = LSEG / 16, LRPI = 512 / LLPS, SRPI = 512 / 4, U = 8;
+  const int tid = threadIdx.x;
+  const long long src_row = a.row_bytes / 2, dst_row = a.row_bytes;
+  const int wg = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int member = wg % GANG, g = wg / GANG;
+  __shared__ unsigned next_s;
+  unsigned* cnt = a.counter;
+  unsigned* mbox = a.counter + 256 + 16 * g;
+  f4 v[U];
+#pragma unroll
+  for (int q = 0; q < U; ++q) v[q] = f4{1.f, 2.f, 3.f, 4.f};
+  for (int it = 0;; ++it) {
+    if (tid == 0) {
+      unsigned tk;
+      if (member == 0) {
+        tk = atomicAdd(cnt, 1u);
+        __hip_atomic_store(mbox + (it & 15), ((unsigned)(it + 1) << 16) | tk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        tk = 0xffffu;
+        for (int sp = 0; sp < (1 << 20); ++sp) {
+          const unsigned w = __hip_atomic_load(mbox + (it & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((w >> 16) == (unsigned)(it + 1)) { tk = w & 0xffffu; break; }
+          __builtin_amdgcn_s_sleep(2);
+        }
+      }
+      next_s = tk;
+    }
+    __syncthreads(); int t = (int)next_s; __syncthreads();
+    t = t * GANG + member;
+    if (t >= a.n_tiles) break;                  // tiles = 16-channel columns x batch elements (cols = 48)
+    const long long b = t / a.cols, col = t % a.cols;
+    const long long sbase = b * a.tile_rows * src_row + (OVF ? (col / 2) * 64 : col * 32);
+    const long long dbase = b * a.tile_rows * dst_row + col * 64;
+    const long long l_off = (long long)(tid / LLPS) * src_row + (tid % LLPS) * 16, s_off = (long long)(tid / 4) * dst_row + (tid % 4) * 16;
+    for (int c = 0; c < a.tile_rows / (SRPI * U); ++c) {           // 1024 rows per chunk
+      constexpr int LI = SRPI * U / LRPI;                          // load instructions per chunk: 4 (32-byte segments) or 8 (64-byte)
+      if (a.mode != 2) {
+#pragma unroll
+        for (int q = 0; q < LI; ++q) v[q] = *reinterpret_cast<const f4*>(a.src + sbase + l_off + ((long long)c * LI + q) * LRPI * src_row);
+      }
+      if (a.mode == 0) {
+#pragma unroll
+        for (int q = 0; q < U; ++q) *reinterpret_cast<f4*>(a.dst + dbase + s_off + ((long long)c * U + q) * SRPI * dst_row) = v[q];
+      } else if (a.mode == 1) {
+#pragma unroll
+        for (int q = 0; q < LI; ++q) if (v[q].x == 1.2345e-30f) *reinterpret_cast<f4*>(a.dst + dbase + s_off + q * SRPI * dst_row) = v[q];
+      } else {
+#pragma unroll
+        for (int q = 0; q < U; ++q) *reinterpret_cast<f4*>(a.dst + dbase + s_off + ((long long)c * U + q) * SRPI * dst_row) = v[q];
+      }
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) wl_flat(const f4* __restrict__ src, f4* __restrict__ dst) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   dst[i] = src[i];
@@ -261,6 +321,23 @@ int main(int argc, char** argv) {
   }
   // round 6: how many requests should a lane keep in flight?  (the masked C4 probe of rounds 4-5 had ONE per wave — hipcc had serialised its
   // predicated loads — and was 25 % FASTER than the same copy with sixteen)
+  // round 6: bf16 rows in / fp32 rows out — 32-byte load segments in quads (the product) against over-fetched 64-byte segments in pairs
+  auto runm = [&](auto kern, const char* name, int gang, int mode) {
+    char full[96];
+    static const char* moden[3] = {"copy", "load", "store"};
+    snprintf(full, sizeof full, "bf16->f32 %-30s %s", name, moden[mode]);
+    if (!wanted(full)) return;
+    LabArgs x{};
+    x.src = a; x.dst = b; x.row_bytes = row_bytes; x.tile_rows = 4096; x.mode = mode;
+    x.cols = (int)(row_bytes / 64); x.n_tiles = (int)(rows / 4096) * x.cols;
+    x.n_wg = cus / gang * gang; x.counter = counter;
+    auto go = [&] { CK(hipMemsetAsync(counter, 0, 65536, 0)); hipLaunchKernelGGL(kern, dim3(x.n_wg), dim3(512), 0, 0, x); };
+    report(full, time(go), (mode == 0 ? 1.5 : mode == 1 ? 0.5 : 1.0) * bytes);
+  };
+  for (int mode : {0, 1, 2}) {
+    runm(wl_mixed<0>, "32-byte loads, quads", 4, mode);
+    runm(wl_mixed<1>, "64-byte over-fetch, pairs", 2, mode);
+  }
   // round 6: one ticket per FOUR / EIGHT workgroups = 2 / 4 adjacent lines of a row (64-byte tiles)
   for (int mode : {0, 1, 2}) {
     run(wl_tile<DYNG, 64, 8, 4>, "ticket per 4 wgs (2 lines)", 64, true, mode, 4);
