@@ -89,16 +89,23 @@ __device__ __forceinline__ uint32_t f32_to_bf16_rne(float f) {
   return x >> 16;
 }
 // Two values -> one packed dword (a in the low half), the same rounding: gfx950 has an instruction for it (v_cvt_pk_bf16_f32, round to
-// nearest even) where the bit arithmetic above costs ~12 VALU instructions per pair — 700 of the ~5 400 per thread and 4096-row tile in the
-// kernels that write bf16 rows (round 5: those kernels are bound by their instruction stream, and by the power it draws).  NaNs are made the
-// canonical 0x7fc0 the scalar form (and torch's conversion) returns, so the result stays bit-identical for every input.
+// nearest even, overflow to infinity) where the bit arithmetic above costs ~12 VALU instructions per pair — 700 of the ~5 400 per thread and
+// 4096-row tile in the kernels that write bf16 rows (round 5).  Bit-identical to the scalar form (and to torch's conversion) for every
+// input that is not a NaN.  NaNs (round 6): the instruction returns a QUIET NaN that keeps the input's sign and upper payload bits
+// (0x7fc1 for 0x7fc10000, 0xffc0 for 0xffc00000, 0x7fc0 for the signalling 0x7f800001; tools/gpu_jobs/r06_nanfix.sh), where the scalar
+// form and torch return the canonical 0x7fc0 for every NaN.  Rounds 4-5 patched the canonical pattern in behind the instruction —
+// two compares, two selects, and / or and the wait states of the VCC hazard per pair: 900 instructions per thread and tile, 3.3 % of the
+// bf16 -> bf16 launch (1.121 -> 1.084 ms, profiles/r06_nanfix_ab.log) — for a value that is "not a number" either way.  Not any more:
+// a NaN result is a quiet NaN, its sign and payload are unspecified.  -DSPECTRE_BF16_CANONICAL_NAN restores the patch.
 typedef __bf16 rt_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float rt_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t f32x2_to_bf16x2_rne(float a, float b) {
   const rt_f32x2 v = {a, b};
   uint32_t r = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, rt_bf16x2));
+#ifdef SPECTRE_BF16_CANONICAL_NAN
   if (a != a) r = (r & 0xffff0000u) | 0x7fc0u;
   if (b != b) r = (r & 0x0000ffffu) | 0x7fc00000u;
+#endif
   return r;
 }
 
