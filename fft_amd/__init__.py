@@ -9,9 +9,9 @@ from .functional import (copy_probe, describe, empty_on_fast_allocation, get_til
                          spectral_mix_backward, time_kernel)
 from .decode import PrefixFFTCache, rfft_prefill
 from .shard import batch_shard
-from .spectre import (AttentionPooling, ComplexModReLU, DCTPooling, MeanPool, SpectreHead, SpectreMultiHead,
+from .spectre import (AttentionPooling, ComplexModReLU, DCTPooling, MeanPool, SpectreBlock, SpectreHead, SpectreMultiHead,
                       resample_complex)
 
-__all__ = ["spectral_mix", "spectral_mix_backward", "spectral_gate_fused", "describe", "time_kernel", "set_tile_order", "get_tile_order", "copy_probe", "empty_on_fast_allocation", "SpectreHead", "SpectreMultiHead", "ComplexModReLU", "DCTPooling",
+__all__ = ["spectral_mix", "spectral_mix_backward", "spectral_gate_fused", "describe", "time_kernel", "set_tile_order", "get_tile_order", "copy_probe", "empty_on_fast_allocation", "SpectreHead", "SpectreMultiHead", "SpectreBlock", "ComplexModReLU", "DCTPooling",
            "AttentionPooling", "MeanPool", "resample_complex", "batch_shard", "PrefixFFTCache", "rfft_prefill"]
 __version__ = "0.1.0"

@@ -147,6 +147,26 @@ def spectral_mix_backward(V: torch.Tensor, gate: torch.Tensor, grad_out: torch.T
 TILE_ORDERS = {"auto": 0, "static": 1, "tickets": 2, "pair": 3}       # SPECTRE_ORDER_* of include/spectre_hip.h
 
 
+def spectral_memory_grad(grad_out: torch.Tensor, n_fft: int) -> torch.Tensor:
+    """d/d(memory_fft) of `spectral_mix` for the upstream gradient `grad_out` (B, N_out, D): the (F, D) complex64 tensor torch's autograd
+    returns for the `+ memory_fft` of spectre.py:548-549 followed by `irfft(..., n=n_fft)[:, :N]` (:551-553).
+
+    The spectrum is shared by the batch and enters linearly, so the gradient is the adjoint of irfft applied to sum_b grad_out[b]:
+    `w_k / n_fft * rfft(sum_b grad_out[b], n_fft)[k]` with w = 1 at DC (and at Nyquist for even n_fft), 2 elsewhere — the imaginary parts
+    that irfft ignores at those bins get the zero gradient they have in the reference (rfft of a real sequence is real there).  The batch
+    sum is a stock reduction; the transform is the library's own rfft launch (`spectre_rfft_fwd`, zero-padding rows N_out .. n_fft - 1)."""
+    from .decode import rfft_prefill
+    if grad_out.dim() != 3:
+        raise ValueError(f"grad_out must be (B, N_out, D), got {tuple(grad_out.shape)}")
+    spec = rfft_prefill(grad_out.sum(dim=0, dtype=torch.float32), n_fft)
+    F = n_fft // 2 + 1
+    w = torch.full((F, 1), 2.0 / n_fft, dtype=torch.float32, device=grad_out.device)
+    w[0] = 1.0 / n_fft
+    if n_fft % 2 == 0:
+        w[-1] = 1.0 / n_fft
+    return spec * w
+
+
 def set_tile_order(n_fft: int, order: str = "auto", device=None) -> None:
     """Tile order of the persistent kernels (n_fft = 4096, 3000, 3600, 3840) on `device` (C ABI `spectre_plan_set_tile_order`):
     "auto" (default: tickets, measured once per shape class, the static map only where it is at least 1 % faster), "static", "tickets"

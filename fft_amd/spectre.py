@@ -26,7 +26,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .functional import spectral_gate_backward, spectral_gate_fused, spectral_mix, spectral_mix_backward
+from .functional import spectral_gate_backward, spectral_gate_fused, spectral_memory_grad, spectral_mix, spectral_mix_backward
 
 try:  # optional, exactly as the reference treats it (spectre.py:10-14)
     import torch_dct as _dct
@@ -124,20 +124,21 @@ class _SpectralMixFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, V, gate, memory_fft, n_fft):
-        if memory_fft is not None and memory_fft.requires_grad:
-            raise NotImplementedError("fft_amd: memory_fft is a frozen buffer in the reference (spectre.py:951-959); "
-                                      "its gradient is not implemented")
         ctx.save_for_backward(V, gate)
         ctx.n_fft = n_fft
-        return spectral_mix(V, gate, memory_fft, n_fft)
+        return spectral_mix(V, gate, None if memory_fft is None else memory_fft.detach(), n_fft)
 
     @staticmethod
     @torch.autograd.function.once_differentiable      # the gradients come from C-ABI launches: no graph behind them, so double backward must raise
     def backward(ctx, grad_out):
         V, gate = ctx.saved_tensors
-        dv, dgate = spectral_mix_backward(V, gate, grad_out.contiguous(), ctx.n_fft,
+        grad_out = grad_out.contiguous()
+        dv, dgate = spectral_mix_backward(V, gate, grad_out, ctx.n_fft,
                                           need_dv=ctx.needs_input_grad[0], need_dgate=ctx.needs_input_grad[1])
-        return dv, dgate, None, None
+        # memory_fft is frozen in the reference (spectre.py:961) but a caller may un-freeze it: the spectrum is added in front of the
+        # irfft (:548-551), so its gradient is the irfft's adjoint of the batch sum of grad_out — one (N, D) reduction + one small rfft launch
+        dmem = spectral_memory_grad(grad_out, ctx.n_fft) if ctx.needs_input_grad[2] else None
+        return dv, dgate, dmem, None
 
 
 class _SpectralGateFn(torch.autograd.Function):
@@ -247,7 +248,7 @@ class SpectreHead(nn.Module):
         gate = gate.to(torch.complex64)
         if memory_fft is not None:
             memory_fft = memory_fft.to(torch.complex64)
-        if torch.is_grad_enabled() and (V.requires_grad or gate.requires_grad):
+        if torch.is_grad_enabled() and (V.requires_grad or gate.requires_grad or (memory_fft is not None and memory_fft.requires_grad)):
             mixed = _SpectralMixFn.apply(V, gate, memory_fft, self.n_fft)
         else:
             mixed = spectral_mix(V, gate, memory_fft, self.n_fft)          # spectre.py:506, :542-553
@@ -389,3 +390,56 @@ class SpectreMultiHead(nn.Module):
         gate_all = torch.cat(gates, dim=1)
         mixed = spectral_mix(V, gate_all, None if memory_fft is None else memory_fft.to(torch.complex64), self.heads[0].n_fft)
         return self.out_proj(mixed)
+
+
+# --------------------------------------------------------------------------------------------------
+# transformer block (the outermost caller of the path, SURVEY.md section 8(b) "Callers")
+# --------------------------------------------------------------------------------------------------
+class SpectreBlock(nn.Module):
+    """Pre-norm residual block around the multi-head mix — same surface as spectre.py:892-982 (constructor keywords, `ln1` / `mix` /
+    `ln2` / `mlp` / `memory_fft` names, `forward(x)`), so a reference block's `state_dict()` loads unchanged.
+
+    What reaches the hot path from here is the block's frozen spectral memory (spectre.py:946-965): a `(mem_bins, embed_dim)` complex
+    parameter that the reference zero-pads to `n_fft // 2 + 1` bins on EVERY forward (`:973-977`) and chunks per head (`:706-707`).
+    Here the padded spectrum is built once per parameter version and handed un-chunked to the one fused launch over all heads (row a4 +
+    row N3).  LayerNorm, the MLP and the residual adds are stock PyTorch-ROCm ops (GEMM-bound).
+    `wavelet_on_rate`: as for `SpectreMultiHead` (the stochastic refinement is out of scope: None / 0.0 only).
+    """
+
+    def __init__(self, embed_dim: int, num_heads: int, n_fft: int, mlp_ratio: int = 4, d_gate: int = 256, use_toeplitz: bool = False,
+                 dropout_p: float = 0.0, pooling_type: str = "dct", num_groups: int = 4, num_buckets: Optional[int] = None,
+                 wavelet_on_rate: Optional[float] = None, memory_size: int = 0):
+        super().__init__()
+        self.ln1 = nn.LayerNorm(embed_dim)
+        self.mix = SpectreMultiHead(embed_dim, num_heads, n_fft, d_gate=d_gate, use_toeplitz=use_toeplitz, dropout_p=dropout_p,
+                                    pooling_type=pooling_type, num_groups=num_groups, num_buckets=num_buckets,
+                                    wavelet_on_rate=wavelet_on_rate)
+        self.ln2 = nn.LayerNorm(embed_dim)
+        self.mlp = nn.Sequential(nn.Linear(embed_dim, mlp_ratio * embed_dim), nn.GELU(), nn.Linear(mlp_ratio * embed_dim, embed_dim))
+        self.full_freq_bins = n_fft // 2 + 1
+        if memory_size > 0:
+            # memory_size == 1 means "all bins", > 1 that many (truncated) bins — spectre.py:949
+            bins = min(memory_size, self.full_freq_bins) if memory_size > 1 else self.full_freq_bins
+            self.memory_fft = nn.Parameter(torch.randn(bins, embed_dim, dtype=torch.cfloat) / math.sqrt(embed_dim), requires_grad=False)
+            self.memory_freq_bins = bins
+        else:
+            self.memory_fft = None
+        self._mem_padded = None            # (key, tensor): the (F, embed_dim) spectrum the kernel reads
+
+    def _memory_spectrum(self) -> Optional[torch.Tensor]:
+        m = self.memory_fft
+        if m is None:
+            return None
+        if m.requires_grad and torch.is_grad_enabled():            # un-frozen by the caller: keep it in the graph, pad per call like the reference
+            return F.pad(m, (0, 0, 0, self.full_freq_bins - m.shape[0])) if m.shape[0] < self.full_freq_bins else m
+        key = (m.data_ptr(), m._version, m.device, m.shape[0])
+        if self._mem_padded is None or self._mem_padded[0] != key:
+            full = m.detach().to(torch.complex64)
+            if full.shape[0] < self.full_freq_bins:
+                full = F.pad(full, (0, 0, 0, self.full_freq_bins - full.shape[0]))
+            self._mem_padded = (key, full.contiguous())
+        return self._mem_padded[1]
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        x = x + self.mix(self.ln1(x), memory_fft=self._memory_spectrum())
+        return x + self.mlp(self.ln2(x))

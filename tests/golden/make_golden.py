@@ -241,6 +241,37 @@ def case_multihead(name, B, N, E, H, n_fft, G, seed, *, with_mem=False, with_pha
     print(f"{name:28s} multihead x{tuple(x.shape)} H={H}{' + gradients' if with_grad else ''}  {os.path.getsize(path) / 1e3:.0f} kB")
 
 
+def case_block(name, B, N, E, H, n_fft, G, seed, *, memory_size=0, with_grad=False, train_memory=False):
+    """SpectreBlock.forward (spectre.py:892-982), the outermost caller of the path: pre-norm residual block around the multi-head mix,
+    with its frozen spectral memory (`memory_size` bins, zero-padded to n_fft // 2 + 1 at :973-977 and chunked per head at :706-707);
+    wavelet refinement off.  with_grad: the reference's autograd for a fixed upstream gradient; train_memory: with the memory
+    un-frozen (`requires_grad_(True)`), so that d/d(memory_fft) — through the pad and the irfft — is in the fixture as well."""
+    torch.manual_seed(seed)
+    blk = ref.SpectreBlock(E, H, n_fft, pooling_type="mean", num_groups=G, wavelet_on_rate=0.0, memory_size=memory_size).eval()
+    if train_memory:
+        blk.memory_fft.requires_grad_(True)
+    g = torch.Generator().manual_seed(seed + 6000)
+    x = torch.randn(B, N, E, generator=g)
+    d_out = {"x": x.numpy(), "n_fft": np.int64(n_fft), "G": np.int64(G), "H": np.int64(H), "memory_size": np.int64(memory_size)}
+    with torch.no_grad():
+        d_out["out"] = blk(x).numpy()
+    if with_grad:
+        xg = x.clone().requires_grad_(True)
+        out = blk(xg)
+        dout = torch.randn(out.shape, generator=g)
+        (out * dout).sum().backward()
+        d_out["dout"] = dout.numpy()
+        d_out["grad_x"] = xg.grad.numpy()
+        for k, prm in blk.named_parameters():
+            if prm.grad is not None:
+                d_out["grad/" + k] = prm.grad.numpy()
+    for k, v in blk.state_dict().items():
+        d_out["sd/" + k] = v.numpy()
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **d_out)
+    print(f"{name:28s} block x{tuple(x.shape)} H={H} memory_size={memory_size}{' + gradients' if with_grad else ''}  {os.path.getsize(path) / 1e3:.0f} kB")
+
+
 def g_random(scale=0.3, zero_frac=0.18):
     def f(B, G, F, gen):
         z = torch.complex(torch.randn(B, G, F, generator=gen), torch.randn(B, G, F, generator=gen)) * scale
@@ -317,6 +348,12 @@ def main():
     case_multihead("g11_multihead_h4_mem_phase", 2, 48, 64, 4, 64, 2, 41, with_mem=True, with_phase=True)
     case_multihead("g11_multihead_h3_grad", 2, 256, 96, 3, 256, 2, 42, with_grad=True)
     case_multihead("g11_multihead_h2_grad_mem_phase", 2, 50, 64, 2, 64, 4, 43, with_mem=True, with_phase=True, with_grad=True)
+    # G12 — the transformer block: residuals, LayerNorms, MLP, and the spectral memory in its three sizes (off, all bins, truncated)
+    case_block("g12_block_nomem", 2, 64, 32, 2, 64, 2, 50)
+    case_block("g12_block_mem_full", 2, 48, 32, 2, 64, 2, 51, memory_size=1)
+    case_block("g12_block_mem_trunc9_grad", 2, 64, 32, 2, 64, 2, 52, memory_size=9, with_grad=True)
+    case_block("g12_block_mem_trunc40_trainmem", 2, 100, 48, 3, 128, 2, 53, memory_size=40, with_grad=True, train_memory=True)
+    case_block("g12_block_mem_full_trainmem_odd", 2, 45, 16, 2, 45, 2, 54, memory_size=1, with_grad=True, train_memory=True)
     # G8 — bf16 input values; oracle = reference on x_bf16.float(); bf16 rounding of the result stored
     case_fixed_gate("g8_bf16_n1024", 1, 1024, 16, 1024, 4, 22, g_random(), bf16=True)
     case_fixed_gate("g8_bf16_n4096", 1, 4096, 16, 4096, 4, 23, g_random(), bf16=True)
@@ -326,7 +363,7 @@ if __name__ == "__main__":
     # optional name prefixes: `python make_golden.py g10` regenerates only the matching cases
     if len(sys.argv) > 1:
         _only = tuple(sys.argv[1:])
-        for _fn in ("case_module", "case_fixed_gate", "case_backward", "case_decode", "case_multihead"):
+        for _fn in ("case_module", "case_fixed_gate", "case_backward", "case_decode", "case_multihead", "case_block"):
             def _wrap(f):
                 return lambda name, *a, **k: f(name, *a, **k) if name.startswith(_only) else None
             globals()[_fn] = _wrap(globals()[_fn])
