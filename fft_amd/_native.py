@@ -14,7 +14,7 @@ import torch  # noqa: F401  — must be imported first: the library binds to the
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPECTRE_HIP_LIB") or os.path.join(_HERE, "lib", "libspectre_hip.so")   # env: A/B builds
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 F32, BF16 = 0, 1
 ALGO = {"auto": 0, "stockham": 1, "regtile": 2}
 
@@ -23,7 +23,7 @@ EXPORTS = ("spectre_version", "spectre_last_error", "spectre_mix_fwd", "spectre_
            "spectre_plan_create", "spectre_plan_destroy", "spectre_mix_time", "spectre_mix_bwd",
            "spectre_mix_bwd_workspace_bytes", "spectre_gate_fwd", "spectre_gate_bwd", "spectre_rfft_fwd", "spectre_decode_workspace_bytes",
            "spectre_decode_step", "spectre_decode_head_workspace_bytes", "spectre_decode_head_step", "spectre_probe_copy", "spectre_plans_release_retired",
-           "spectre_plan_set_tile_order", "spectre_plan_get_tile_order")
+           "spectre_plan_set_tile_order", "spectre_plan_get_tile_order", "spectre_wavelet_refine", "spectre_wavelet_gate_grad")
 
 
 class SpectreMixArgs(ctypes.Structure):
@@ -51,6 +51,25 @@ class SpectreGateBwdArgs(ctypes.Structure):
         ("workspace", ctypes.c_void_p), ("danchors", ctypes.c_void_p), ("dbias", ctypes.c_void_p), ("dphase", ctypes.c_void_p),
         ("B", ctypes.c_int64), ("G", ctypes.c_int64), ("K", ctypes.c_int64), ("F", ctypes.c_int64),
         ("phase_sb", ctypes.c_int64), ("eps", ctypes.c_float), ("device", ctypes.c_int32), ("stream", ctypes.c_void_p),
+    ]
+
+
+class SpectreWaveletArgs(ctypes.Structure):
+    _fields_ = [
+        ("v", ctypes.c_void_p), ("out", ctypes.c_void_p), ("vref", ctypes.c_void_p), ("mask", ctypes.c_void_p), ("gate", ctypes.c_void_p),
+        ("B", ctypes.c_int64), ("N", ctypes.c_int64), ("D", ctypes.c_int64),
+        ("v_sb", ctypes.c_int64), ("v_sn", ctypes.c_int64), ("out_sb", ctypes.c_int64), ("out_sn", ctypes.c_int64),
+        ("ref_sb", ctypes.c_int64), ("ref_sn", ctypes.c_int64),
+        ("dtype", ctypes.c_int32), ("device", ctypes.c_int32), ("stream", ctypes.c_void_p),
+    ]
+
+
+class SpectreWaveletGradArgs(ctypes.Structure):
+    _fields_ = [
+        ("dout", ctypes.c_void_p), ("vref", ctypes.c_void_p), ("mask", ctypes.c_void_p), ("dgate", ctypes.c_void_p),
+        ("B", ctypes.c_int64), ("N", ctypes.c_int64), ("D", ctypes.c_int64),
+        ("d_sb", ctypes.c_int64), ("d_sn", ctypes.c_int64), ("ref_sb", ctypes.c_int64), ("ref_sn", ctypes.c_int64),
+        ("dtype", ctypes.c_int32), ("device", ctypes.c_int32), ("stream", ctypes.c_void_p),
     ]
 
 
@@ -167,6 +186,10 @@ def load():
         lib.spectre_decode_head_step.restype = ctypes.c_int
         lib.spectre_probe_copy.argtypes = [ctypes.POINTER(SpectreProbeArgs), ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
         lib.spectre_probe_copy.restype = ctypes.c_int
+        lib.spectre_wavelet_refine.argtypes = [ctypes.POINTER(SpectreWaveletArgs)]
+        lib.spectre_wavelet_refine.restype = ctypes.c_int
+        lib.spectre_wavelet_gate_grad.argtypes = [ctypes.POINTER(SpectreWaveletGradArgs)]
+        lib.spectre_wavelet_gate_grad.restype = ctypes.c_int
         ver = lib.spectre_version()
         if ver != ABI_VERSION:
             raise NativeLibraryError(f"ABI mismatch: library {ver}, binding {ABI_VERSION}")

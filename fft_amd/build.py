@@ -19,11 +19,11 @@ LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libspectre_hip.so")
 
-SOURCES = ["spectre_hip.hip", "copy_probe.hip", "regtile_n4096.hip", "regtile_n4096p.hip", "regtile_n2048.hip", "regtile_n1024.hip", "regtile_n512.hip",
+SOURCES = ["spectre_hip.hip", "copy_probe.hip", "wavelet.hip", "regtile_n4096.hip", "regtile_n4096p.hip", "regtile_n2048.hip", "regtile_n1024.hip", "regtile_n512.hip",
            "regtile_n256.hip", "regtile_wide.hip", "regtile_n3000.hip", "regtile_mixedp.hip", "regtile_n768.hip", "regtile_n1536.hip",
            "regtile_n3072.hip", "regtile_n1000.hip", "regtile_n2000.hip", "regtile_n1280.hip", "regtile_n2560.hip", "regtile_n3840.hip",
            "regtile_mixed_small.hip", "regtile_mixed_mid.hip", "regtile_mixed_mid2.hip", "regtile_n2400.hip", "regtile_n3600.hip", "regtile_n8192.hip", "regtile_n6144.hip", "regtile_n16384.hip", "regtile_n12288.hip"]
-HEADERS = ["fft_regs.h", "fft_regs_mixed.h", "fft_tables_mixed.h", "kernel_regtile.h", "kernel_regtile64p.h", "kernel_tickets.h", "kernel_regtile_wide.h", "kernel_regtile_grad.h", "kernel_regtile_mixed.h", "kernel_regtile_mixedp.h", "kernel_regtile_mixed_grad.h", "kernel_regtile_long.h", "kernel_regtile_long_grad.h", "kernel_regtile_quad.h", "kernel_stockham.h", "kernel_gate.h", "kernel_gate_grad_twopass.h", "kernel_decode.h", os.path.join("..", "..", "include", "spectre_hip.h")]
+HEADERS = ["fft_regs.h", "fft_regs_mixed.h", "fft_tables_mixed.h", "kernel_regtile.h", "kernel_regtile64p.h", "kernel_tickets.h", "kernel_regtile_wide.h", "kernel_regtile_grad.h", "kernel_regtile_mixed.h", "kernel_regtile_mixedp.h", "kernel_regtile_mixed_grad.h", "kernel_regtile_long.h", "kernel_regtile_long_grad.h", "kernel_regtile_quad.h", "kernel_stockham.h", "kernel_gate.h", "kernel_gate_grad_twopass.h", "kernel_decode.h", "kernel_wavelet.h", os.path.join("..", "..", "include", "spectre_hip.h")]
 
 # -fno-slp-vectorize: SLP packs the butterflies into v_pk_*_f32 (no faster than two scalar ops on gfx950)
 # plus register-pair shuffles, which pushes the 64-point kernel past 256 VGPRs into scratch.

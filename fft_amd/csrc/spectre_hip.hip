@@ -38,6 +38,8 @@ template <> hipError_t launch_regtile<32, 32>(const RegtileArgs&, bool, bool, in
 template <> hipError_t launch_regtile<64, 32>(const RegtileArgs&, bool, bool, int, hipStream_t);
 template <> hipError_t launch_regtile<64, 64>(const RegtileArgs&, bool, bool, int, hipStream_t);
 int probe_copy(const SpectreProbeArgs*, int warmup, int iters, float* ms_per_launch, const char** why);                  // copy_probe.hip
+int wavelet_refine(const SpectreWaveletArgs*, const char** why);                                                           // wavelet.hip
+int wavelet_gate_grad(const SpectreWaveletGradArgs*, const char** why);
 hipError_t launch_regtile64p(const RegtileArgs&, bool in_bf16, bool out_bf16, bool burst, hipStream_t);                           // regtile_n4096p.hip (persistent, pipelined)
 template <int RF, int RS> hipError_t launch_regtile_mixedp(const RegtileArgs&, hipStream_t);        // kernel_regtile_mixedp.h (persistent, deferred row blocks)
 template <> hipError_t launch_regtile_mixedp<60, 50>(const RegtileArgs&, hipStream_t);               // regtile_mixedp.hip
@@ -849,6 +851,18 @@ int spectre_probe_copy(const SpectreProbeArgs* a, int warmup, int iters, float* 
   const char* why = "";
   const int rc = sfft::probe_copy(a, warmup, iters, ms_per_launch, &why);
   return rc == SPECTRE_OK ? SPECTRE_OK : fail(rc, "spectre_probe_copy: %s", why);
+}
+
+int spectre_wavelet_refine(const SpectreWaveletArgs* a) {                     // wavelet.hip
+  const char* why = "";
+  const int rc = sfft::wavelet_refine(a, &why);
+  return rc == SPECTRE_OK ? SPECTRE_OK : fail(rc, "spectre_wavelet_refine: %s", why);
+}
+
+int spectre_wavelet_gate_grad(const SpectreWaveletGradArgs* a) {
+  const char* why = "";
+  const int rc = sfft::wavelet_gate_grad(a, &why);
+  return rc == SPECTRE_OK ? SPECTRE_OK : fail(rc, "spectre_wavelet_gate_grad: %s", why);
 }
 
 const char* spectre_last_error(void) { return g_err.c_str(); }

@@ -167,6 +167,73 @@ def spectral_memory_grad(grad_out: torch.Tensor, n_fft: int) -> torch.Tensor:
     return spec * w
 
 
+def wavelet_refine(v: torch.Tensor, gate: torch.Tensor, on_mask: torch.Tensor, *, inplace: bool = False, want_ref: bool = False):
+    """`v + (R(v) * gate[:, None, :]) * on_mask[:, None, None]` with R the Haar analysis / synthesis round trip of the reference's
+    WaveletRefinement along the sequence (spectre.py:853-872, :884-886) — one launch, only the switched-on batch elements are read.
+
+    v (B, N, D) f32|bf16 with N a power of two;  gate (B, D) (`gate_mlp(q_pool)`, :848);  on_mask (B) or (B, 1, 1) bool
+    (`torch.rand(B, 1, 1) < on_rate`, :841).  inplace: write into v.  want_ref: also return R(v) for the switched-on elements (rows of
+    the others are uninitialised) — the operand of `wavelet_gate_grad`.  Returns (out, vref | None)."""
+    lib = _native.load()
+    if not v.is_cuda:
+        raise RuntimeError("wavelet_refine runs on a HIP device only (no CPU path)")
+    if v.dim() != 3:
+        raise ValueError(f"v must be (B, N, D), got {tuple(v.shape)}")
+    if v.dtype not in _DT:
+        raise TypeError(f"v dtype {v.dtype} unsupported (float32 or bfloat16)")
+    B, N, D = v.shape
+    if tuple(gate.shape) != (B, D):
+        raise ValueError(f"gate must be (B={B}, D={D}), got {tuple(gate.shape)}")
+    if on_mask.numel() != B or on_mask.dtype != torch.bool:
+        raise ValueError(f"on_mask must hold B={B} booleans, got {tuple(on_mask.shape)} {on_mask.dtype}")
+    if gate.device != v.device or on_mask.device != v.device:
+        raise RuntimeError("v, gate and on_mask must be on the same device")
+    if v.stride(2) != 1:
+        if inplace:
+            raise ValueError("wavelet_refine(inplace=True) needs unit stride along the channels")
+        v = v.contiguous()
+    gate = gate.detach().to(torch.float32).contiguous()
+    mask = on_mask.reshape(B).contiguous()
+    out = v if inplace else torch.empty((B, N, D), dtype=v.dtype, device=v.device)
+    vref = torch.empty((B, N, D), dtype=v.dtype, device=v.device) if want_ref else None
+    a = _native.SpectreWaveletArgs()
+    a.v, a.out, a.vref = v.data_ptr(), out.data_ptr(), (vref.data_ptr() if vref is not None else None)
+    a.mask, a.gate = mask.data_ptr(), gate.data_ptr()
+    a.B, a.N, a.D = B, N, D
+    a.v_sb, a.v_sn, a.out_sb, a.out_sn = v.stride(0), v.stride(1), out.stride(0), out.stride(1)
+    a.ref_sb, a.ref_sn = (vref.stride(0), vref.stride(1)) if vref is not None else (0, 0)
+    a.dtype = _DT[v.dtype]
+    a.device = v.device.index if v.device.index is not None else torch.cuda.current_device()
+    a.stream = torch.cuda.current_stream(v.device).cuda_stream
+    _native.check(lib.spectre_wavelet_refine(ctypes.byref(a)), "spectre_wavelet_refine")
+    return out, vref
+
+
+def wavelet_gate_grad(grad_out: torch.Tensor, vref: torch.Tensor, on_mask: torch.Tensor) -> torch.Tensor:
+    """d/d(gate) of `wavelet_refine`: (B, D) f32 = on_mask * sum_n grad_out * R(v) (the round trip is detached in the reference,
+    spectre.py:884, so d/dv is the identity and this is the only other gradient)."""
+    lib = _native.load()
+    if not grad_out.is_cuda:
+        raise RuntimeError("wavelet_gate_grad runs on a HIP device only (no CPU path)")
+    if grad_out.dim() != 3 or grad_out.shape != vref.shape or grad_out.dtype != vref.dtype or grad_out.dtype not in _DT:
+        raise ValueError(f"grad_out and vref must be equal-shaped (B, N, D) f32|bf16 tensors, got {tuple(grad_out.shape)} {grad_out.dtype} "
+                         f"and {tuple(vref.shape)} {vref.dtype}")
+    if grad_out.stride(2) != 1:
+        grad_out = grad_out.contiguous()
+    B, N, D = grad_out.shape
+    mask = on_mask.reshape(B).contiguous()
+    dgate = torch.empty((B, D), dtype=torch.float32, device=grad_out.device)
+    a = _native.SpectreWaveletGradArgs()
+    a.dout, a.vref, a.mask, a.dgate = grad_out.data_ptr(), vref.data_ptr(), mask.data_ptr(), dgate.data_ptr()
+    a.B, a.N, a.D = B, N, D
+    a.d_sb, a.d_sn, a.ref_sb, a.ref_sn = grad_out.stride(0), grad_out.stride(1), vref.stride(0), vref.stride(1)
+    a.dtype = _DT[grad_out.dtype]
+    a.device = grad_out.device.index if grad_out.device.index is not None else torch.cuda.current_device()
+    a.stream = torch.cuda.current_stream(grad_out.device).cuda_stream
+    _native.check(lib.spectre_wavelet_gate_grad(ctypes.byref(a)), "spectre_wavelet_gate_grad")
+    return dgate
+
+
 def set_tile_order(n_fft: int, order: str = "auto", device=None) -> None:
     """Tile order of the persistent kernels (n_fft = 4096, 3000, 3600, 3840) on `device` (C ABI `spectre_plan_set_tile_order`):
     "auto" (default: tickets, measured once per shape class, the static map only where it is at least 1 % faster), "static", "tickets"

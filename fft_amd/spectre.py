@@ -26,7 +26,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .functional import spectral_gate_backward, spectral_gate_fused, spectral_memory_grad, spectral_mix, spectral_mix_backward
+from .functional import (spectral_gate_backward, spectral_gate_fused, spectral_memory_grad, spectral_mix, spectral_mix_backward,
+                         wavelet_gate_grad, wavelet_refine)
 
 try:  # optional, exactly as the reference treats it (spectre.py:10-14)
     import torch_dct as _dct
@@ -298,43 +299,79 @@ class _MultiHeadValueFn(torch.autograd.Function):
         return (dx, *dws)
 
 
-class _WaveletRefinementParams(nn.Module):
-    """Holds the parameters of the reference's `WaveletRefinement` (spectre.py:819-832) so that its state_dict loads;
-    the refinement itself is out of scope (stochastic per batch element) and is only accepted
-    switched off."""
+class _WaveletRefineFn(torch.autograd.Function):
+    """autograd node of the refinement launch: `v + (R(v).detach() * gate) * on_mask` (spectre.py:884-886) — d/dv is the identity, d/dgate
+    one reduction launch over the round trip the forward launch left behind for the switched-on elements."""
 
-    def __init__(self, embed_dim: int, on_rate: float):
+    @staticmethod
+    def forward(ctx, v, gate, on_mask, inplace):
+        want_ref = ctx.needs_input_grad[1]
+        out, vref = wavelet_refine(v, gate, on_mask, inplace=inplace, want_ref=want_ref)
+        if inplace:
+            ctx.mark_dirty(v)
+        ctx.save_for_backward(on_mask, *([vref] if want_ref else []))
+        ctx.gate_dtype = gate.dtype
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_out):
+        on_mask, *ref = ctx.saved_tensors
+        dgate = wavelet_gate_grad(grad_out, ref[0], on_mask).to(ctx.gate_dtype) if ref else None
+        return grad_out, dgate, None, None
+
+
+class WaveletRefinement(nn.Module):
+    """The optional refinement between the heads' concatenation and `out_proj` — same surface as spectre.py:819-887 (`on_rate`, `gate_mlp`,
+    `forward(v, q_pool)`), same coin flip per batch element and forward pass (`torch.rand(B, 1, 1, device=v.device) < on_rate`, :841).
+
+    The reference loops over the batch in Python, transposes every switched-on element, runs its Haar analysis / synthesis pair (which, because
+    of the analysis' one-sample circular pad, is a fixed linear operator R != identity along the sequence — SURVEY.md section 2 row 10) and
+    stacks the results; here that is ONE launch (`fft_amd.functional.wavelet_refine`, kernel_wavelet.h) that reads the mask on the device, so
+    there is no `on_mask.any()` round trip to the host (:845) and switched-off elements cost nothing.  Like the reference, only power-of-two
+    sequence lengths work (its synthesis fails with a size mismatch otherwise, :271) — here that is a ValueError whenever on_rate > 0, not
+    only when the coin happens to switch an element on.  Gradients: identity to v, through `gate_mlp` to q_pool (the round trip is detached, :884).
+    """
+
+    def __init__(self, embed_dim: int, on_rate: float = 0.1):
         super().__init__()
         self.on_rate = on_rate
         self.gate_mlp = nn.Sequential(nn.Linear(embed_dim, embed_dim), nn.SiLU(), nn.Linear(embed_dim, embed_dim), nn.Sigmoid())
+        self.forced_mask: Optional[torch.Tensor] = None      # tests / reproducing a reference run: use this (B,) bool mask instead of the draw
+
+    def _draw(self, B: int, device) -> torch.Tensor:
+        drawn = torch.rand(B, 1, 1, device=device) < self.on_rate          # always drawn, like the reference: the generator advances equally
+        return drawn.view(B) if self.forced_mask is None else self.forced_mask.to(device=device, dtype=torch.bool).view(B)
+
+    def forward(self, v: torch.Tensor, q_pool: torch.Tensor, *, inplace: bool = False) -> torch.Tensor:
+        B, N, d = v.shape
+        on_mask = self._draw(B, v.device)
+        if self.on_rate <= 0.0 and self.forced_mask is None:
+            return v                                                       # never on: the reference's early exit (:845-846)
+        if N & (N - 1):
+            raise ValueError(f"WaveletRefinement: sequence length {N} is not a power of two — the reference's Haar synthesis raises a size "
+                             "mismatch for it as soon as a batch element is switched on (spectre.py:271); use wavelet_on_rate=0.0")
+        gate = self.gate_mlp(q_pool)
+        if torch.is_grad_enabled() and (v.requires_grad or gate.requires_grad):
+            inplace = inplace and not (v.is_leaf and v.requires_grad) and v._base is None
+            return _WaveletRefineFn.apply(v, gate, on_mask, inplace)
+        return wavelet_refine(v, gate, on_mask, inplace=inplace)[0]
 
 
 class SpectreMultiHead(nn.Module):
-    """Several SpectreHeads side by side plus the output projection — same surface as spectre.py:660-726.
+    """Several SpectreHeads side by side, the wavelet refinement and the output projection — same surface as spectre.py:660-726.
 
     The reference loops over heads and concatenates their outputs (`:712-719`); here every head's fused mix writes
     straight into its channel slice of one (B, N, embed_dim) buffer (strided output views of the C ABI), so the
-    concatenation pass over the activations disappears.  `wavelet_on_rate` must be 0 (see `_WaveletRefinementParams`).
+    concatenation pass over the activations disappears.  The refinement (`:724`, default `wavelet_on_rate=0.1` like the reference —
+    stochastic per batch element, active in eval() too) is one more launch, in place on that buffer (`WaveletRefinement`).
     """
 
     def __init__(self, embed_dim: int, num_heads: int, n_fft: int, d_gate: int = 256, use_toeplitz: bool = False,
                  dropout_p: float = 0.0, pooling_type: str = "dct", num_groups: int = 4,
-                 num_buckets: Optional[int] = None, wavelet_on_rate: Optional[float] = None):
+                 num_buckets: Optional[int] = None, wavelet_on_rate: float = 0.1):
         super().__init__()
         assert embed_dim % num_heads == 0
-        # Deviation from the reference's default (0.1): the refinement is out of scope (DESIGN.md section 1), so the default
-        # constructor builds the layer WITHOUT it instead of failing; asking for it explicitly still raises.
-        if wavelet_on_rate is None:
-            # the reference's constructor default is 0.1 (spectre.py:673): a caller who never mentions the rate gets a layer WITHOUT the
-            # stochastic refinement here — say so once instead of silently building a different function
-            warnings.warn("fft_amd.SpectreMultiHead: the stochastic WaveletRefinement (spectre.py:819-878; reference default "
-                          "wavelet_on_rate=0.1, active even in eval()) is not implemented — this layer is built without it. "
-                          "Pass wavelet_on_rate=0.0 to acknowledge (and to compare with a reference module constructed the same way).",
-                          stacklevel=2)
-            wavelet_on_rate = 0.0
-        if wavelet_on_rate != 0.0:
-            raise NotImplementedError("fft_amd.SpectreMultiHead: the stochastic WaveletRefinement (spectre.py:819-878) is not "
-                                      "implemented; construct with wavelet_on_rate=0.0 (the reference's default is 0.1)")
         self.num_heads = num_heads
         self.head_dim = embed_dim // num_heads
         self.heads = nn.ModuleList([
@@ -342,16 +379,18 @@ class SpectreMultiHead(nn.Module):
                         pooling_type=pooling_type, num_groups=num_groups, num_buckets=num_buckets)
             for _ in range(num_heads)])
         self.out_proj = nn.Linear(embed_dim, embed_dim, bias=False)
-        self.wavelet_refinement = _WaveletRefinementParams(embed_dim, wavelet_on_rate)
+        self.wavelet_refinement = WaveletRefinement(embed_dim, on_rate=wavelet_on_rate)
 
     fused_autograd = True          # under autograd: one value-projection node + ONE spectral-mix node for all heads (False: the reference's loop)
 
     def _forward_per_head(self, x, pos_phase, memory_fft):
-        """The reference's own structure (spectre.py:712-719): per-head modules, concatenated.  Kept for autocast and as the
+        """The reference's own structure (spectre.py:712-724): per-head modules, concatenated, refined.  Kept for autocast and as the
         comparison path of the tests."""
         chunks = torch.chunk(x, self.num_heads, dim=-1)
         mems = torch.chunk(memory_fft, self.num_heads, dim=-1) if memory_fft is not None else [None] * self.num_heads
-        mixed = torch.cat([h(c, pos_phase, memory_fft=m) for h, c, m in zip(self.heads, chunks, mems)], dim=-1)
+        pairs = [h(c, pos_phase, return_q_pool=True, memory_fft=m) for h, c, m in zip(self.heads, chunks, mems)]
+        mixed = torch.cat([m for m, _ in pairs], dim=-1)
+        mixed = self.wavelet_refinement(mixed, torch.cat([q for _, q in pairs], dim=-1), inplace=True)      # `mixed` is the cat's own buffer
         return self.out_proj(mixed)
 
     def forward(self, x: torch.Tensor, pos_phase: Optional[torch.Tensor] = None, memory_fft: Optional[torch.Tensor] = None):
@@ -369,12 +408,16 @@ class SpectreMultiHead(nn.Module):
             # backward = one dV launch + one dgate launch over H*G groups).  Dropout (same p in every head, spectre.py:689) acts on
             # the fused tensor: the same distribution as per-head masks, drawn in one call.
             V = _MultiHeadValueFn.apply(x, *[h.W_v.weight for h in self.heads])
-            gate_all = torch.cat([h.spectral_gate(c, pos_phase, with_value=False)[1].to(torch.complex64)
-                                  for h, c in zip(self.heads, chunks)], dim=1)
+            gates, pools = [], []
+            for h, c in zip(self.heads, chunks):
+                _, gate, q_pool = h.spectral_gate(c, pos_phase, with_value=False)
+                gates.append(gate.to(torch.complex64))
+                pools.append(q_pool)
             mem = None if memory_fft is None else memory_fft.to(torch.complex64)
-            mixed = _SpectralMixFn.apply(V, gate_all, mem, self.heads[0].n_fft)
+            mixed = _SpectralMixFn.apply(V, torch.cat(gates, dim=1), mem, self.heads[0].n_fft)
             if p_drop > 0.0 and self.training:
                 mixed = F.dropout(mixed, p_drop, True)
+            mixed = self.wavelet_refinement(mixed, torch.cat(pools, dim=-1), inplace=True)
             return self.out_proj(mixed)
         if p_drop > 0.0 and self.training:
             return self._forward_per_head(x, pos_phase, memory_fft)
@@ -383,12 +426,13 @@ class SpectreMultiHead(nn.Module):
         # the per-head calls — and memory_fft is used un-chunked.  Replaces the reference's per-head loop + torch.cat (:712-719).
         hd = self.head_dim
         V = torch.empty(x.shape[0], x.shape[1], x.shape[2], dtype=x.dtype, device=x.device)
-        gates = []
+        gates, pools = [], []
         for i, (h, c) in enumerate(zip(self.heads, chunks)):
-            _, gate, _ = h.spectral_gate(c, pos_phase, v_out=V[:, :, i * hd:(i + 1) * hd])
+            _, gate, q_pool = h.spectral_gate(c, pos_phase, v_out=V[:, :, i * hd:(i + 1) * hd])
             gates.append(gate.to(torch.complex64))
-        gate_all = torch.cat(gates, dim=1)
-        mixed = spectral_mix(V, gate_all, None if memory_fft is None else memory_fft.to(torch.complex64), self.heads[0].n_fft)
+            pools.append(q_pool)
+        mixed = spectral_mix(V, torch.cat(gates, dim=1), None if memory_fft is None else memory_fft.to(torch.complex64), self.heads[0].n_fft)
+        mixed = self.wavelet_refinement(mixed, torch.cat(pools, dim=-1), inplace=True)
         return self.out_proj(mixed)
 
 
@@ -403,12 +447,12 @@ class SpectreBlock(nn.Module):
     parameter that the reference zero-pads to `n_fft // 2 + 1` bins on EVERY forward (`:973-977`) and chunks per head (`:706-707`).
     Here the padded spectrum is built once per parameter version and handed un-chunked to the one fused launch over all heads (row a4 +
     row N3).  LayerNorm, the MLP and the residual adds are stock PyTorch-ROCm ops (GEMM-bound).
-    `wavelet_on_rate`: as for `SpectreMultiHead` (the stochastic refinement is out of scope: None / 0.0 only).
+    `wavelet_on_rate`: the stochastic refinement of the layer inside (`WaveletRefinement`; the reference's default 0.1).
     """
 
     def __init__(self, embed_dim: int, num_heads: int, n_fft: int, mlp_ratio: int = 4, d_gate: int = 256, use_toeplitz: bool = False,
                  dropout_p: float = 0.0, pooling_type: str = "dct", num_groups: int = 4, num_buckets: Optional[int] = None,
-                 wavelet_on_rate: Optional[float] = None, memory_size: int = 0):
+                 wavelet_on_rate: float = 0.1, memory_size: int = 0):
         super().__init__()
         self.ln1 = nn.LayerNorm(embed_dim)
         self.mix = SpectreMultiHead(embed_dim, num_heads, n_fft, d_gate=d_gate, use_toeplitz=use_toeplitz, dropout_p=dropout_p,

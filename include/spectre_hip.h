@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SPECTRE_ABI_VERSION 9
+#define SPECTRE_ABI_VERSION 10
 
 enum {
   SPECTRE_OK = 0,
@@ -272,6 +272,48 @@ typedef struct SpectreDecodeHeadArgs {
 
 int64_t spectre_decode_head_workspace_bytes(int64_t n_fft, int64_t d, int64_t G, int64_t K);
 int spectre_decode_head_step(const SpectreDecodeHeadArgs* args);
+
+/* Wavelet refinement of the multi-head layer (the step between the heads' concatenation and `out_proj`,
+ * spectre.py:724): replaces WaveletRefinement.forward's per-batch-element Python loop (spectre.py:853-872: transpose, `dwt_decompose` :288-312,
+ * `dwt_reconstruct` :315-328, stack) and the gated residual `v + (v_ref.detach() * gate) * on_mask` (:884-886) with ONE launch that touches
+ * the switched-on batch elements only and needs no host-side look at the mask (the reference's `on_mask.any()` :845 is a device-to-host sync).
+ *   v     (B, N, D)  f32|bf16, last dim unit stride, element strides v_sb, v_sn;  N a power of two <= 32768 (the reference raises for others)
+ *   out   (B, N, D)  same dtype, strides out_sb, out_sn; may be `v` itself (in place: switched-off elements cost nothing)
+ *   mask  (B)        one byte per batch element, non-zero = on (`torch.rand(B, 1, 1) < on_rate`, :841 — drawn by the caller)
+ *   gate  (B, D)     f32 contiguous: `gate_mlp(q_pool)` (:848)
+ *   vref  (B, N, D)  optional, same dtype, strides ref_sb, ref_sn: the round trip R(v) of the switched-on elements (rows of the others
+ *                    are not touched) — what spectre_wavelet_gate_grad needs; NULL in inference
+ */
+typedef struct SpectreWaveletArgs {
+  const void* v;
+  void* out;
+  void* vref;
+  const void* mask;
+  const void* gate;
+  int64_t B, N, D;
+  int64_t v_sb, v_sn, out_sb, out_sn, ref_sb, ref_sn;
+  int32_t dtype;
+  int32_t device;
+  void* stream;
+} SpectreWaveletArgs;
+
+int spectre_wavelet_refine(const SpectreWaveletArgs* args);
+
+/* Its backward with respect to the gate (what autograd derives through spectre.py:884: the round trip itself is detached, d/dv is the
+ * identity): dgate[b, c] = on[b] * sum_n dout[b, n, c] * vref[b, n, c];  dgate (B, D) f32 contiguous out (zeros for switched-off elements). */
+typedef struct SpectreWaveletGradArgs {
+  const void* dout;
+  const void* vref;
+  const void* mask;
+  void* dgate;
+  int64_t B, N, D;
+  int64_t d_sb, d_sn, ref_sb, ref_sn;
+  int32_t dtype;
+  int32_t device;
+  void* stream;
+} SpectreWaveletGradArgs;
+
+int spectre_wavelet_gate_grad(const SpectreWaveletGradArgs* args);
 
 /* Measurement only (bench.py's roofline block; nothing on the product path calls it): a PURE COPY of the spectral mix's bytes with a
  * chosen access pattern, timed with HIP events on `stream` — the ceiling the memory system of this device gives a kernel that does

@@ -29,7 +29,7 @@ def pytest_collection_modifyitems(config, items):
 
 def golden_files():
     """Forward / backward fixtures of the spectral mix (the decode and multi-head fixtures g10_*, g11_* have their own tests)."""
-    return sorted(f for f in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")) if not os.path.basename(f).startswith(("g10_decode", "g11_multihead", "g12_block")))
+    return sorted(f for f in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")) if not os.path.basename(f).startswith(("g10_decode", "g11_multihead", "g12_block", "g13_")))
 
 
 def golden_ids():

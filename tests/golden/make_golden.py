@@ -272,6 +272,74 @@ def case_block(name, B, N, E, H, n_fft, G, seed, *, memory_size=0, with_grad=Fal
     print(f"{name:28s} block x{tuple(x.shape)} H={H} memory_size={memory_size}{' + gradients' if with_grad else ''}  {os.path.getsize(path) / 1e3:.0f} kB")
 
 
+def _mask_the_reference_draws(seed, B, on_rate):
+    """The coin flip of WaveletRefinement.forward (spectre.py:841) is the first use of the global generator in the forwards recorded below
+    (dropout is off), so re-seeding and drawing the same shape reproduces it."""
+    torch.manual_seed(seed)
+    return (torch.rand(B, 1, 1) < on_rate).view(B)
+
+
+def case_wavelet(name, B, N, d, seed, on_rate):
+    """WaveletRefinement.forward (spectre.py:834-887) alone: v, q_pool -> v + (R(v).detach() * gate_mlp(q_pool)) * on_mask, the mask it drew,
+    the gate it computed, and what the reference's autograd returns for a fixed upstream gradient (d/dv, d/dq_pool, d/d gate_mlp)."""
+    torch.manual_seed(seed)
+    wr = ref.WaveletRefinement(d, on_rate=on_rate)
+    g = torch.Generator().manual_seed(seed + 7000)
+    v = torch.randn(B, N, d, generator=g).requires_grad_(True)
+    q = torch.randn(B, d, generator=g).requires_grad_(True)
+    mask = _mask_the_reference_draws(seed + 1, B, on_rate)
+    torch.manual_seed(seed + 1)
+    out = wr(v, q)
+    dout = torch.randn(out.shape, generator=g)
+    (out * dout).sum().backward()
+    d_out = {"v": v.detach().numpy(), "q_pool": q.detach().numpy(), "mask": mask.numpy(), "on_rate": np.float64(on_rate),
+             "gate": wr.gate_mlp(q).detach().numpy(), "out": out.detach().numpy(), "dout": dout.numpy(),
+             "grad_v": v.grad.numpy(), "grad_q_pool": q.grad.numpy() if q.grad is not None else np.zeros((B, d), np.float32)}
+    for k, prm in wr.named_parameters():
+        d_out["grad/" + k] = prm.grad.numpy() if prm.grad is not None else np.zeros(tuple(prm.shape), np.float32)
+    for k, val in wr.state_dict().items():
+        d_out["sd/" + k] = val.numpy()
+    assert mask.any() or on_rate == 0.0
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **d_out)
+    print(f"{name:28s} wavelet v{tuple(v.shape)} on={mask.int().tolist()}  {os.path.getsize(path) / 1e3:.0f} kB")
+
+
+def case_wavelet_layer(name, kind, B, N, E, H, n_fft, G, seed, on_rate, *, memory_size=0):
+    """SpectreMultiHead (kind="multihead") or SpectreBlock (kind="block") WITH the stochastic refinement (spectre.py:724): input, state_dict,
+    the mask the refinement drew, output, and the reference's autograd for a fixed upstream gradient."""
+    torch.manual_seed(seed)
+    if kind == "multihead":
+        m = ref.SpectreMultiHead(E, H, n_fft, pooling_type="mean", num_groups=G, wavelet_on_rate=on_rate).eval()
+    else:
+        m = ref.SpectreBlock(E, H, n_fft, pooling_type="mean", num_groups=G, wavelet_on_rate=on_rate, memory_size=memory_size).eval()
+    g = torch.Generator().manual_seed(seed + 8000)
+    x = torch.randn(B, N, E, generator=g)
+    mask = _mask_the_reference_draws(seed + 1, B, on_rate)
+    d_out = {"x": x.numpy(), "n_fft": np.int64(n_fft), "G": np.int64(G), "H": np.int64(H), "memory_size": np.int64(memory_size),
+             "mask": mask.numpy(), "on_rate": np.float64(on_rate)}
+    torch.manual_seed(seed + 1)
+    with torch.no_grad():
+        d_out["out"] = m(x).numpy()
+    xg = x.clone().requires_grad_(True)
+    torch.manual_seed(seed + 1)
+    out = m(xg)
+    assert np.array_equal(out.detach().numpy(), d_out["out"])          # same coin flips in both runs
+    dout = torch.randn(out.shape, generator=g)
+    (out * dout).sum().backward()
+    d_out["dout"] = dout.numpy()
+    d_out["grad_x"] = xg.grad.numpy()
+    for k, prm in m.named_parameters():
+        if prm.grad is not None:
+            d_out["grad/" + k] = prm.grad.numpy()
+    for k, val in m.state_dict().items():
+        d_out["sd/" + k] = val.numpy()
+    assert mask.any() and not mask.all()
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **d_out)
+    print(f"{name:28s} {kind} + wavelet x{tuple(x.shape)} on={mask.int().tolist()}  {os.path.getsize(path) / 1e3:.0f} kB")
+
+
 def g_random(scale=0.3, zero_frac=0.18):
     def f(B, G, F, gen):
         z = torch.complex(torch.randn(B, G, F, generator=gen), torch.randn(B, G, F, generator=gen)) * scale
@@ -354,6 +422,14 @@ def main():
     case_block("g12_block_mem_trunc9_grad", 2, 64, 32, 2, 64, 2, 52, memory_size=9, with_grad=True)
     case_block("g12_block_mem_trunc40_trainmem", 2, 100, 48, 3, 128, 2, 53, memory_size=40, with_grad=True, train_memory=True)
     case_block("g12_block_mem_full_trainmem_odd", 2, 45, 16, 2, 45, 2, 54, memory_size=1, with_grad=True, train_memory=True)
+    # G13 — the stochastic wavelet refinement (spectre.py:819-887), alone and inside the layer / the block
+    case_wavelet("g13_wavelet_n64", 6, 64, 16, 60, 0.5)
+    case_wavelet("g13_wavelet_n8_all_on", 2, 8, 4, 61, 1.0)
+    case_wavelet("g13_wavelet_n256_d24", 4, 256, 24, 62, 0.5)
+    case_wavelet("g13_wavelet_n2", 3, 2, 8, 63, 0.7)
+    case_wavelet("g13_wavelet_n1024_d5", 3, 1024, 5, 64, 0.6)
+    case_wavelet_layer("g13_layer_multihead_wavelet", "multihead", 4, 64, 32, 2, 64, 2, 65, 0.5)
+    case_wavelet_layer("g13_layer_block_wavelet_mem", "block", 4, 128, 32, 2, 128, 2, 66, 0.5, memory_size=9)
     # G8 — bf16 input values; oracle = reference on x_bf16.float(); bf16 rounding of the result stored
     case_fixed_gate("g8_bf16_n1024", 1, 1024, 16, 1024, 4, 22, g_random(), bf16=True)
     case_fixed_gate("g8_bf16_n4096", 1, 4096, 16, 4096, 4, 23, g_random(), bf16=True)
@@ -363,7 +439,7 @@ if __name__ == "__main__":
     # optional name prefixes: `python make_golden.py g10` regenerates only the matching cases
     if len(sys.argv) > 1:
         _only = tuple(sys.argv[1:])
-        for _fn in ("case_module", "case_fixed_gate", "case_backward", "case_decode", "case_multihead", "case_block"):
+        for _fn in ("case_module", "case_fixed_gate", "case_backward", "case_decode", "case_multihead", "case_block", "case_wavelet", "case_wavelet_layer"):
             def _wrap(f):
                 return lambda name, *a, **k: f(name, *a, **k) if name.startswith(_only) else None
             globals()[_fn] = _wrap(globals()[_fn])

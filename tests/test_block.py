@@ -56,12 +56,10 @@ def test_surface_and_reference_state_dicts():
         assert again is not full and torch.equal(again[:bins], blk.memory_fft.detach())                      # ... per parameter version
 
 
-def test_block_refuses_the_wavelet_refinement_like_the_layer_inside():
+def test_block_passes_the_wavelet_rate_to_the_layer_inside():
     from fft_amd import SpectreBlock
-    with pytest.raises(NotImplementedError, match="wavelet_on_rate"):
-        SpectreBlock(32, 2, 64, wavelet_on_rate=0.1)
-    with pytest.warns(UserWarning, match="WaveletRefinement"):
-        SpectreBlock(32, 2, 64)
+    assert SpectreBlock(32, 2, 64).mix.wavelet_refinement.on_rate == 0.1                  # spectre.py:921, :936
+    assert SpectreBlock(32, 2, 64, wavelet_on_rate=0.3).mix.wavelet_refinement.on_rate == 0.3
 
 
 def test_cpu_tensors_raise():

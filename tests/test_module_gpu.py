@@ -1,4 +1,5 @@
 """The drop-in module on a real GPU: reference state_dict + x -> the reference's output (fixtures)."""
+import numpy as np
 import pytest
 import torch
 
@@ -26,14 +27,28 @@ def test_module_forward_matches_reference(path, cid):
     assert_close(out.cpu().numpy(), d["out"], rtol=1e-4, atol_rms=2e-4, what=cid)
 
 
-def test_memory_fft_gradient_is_refused_not_silently_dropped():
+def test_memory_fft_gradient_reaches_an_unfrozen_memory():
+    """The reference freezes memory_fft (spectre.py:961) but autograd would train it if a caller un-freezes it: the layer must return that
+    gradient (round 6; it used to refuse), with frozen parameters too (the routing then depends on the memory alone), and the same value the
+    oracle's torch restatement gives for the head's own V and gate.  (Reference-made fixtures: tests/test_block.py `*_trainmem`.)"""
     from fft_amd import SpectreHead
+    from oracle.spectral_mix_oracle import assert_close, spectral_mix_torch
     head = SpectreHead(32, 256, num_groups=2, pooling_type="mean").to("cuda:0")
+    for p in head.parameters():
+        p.requires_grad_(False)
     x = torch.randn(2, 256, 32, device="cuda:0")
     mem = torch.randn(129, 32, dtype=torch.complex64, device="cuda:0", requires_grad=True)
-    with pytest.raises(NotImplementedError, match="memory_fft"):
-        head(x, memory_fft=mem)
-    head(x, memory_fft=mem.detach()).sum().backward()               # frozen memory (as in the reference) trains fine
+    out = head(x, memory_fft=mem)
+    assert out.requires_grad
+    dout = torch.randn_like(out)
+    (out * dout).sum().backward()
+    with torch.no_grad():
+        V, gate, _ = head.spectral_gate(x)
+    m = mem.detach().cpu().requires_grad_(True)
+    (spectral_mix_torch(V.cpu(), gate.to(torch.complex64).cpu(), m, 256) * dout.cpu()).sum().backward()
+    g, e = mem.grad.cpu().numpy(), m.grad.numpy()
+    assert_close(np.stack((g.real, g.imag)), np.stack((e.real, e.imag)), rtol=1e-4, atol_rms=1e-4, what="d/d memory_fft")
+    head(x, memory_fft=mem.detach()).sum()                            # frozen memory (as in the reference): no graph needed
 
 
 def test_mean_pooling_fold_is_the_same_layer():
