@@ -23,7 +23,10 @@ SOURCES = ["spectre_hip.hip", "copy_probe.hip", "wavelet.hip", "regtile_n4096.hi
            "regtile_n256.hip", "regtile_wide.hip", "regtile_n3000.hip", "regtile_mixedp.hip", "regtile_n768.hip", "regtile_n1536.hip",
            "regtile_n3072.hip", "regtile_n1000.hip", "regtile_n2000.hip", "regtile_n1280.hip", "regtile_n2560.hip", "regtile_n3840.hip",
            "regtile_mixed_small.hip", "regtile_mixed_mid.hip", "regtile_mixed_mid2.hip", "regtile_n2400.hip", "regtile_n3600.hip", "regtile_n8192.hip", "regtile_n6144.hip", "regtile_n16384.hip", "regtile_n12288.hip"]
-HEADERS = ["fft_regs.h", "fft_regs_mixed.h", "fft_tables_mixed.h", "kernel_regtile.h", "kernel_regtile64p.h", "kernel_tickets.h", "kernel_regtile_wide.h", "kernel_regtile_grad.h", "kernel_regtile_mixed.h", "kernel_regtile_mixedp.h", "kernel_regtile_mixed_grad.h", "kernel_regtile_long.h", "kernel_regtile_long_grad.h", "kernel_regtile_quad.h", "kernel_stockham.h", "kernel_gate.h", "kernel_gate_grad_twopass.h", "kernel_decode.h", "kernel_wavelet.h", os.path.join("..", "..", "include", "spectre_hip.h")]
+HEADERS = ["fft_regs.h", "fft_regs_mixed.h", "fft_tables_mixed.h", "kernel_regtile.h", "kernel_regtile64p.h", "kernel_tickets.h", "kernel_regtile_wide.h", "kernel_regtile_grad.h", "kernel_regtile_mixed.h", "kernel_regtile_mixedp.h", "kernel_regtile_mixed_grad.h", "kernel_regtile_long.h", "kernel_regtile_long_grad.h", "kernel_regtile_quad.h", "kernel_stockham.h", "kernel_gate.h", "kernel_gate_grad_twopass.h", "kernel_decode.h", os.path.join("..", "..", "include", "spectre_hip.h")]
+
+# headers only ONE translation unit includes: a change rebuilds that unit, not all of them
+OWN_HEADERS = {"wavelet.hip": ["kernel_wavelet.h"]}
 
 # -fno-slp-vectorize: SLP packs the butterflies into v_pk_*_f32 (no faster than two scalar ops on gfx950)
 # plus register-pair shuffles, which pushes the 64-point kernel past 256 VGPRs into scratch.
@@ -67,6 +70,7 @@ def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
     deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS] + [os.path.join(HERE, "isa_lint.py")]
+    deps += [os.path.join(CSRC, h) for hs in OWN_HEADERS.values() for h in hs]
     return _newest(deps) > os.path.getmtime(LIB)
 
 
@@ -80,7 +84,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     def compile_one(src: str) -> str:
         obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
-        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(hdr_time, os.path.getmtime(os.path.join(CSRC, src))):
+        own = [os.path.getmtime(os.path.join(CSRC, h)) for h in OWN_HEADERS.get(src, [])]
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(hdr_time, os.path.getmtime(os.path.join(CSRC, src)), *own):
             return obj                                # up to date (every translation unit includes most of the headers)
         # -save-temps=obj in a scratch directory of its own: the device listing (.s) is a by-product of the compile that the lint reads
         tmp = os.path.join(OBJDIR, "tmp_" + src.replace(".hip", ""))

@@ -35,7 +35,7 @@ int wavelet_refine(const SpectreWaveletArgs* p, const char** why) {
     *why = "the Haar round trip needs a power-of-two sequence length (the reference raises for any other, spectre.py:271)";
     return SPECTRE_E_UNSUPPORTED;
   }
-  const int C = wavelet_channels(p->N);
+  int C = wavelet_channels(p->N);
   if (!C) { *why = "sequence too long for the LDS-resident Haar round trip (N <= 32768)"; return SPECTRE_E_UNSUPPORTED; }
   if (p->B == 0) return SPECTRE_OK;
   if (p->B > 65535) { *why = "B > 65535"; return SPECTRE_E_UNSUPPORTED; }
@@ -45,20 +45,45 @@ int wavelet_refine(const SpectreWaveletArgs* p, const char** why) {
   if (!g.ok) { *why = "cannot select the device"; return SPECTRE_E_HIP; }
   WaveletArgs a{};
   a.v = p->v; a.out = p->out; a.vref = p->vref; a.mask = static_cast<const unsigned char*>(p->mask); a.gate = static_cast<const float*>(p->gate);
-  a.B = (int)p->B; a.N = (int)p->N; a.D = (int)p->D; a.C = C;
+  a.B = (int)p->B; a.N = (int)p->N; a.D = (int)p->D;
   a.levels = 0;
   while (((int64_t)1 << a.levels) < p->N) ++a.levels;          // int(log2(N)) levels, down to one approximation sample (spectre.py:296, :307)
   a.v_sb = p->v_sb; a.v_sn = p->v_sn; a.out_sb = p->out_sb; a.out_sn = p->out_sn; a.ref_sb = p->ref_sb; a.ref_sn = p->ref_sn;
-  const size_t lds = (size_t)p->N * C * sizeof(float);
-  const dim3 grid((unsigned)((p->D + C - 1) / C), (unsigned)p->B), block(kWaveletThreads);
   hipStream_t stream = reinterpret_cast<hipStream_t>(p->stream);
-  hipError_t e;
-  if (p->dtype == SPECTRE_BF16) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(spectre_wavelet_refine_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e == hipSuccess) hipLaunchKernelGGL(spectre_wavelet_refine_kernel<true>, grid, block, lds, stream, a);
+  // 16-byte (8-byte for bf16) accesses where every one of them stays aligned: whole tiles, channel strides and bases multiples of four
+  const int64_t esz = p->dtype == SPECTRE_BF16 ? 2 : 4;
+  auto al = [&](const void* q, int64_t sb, int64_t sn) { return !q || (reinterpret_cast<uintptr_t>(q) % (4 * esz) == 0 && sb % 4 == 0 && sn % 4 == 0); };
+  const bool aligned = al(p->v, p->v_sb, p->v_sn) && al(p->out, p->out_sb, p->out_sn) && al(p->vref, p->ref_sb, p->ref_sn);
+  hipError_t e = hipSuccess;
+  size_t lds = 0;
+  dim3 grid, block(kWaveletThreads);
+  auto go = [&](auto kernel) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) hipLaunchKernelGGL(kernel, grid, block, lds, stream, a);
+  };
+  // level 0 in registers: the approximation band of a tile of Cr channels is N / 2 * Cr floats (<= 128 KiB), a thread holds P = N * Cr / 4096 pairs
+  int Cr = 16;
+  while (Cr > 4 && (p->N / 2) * Cr > kWaveletMaxFloats) Cr >>= 1;
+  const int64_t P = p->N * Cr / 4096;
+  if (aligned && p->N >= 256 && (p->N / 2) * Cr <= kWaveletMaxFloats && p->D % Cr == 0 && P >= 1 && P <= 16) {
+    a.C = Cr;
+    lds = (size_t)(p->N / 2) * Cr * sizeof(float);
+    grid = dim3((unsigned)(p->D / Cr), (unsigned)p->B);
+    const bool bf = p->dtype == SPECTRE_BF16;
+    switch ((int)P) {
+      case 1: if (bf) go(spectre_wavelet_refine_regs_kernel<true, 1>); else go(spectre_wavelet_refine_regs_kernel<false, 1>); break;
+      case 2: if (bf) go(spectre_wavelet_refine_regs_kernel<true, 2>); else go(spectre_wavelet_refine_regs_kernel<false, 2>); break;
+      case 4: if (bf) go(spectre_wavelet_refine_regs_kernel<true, 4>); else go(spectre_wavelet_refine_regs_kernel<false, 4>); break;
+      case 8: if (bf) go(spectre_wavelet_refine_regs_kernel<true, 8>); else go(spectre_wavelet_refine_regs_kernel<false, 8>); break;
+      default: if (bf) go(spectre_wavelet_refine_regs_kernel<true, 16>); else go(spectre_wavelet_refine_regs_kernel<false, 16>); break;
+    }
   } else {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(spectre_wavelet_refine_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e == hipSuccess) hipLaunchKernelGGL(spectre_wavelet_refine_kernel<false>, grid, block, lds, stream, a);
+    a.C = C;
+    lds = (size_t)p->N * C * sizeof(float);
+    grid = dim3((unsigned)((p->D + C - 1) / C), (unsigned)p->B);
+    const bool vec = C >= 4 && p->D % C == 0 && aligned;
+    if (p->dtype == SPECTRE_BF16) { if (vec) go(spectre_wavelet_refine_kernel<true, 4>); else go(spectre_wavelet_refine_kernel<true, 1>); }
+    else { if (vec) go(spectre_wavelet_refine_kernel<false, 4>); else go(spectre_wavelet_refine_kernel<false, 1>); }
   }
   if (e == hipSuccess) e = hipGetLastError();
   if (e != hipSuccess) { *why = hipGetErrorString(e); return SPECTRE_E_HIP; }

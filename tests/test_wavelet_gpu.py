@@ -28,7 +28,9 @@ def _problem(B, N, D, seed, p_on=0.5):
 
 
 @pytest.mark.parametrize("B,N,D", [(3, 1, 4), (3, 2, 8), (2, 4, 3), (4, 8, 16), (5, 64, 48), (3, 256, 40), (2, 1024, 17), (3, 2048, 32),
-                                   (3, 4096, 24), (2, 8192, 12), (2, 16384, 6), (2, 32768, 3)])
+                                   (3, 4096, 24), (2, 8192, 12), (2, 16384, 6), (2, 32768, 3),
+                                   # whole aligned tiles: level 0 in registers (P = 1, 2, 4, 8, 16 pairs per thread; 16 / 8 / 4 channels per tile)
+                                   (3, 256, 16), (2, 512, 32), (2, 1024, 48), (3, 2048, 64), (3, 4096, 32), (2, 8192, 16), (2, 16384, 8)])
 def test_kernel_against_oracle(B, N, D):
     from fft_amd import wavelet_refine
     v, gate, mask = _problem(B, N, D, seed=N + D)
@@ -57,6 +59,12 @@ def test_strided_views_and_bf16():
     torch.cuda.synchronize()
     e = wavelet_refinement_numpy(v.numpy(), gate.numpy(), mask.numpy())
     assert_close(out.cpu().numpy(), e, rtol=1e-5, atol_rms=1e-5, what="strided view, in place")
+    big2 = torch.zeros(4, 512, 128)
+    big2[:, :, 32:112] = v
+    view2 = big2.to(DEV)[:, :, 32:112]                                                     # 80 = 5 x 16 channels at an aligned offset: the register form, strided
+    out2, ref2 = wavelet_refine(view2, gate.to(DEV), mask.to(DEV), want_ref=True)
+    assert_close(out2.cpu().numpy(), e, rtol=1e-5, atol_rms=1e-5, what="strided view, register form")
+    assert torch.equal(wavelet_refine(view2, gate.to(DEV), mask.to(DEV), inplace=True)[0], out2)
     vb = v.to(torch.bfloat16)
     ob, rb = wavelet_refine(vb.to(DEV), gate.to(DEV), mask.to(DEV), want_ref=True)
     torch.cuda.synchronize()
