@@ -88,16 +88,17 @@ template <bool BF16, int VEC> __device__ inline void wv_store_pack(void* p, long
 // overwrites it; the one exception is the wrap (pair 0's hi lives in row L - 1, which the top pair overwrites): it is read first.
 constexpr int kWaveletChunk = 8;
 
+template <int T = kWaveletThreads>
 __device__ inline void wv_pyramid(float* wx, const int N, const int levels, const int cs, const int tid) {
   const int C = 1 << cs;
   const float s = 0.70710678118654752440f;
   for (int l = 0; l < levels; ++l) {                           // analysis, in place
     const int L = N >> l, work = (L >> 1) << cs;
-    for (int i0 = tid; i0 < work; i0 += kWaveletThreads * kWaveletChunk) {
+    for (int i0 = tid; i0 < work; i0 += T * kWaveletChunk) {
       float xa[kWaveletChunk], xb[kWaveletChunk];
 #pragma unroll
       for (int u = 0; u < kWaveletChunk; ++u) {
-        const int i = i0 + u * kWaveletThreads, j = i >> cs, c = i & (C - 1);
+        const int i = i0 + u * T, j = i >> cs, c = i & (C - 1);
         if (i < work) {
           xa[u] = wx[((((2 * j - 1) & (L - 1)) << l) << cs) + c];
           xb[u] = wx[(((2 * j) << l) << cs) + c];
@@ -105,7 +106,7 @@ __device__ inline void wv_pyramid(float* wx, const int N, const int levels, cons
       }
 #pragma unroll
       for (int u = 0; u < kWaveletChunk; ++u) {
-        const int i = i0 + u * kWaveletThreads, j = i >> cs, c = i & (C - 1);
+        const int i = i0 + u * T, j = i >> cs, c = i & (C - 1);
         if (i < work) {
           wx[(((2 * j) << l) << cs) + c] = (xa[u] + xb[u]) * s;
           wx[((((2 * j - 1) & (L - 1)) << l) << cs) + c] = (xb[u] - xa[u]) * s;
@@ -116,15 +117,15 @@ __device__ inline void wv_pyramid(float* wx, const int N, const int levels, cons
   }
   for (int l = levels - 1; l >= 0; --l) {                      // synthesis
     const int L = N >> l, work = (L >> 1) << cs;
-    const int chunks = (work + kWaveletThreads * kWaveletChunk - 1) / (kWaveletThreads * kWaveletChunk);
+    const int chunks = (work + T * kWaveletChunk - 1) / (T * kWaveletChunk);
     float hi_wrap = 0.f;
     if (chunks > 1 && tid < C) hi_wrap = wx[(((L - 1) << l) << cs) + tid];      // item (pair 0, channel tid) is this thread's first item
     for (int ch = chunks - 1; ch >= 0; --ch) {
-      const int i0 = tid + ch * kWaveletThreads * kWaveletChunk;
+      const int i0 = tid + ch * T * kWaveletChunk;
       float lo[kWaveletChunk], hi[kWaveletChunk];
 #pragma unroll
       for (int u = 0; u < kWaveletChunk; ++u) {
-        const int i = i0 + u * kWaveletThreads, j = i >> cs, c = i & (C - 1);
+        const int i = i0 + u * T, j = i >> cs, c = i & (C - 1);
         if (i < work) {
           lo[u] = wx[(((2 * j) << l) << cs) + c];
           hi[u] = wx[((((2 * j - 1) & (L - 1)) << l) << cs) + c];
@@ -134,7 +135,7 @@ __device__ inline void wv_pyramid(float* wx, const int N, const int levels, cons
       __syncthreads();
 #pragma unroll
       for (int u = 0; u < kWaveletChunk; ++u) {
-        const int i = i0 + u * kWaveletThreads, j = i >> cs, c = i & (C - 1);
+        const int i = i0 + u * T, j = i >> cs, c = i & (C - 1);
         if (i < work) {
           wx[(((2 * j) << l) << cs) + c] = (lo[u] + hi[u]) * s;
           wx[(((2 * j + 1) << l) << cs) + c] = (lo[u] - hi[u]) * s;
@@ -214,24 +215,24 @@ __global__ __launch_bounds__(kWaveletThreads) void spectre_wavelet_refine_kernel
 // tile) and the deeper levels move half the bytes.  The detail band never leaves the registers, v is read from HBM ONCE (out = v + ... adds
 // to the registers' copy; the one row per thread that belongs to the next thread's first pair is fetched a second time), and the output
 // rows (2j, 2j+1) leave as two 16-byte stores per pair.
-template <bool BF16, int P>
-__global__ __launch_bounds__(kWaveletThreads) void spectre_wavelet_refine_regs_kernel(WaveletArgs a) {
+template <bool BF16, int P, int T = kWaveletThreads>
+__global__ __launch_bounds__(T) void spectre_wavelet_refine_regs_kernel(WaveletArgs a) {
   extern __shared__ float wx[];                                // approximation band [N / 2][C]
   const int tid = threadIdx.x, b = blockIdx.y, C = a.C, N = a.N;
   if (!a.mask[b]) {
     if (a.out != a.v) {                                        // out of place: the switched-off element's tile is copied
       const int c0o = blockIdx.x * C, cso = __ffs(C) - 1, packs = (N << cso) >> 2, co = (tid * 4) & (C - 1);
       const long long vb = (long long)b * a.v_sb + c0o + co, ob = (long long)b * a.out_sb + c0o + co;
-      for (int p0 = tid; p0 < packs; p0 += kWaveletThreads * kWaveletBurst) {
+      for (int p0 = tid; p0 < packs; p0 += T * kWaveletBurst) {
         WvPack<BF16, 4> r[kWaveletBurst];
 #pragma unroll
         for (int k = 0; k < kWaveletBurst; ++k) {
-          const int i = (p0 + k * kWaveletThreads) * 4;
+          const int i = (p0 + k * T) * 4;
           r[k] = wv_load_pack<BF16, 4>(a.v, i < (N << cso) ? vb + (long long)(i >> cso) * a.v_sn : vb);
         }
 #pragma unroll
         for (int k = 0; k < kWaveletBurst; ++k) {
-          const int i = (p0 + k * kWaveletThreads) * 4;
+          const int i = (p0 + k * T) * 4;
           if (i < (N << cso)) wv_store_pack<BF16, 4>(a.out, ob + (long long)(i >> cso) * a.out_sn, r[k]);
         }
       }
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(kWaveletThreads) void spectre_wavelet_refine_regs_k
 #pragma unroll
     for (int e = 0; e < 4; ++e) wx[((j0 + q) << cs) + c + e] = (xa[q].x[e] + xb[q].x[e]) * s;
   __syncthreads();
-  wv_pyramid(wx, N >> 1, a.levels - 1, cs, tid);
+  wv_pyramid<T>(wx, N >> 1, a.levels - 1, cs, tid);
 #pragma unroll
   for (int q = 0; q < P; ++q) {
     const int rb = 2 * (j0 + q);
