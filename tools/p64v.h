@@ -154,7 +154,7 @@ template <int SPLIT> constexpr int p64v_younger_first() { return 4 * (8 - SPLIT)
 //         right behind E2 of the previous one, none behind its stores (round 3: the fp32 kernel's late groups cost a memory latency
 //         per tile — same-box ablation: loads only 1.11 ms, stores only 0.90, neither 0.84).
 // OUT_BF16 = bf16 rows out (round to nearest even, like every other kernel here): a lane stores its 4 channels as 8 bytes.
-template <int SPLIT, int PF, bool WITH_MEM = false, bool IN_BF16 = false, bool OUT_BF16 = false, int GANGX = 0, int AUXD = 0, int AUXL = 0, int AUXS = 0, int PRIO = 0, int MAPX = 0, int DSPREAD = 0, int SYNCP = 0, int TSTAMP = 0, int PFL2 = 0, int STAG = 0, int PFSP = 0, int LATE = 0, int RLF = 0, int PARK = 0, int ESPREAD = 1, int EARLY1 = 0, int SKEW = 0>
+template <int SPLIT, int PF, bool WITH_MEM = false, bool IN_BF16 = false, bool OUT_BF16 = false, int GANGX = 0, int AUXD = 0, int AUXL = 0, int AUXS = 0, int PRIO = 0, int MAPX = 0, int DSPREAD = 0, int SYNCP = 0, int TSTAMP = 0, int PFL2 = 0, int STAG = 0, int PFSP = 0, int LATE = 0, int RLF = 0, int PARK = 0, int ESPREAD = 1, int EARLY1 = 0, int SKEW = 0, int MEET = 0>
 __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) {
   constexpr int ESI = IN_BF16 ? 2 : 4, ESO = OUT_BF16 ? 2 : 4;   // bytes per input / output element
   constexpr float inv_n = 1.0f / 4096.0f;
@@ -283,7 +283,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
   [[maybe_unused]] unsigned nsync = 0;
   [[maybe_unused]] bool sync_on = true;
   [[maybe_unused]] auto gang_meet = [&]() {
-    unsigned* cp = reinterpret_cast<unsigned*>(const_cast<float*>(a.mem)) + (MAPX ? 0 : wg_lin / GANG);
+    unsigned* cp = reinterpret_cast<unsigned*>(const_cast<float*>(a.mem)) + (MAPX >= 4 ? 12288 + 16 * (wg_lin >> 1) : MAPX ? 0 : wg_lin / GANG);   // (pair tickets: the pair is static, only its tiles are drawn)
     ++nsync;
     if (__builtin_amdgcn_readfirstlane(tid0 >> 6) == 0) {
       if (lane == 0) __hip_atomic_fetch_add(cp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -297,6 +297,28 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
         }
         if (i == 128) sync_on = false;
       }
+    }
+    p64v_barrier();
+  };
+
+  // MEET (round 6, third session): the pair's rendezvous in front of the STORE BURST under the ticket order — 1: arrive + poll there (gang_meet
+  // in place of the burst's barrier); 2: arrive behind E2 (one fire-and-forget atomic, ~2 us earlier), poll in front of the burst
+  [[maybe_unused]] auto gang_arrive = [&]() {
+    unsigned* cp = reinterpret_cast<unsigned*>(const_cast<float*>(a.mem)) + 12288 + 16 * (wg_lin >> 1);
+    ++nsync;
+    if (__builtin_amdgcn_readfirstlane(tid0 >> 6) == 0 && lane == 0) __hip_atomic_fetch_add(cp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  [[maybe_unused]] auto gang_wait = [&]() {
+    unsigned* cp = reinterpret_cast<unsigned*>(const_cast<float*>(a.mem)) + 12288 + 16 * (wg_lin >> 1);
+    if (__builtin_amdgcn_readfirstlane(tid0 >> 6) == 0 && sync_on) {
+      int i = 0;
+      for (; i < 128; ++i) {
+        unsigned val;
+        asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(val) : "s"(cp) : "memory");
+        if (val >= (unsigned)GANG * nsync) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (i == 128) sync_on = false;
     }
     p64v_barrier();
   };
@@ -766,6 +788,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
     else p64v_exchange_rest<true>(z, img, p, u);
     mark(6);                                       // deferred stores / loads issue, E1, middle, E2
     if constexpr (SYNCP == 1 || SYNCP == 6) gang_meet();
+    if constexpr (MEET == 2) gang_arrive();
 
     // ---- the image is idle until the next F1: let the first row groups of the next tile land in it, and fetch its gate -----
     const uint32_t voff = (uint32_t)(((long long)(u + 512 * h) * v_sn + 4 * pp) * ESI);
@@ -917,6 +940,7 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
         });
         if constexpr (SYNCP == 3 || SYNCP == 5 || SYNCP == 7) gang_meet();
         mark(7);                                   // DMA issue, twiddles, I2 (wave 0's own)
+        if constexpr (MEET == 1) gang_meet(); else if constexpr (MEET == 2) gang_wait(); else
         if constexpr (SYNCP >= 9) p64v_barrier();
         mark(8);                                   // barrier in front of the burst (the slowest wave's I2)
         if constexpr (PRIO == 4) __builtin_amdgcn_s_setprio(3);
