@@ -431,6 +431,31 @@ def main():
             g32 = B * N * D * 4 / ld / 1e6
             variants["backward_dgate"].update({"load_only_32B_segments_GBps": g32, "frac_of_32B_load_only": variants["backward_dgate"]["achieved_GBps"] / g32})
         del dout
+        # the launch between the heads' concatenation and out_proj in the reference's DEFAULT layer (WaveletRefinement, spectre.py:819-887; beyond
+        # SURVEY section 8), informational: in place on the mix's output, the reference's default rate 0.1 and every element on
+        try:
+            from fft_amd import wavelet_refine
+            if N & (N - 1) == 0 and out.dtype in (torch.float32, torch.bfloat16):
+                wgate = torch.rand(B, D, device=dev)
+                wgen = torch.Generator(device=dev).manual_seed(7)
+                for wname, rate in (("wavelet_refine_on_rate_0.1", 0.1), ("wavelet_refine_all_on", 1.0)):
+                    wmask = torch.rand(B, device=dev, generator=wgen) < rate
+                    n_on = int(wmask.sum())
+                    for _ in range(5):
+                        wavelet_refine(out, wgate, wmask, inplace=True)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(10):
+                        wavelet_refine(out, wgate, wmask, inplace=True)
+                    e1.record(); torch.cuda.synchronize()
+                    ms = e0.elapsed_time(e1) / 10
+                    byt = 2 * n_on * N * D * out.element_size()          # rows of the switched-on elements in and out
+                    variants[wname] = {"kernel_ms": ms, "elements_on": n_on, "achieved_GBps": byt / ms / 1e6 if ms > 0 else 0.0,
+                                       "roofline_frac": byt / ms / 1e6 / HBM_PEAK_GBS if ms > 0 else 0.0}
+                for _ in range(3):
+                    step()                                                # (the refinement overwrote `out`; leave a valid result behind)
+        except Exception as exc:                                          # informational: never take the line down
+            variants["wavelet_refine_on_rate_0.1"] = {"error": repr(exc)}
 
     if rank == 0:
         es = V.element_size()
