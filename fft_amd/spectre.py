@@ -226,7 +226,9 @@ class SpectreHead(nn.Module):
             q_pool = self.q_norm(self.W_q(x.mean(dim=1)))
         else:
             q_pool = self.q_norm(self.pooling(self.W_q(x)))
-        anchors = torch.view_as_complex(self.gate_mlp(q_pool).view(Bsz, self.G, self.B, 2))
+        # .float(): under autocast the MLP returns bf16 / fp16, which view_as_complex refuses (the reference raises there: it is fp32-only);
+        # the filter is complex64 either way, the mix then runs on the autocast dtype's rows (bf16 storage, fp32 arithmetic)
+        anchors = torch.view_as_complex(self.gate_mlp(q_pool).float().view(Bsz, self.G, self.B, 2))
         wants_graph = torch.is_grad_enabled() and (anchors.requires_grad or self.modrelu.bias.requires_grad or
                                                    (pos_phase is not None and pos_phase.requires_grad))
         if x.is_cuda and anchors.dtype == torch.complex64 and not wants_graph:

@@ -187,3 +187,38 @@ def test_layers_with_the_refinement_match_the_reference(path, fused):
         assert_close(prm.grad.cpu().numpy(), d[key], rtol=1e-4, atol_rms=1e-3, what="d/d " + name)
         checked += "wavelet_refinement" in name
     assert checked == 4                                             # the refinement's gate MLP learns (two Linear layers), as in the reference
+
+
+def test_block_under_autocast_and_in_a_graph():
+    """bf16 autocast (per-head path, bf16 rows through the mix and the refinement, fp32 gate) stays close to the fp32 block; and the default
+    block's inference forward — coin flip included — replays from a hipGraph (the mask is drawn and read on the device: nothing looks at it on the host)."""
+    from fft_amd import SpectreBlock
+    torch.manual_seed(3)
+    blk = SpectreBlock(64, 2, 256, pooling_type="mean", num_groups=2, wavelet_on_rate=0.5, memory_size=9).to(DEV).eval()
+    x = torch.randn(4, 256, 64, device=DEV)
+    mask = torch.tensor([True, False, True, True])
+    blk.mix.wavelet_refinement.forced_mask = mask
+    with torch.no_grad():
+        want = blk(x)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            got = blk(x)
+    assert torch.isfinite(got).all()
+    err = (got.float() - want).abs().max().item() / want.abs().max().item()
+    assert err < 3e-2, err
+    xg = x.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        blk(xg).float().square().mean().backward()
+    assert torch.isfinite(xg.grad).all() and all(p.grad is not None and torch.isfinite(p.grad).all() for n, p in blk.named_parameters() if p.requires_grad)
+    # graph capture with the DRAWN mask
+    blk.mix.wavelet_refinement.forced_mask = None
+    with torch.no_grad():
+        blk(x); torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            y = blk(x)
+        outs = []
+        for _ in range(6):
+            g.replay(); torch.cuda.synchronize()
+            outs.append(y.clone())
+    assert all(torch.isfinite(o).all() for o in outs)
+    assert any(not torch.equal(outs[0], o) for o in outs[1:])            # a fresh coin flip per replay (the generator advances under the graph)
