@@ -31,8 +31,25 @@ struct WaveletArgs {
   const unsigned char* mask;  // (B) one byte per batch element, non-zero = on
   const float* gate;          // (B, D) f32
   int B, N, D, C, levels;
+  int tiles, gang;            // channel tiles per batch element (the launch is tiles * B workgroups, one-dimensional); tiles per 128-byte line
   long long v_sb, v_sn, out_sb, out_sn, ref_sb, ref_sn;   // element strides
 };
+
+// Workgroup -> (batch element, channel tile).  The hardware deals workgroup ids round-robin over the 8 XCDs, each with an L2 of its own; the
+// `gang` tiles that share a row's 128-byte line must meet in ONE L2 and close in time, or every line is fetched once per XCD that holds a piece
+// of it and its pieces are written back separately (tools/fold_lab.hip: a half line costs a line then).  A gang's members are therefore the ids
+// x, x + 8, x + 16, ... (congruent mod 8 = one XCD, neighbours in dispatch order), and consecutive gangs go round the XCDs, so that the tiles of
+// a switched-on batch element spread over the whole chip whatever the mask looks like (one XCD per element made the default rate slower).
+__device__ inline void wv_tile(const WaveletArgs& a, int& b, int& ct) {
+  const int n = gridDim.x, id = blockIdx.x, span = 8 * a.gang;
+  int w = id;
+  if (n % span == 0) {
+    const int grp = id / span, r = id - grp * span;
+    w = a.gang * (grp * 8 + (r & 7)) + (r >> 3);
+  }
+  b = w / a.tiles;
+  ct = w - b * a.tiles;
+}
 
 constexpr int kWaveletThreads = 512;
 constexpr int kWaveletMaxFloats = 32768;                       // N * C, 128 KiB of the 160-KiB LDS
@@ -149,8 +166,10 @@ __device__ inline void wv_pyramid(float* wx, const int N, const int levels, cons
 template <bool BF16, int VEC>
 __global__ __launch_bounds__(kWaveletThreads) void spectre_wavelet_refine_kernel(WaveletArgs a) {
   extern __shared__ float wx[];                                // [N][C]
-  const int tid = threadIdx.x, b = blockIdx.y, C = a.C, N = a.N;
-  const int c0 = blockIdx.x * C, cw = min(C, a.D - c0);
+  const int tid = threadIdx.x, C = a.C, N = a.N;
+  int b, ct;
+  wv_tile(a, b, ct);
+  const int c0 = ct * C, cw = min(C, a.D - c0);
   const int cs = __ffs(C) - 1;                                 // C is a power of two
   const int total = N << cs, packs = total / VEC;              // (VEC = 4: C >= 4, so a pack never crosses a row)
   const long long vb = (long long)b * a.v_sb + c0, ob = (long long)b * a.out_sb + c0, rb0 = (long long)b * a.ref_sb + c0;
@@ -218,10 +237,12 @@ __global__ __launch_bounds__(kWaveletThreads) void spectre_wavelet_refine_kernel
 template <bool BF16, int P, int T = kWaveletThreads>
 __global__ __launch_bounds__(T) void spectre_wavelet_refine_regs_kernel(WaveletArgs a) {
   extern __shared__ float wx[];                                // approximation band [N / 2][C]
-  const int tid = threadIdx.x, b = blockIdx.y, C = a.C, N = a.N;
+  const int tid = threadIdx.x, C = a.C, N = a.N;
+  int b, ct;
+  wv_tile(a, b, ct);
   if (!a.mask[b]) {
     if (a.out != a.v) {                                        // out of place: the switched-off element's tile is copied
-      const int c0o = blockIdx.x * C, cso = __ffs(C) - 1, packs = (N << cso) >> 2, co = (tid * 4) & (C - 1);
+      const int c0o = ct * C, cso = __ffs(C) - 1, packs = (N << cso) >> 2, co = (tid * 4) & (C - 1);
       const long long vb = (long long)b * a.v_sb + c0o + co, ob = (long long)b * a.out_sb + c0o + co;
       for (int p0 = tid; p0 < packs; p0 += T * kWaveletBurst) {
         WvPack<BF16, 4> r[kWaveletBurst];
@@ -242,8 +263,8 @@ __global__ __launch_bounds__(T) void spectre_wavelet_refine_regs_kernel(WaveletA
   const int cs = __ffs(C) - 1, Q = C >> 2;                     // quads per row
   const int tq = tid & (Q - 1), tb = tid / Q;                  // (Q is a power of two)
   const int c = 4 * tq, j0 = tb * P;
-  const long long vb = (long long)b * a.v_sb + blockIdx.x * C + c, ob = (long long)b * a.out_sb + blockIdx.x * C + c,
-                  rb0 = (long long)b * a.ref_sb + blockIdx.x * C + c;
+  const long long vb = (long long)b * a.v_sb + ct * C + c, ob = (long long)b * a.out_sb + ct * C + c,
+                  rb0 = (long long)b * a.ref_sb + ct * C + c;
   const float s = 0.70710678118654752440f;
   WvPack<BF16, 4> xa[P], xb[P], edge;
 #pragma unroll
@@ -255,7 +276,7 @@ __global__ __launch_bounds__(T) void spectre_wavelet_refine_regs_kernel(WaveletA
   edge = wv_load_pack<BF16, 4>(a.v, vb + (long long)(2 * (j0 + P) - 1) * a.v_sn);     // x[2j+1] of the last pair = the next thread's first row
   float g[4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) g[e] = a.gate[(long long)b * a.D + blockIdx.x * C + c + e];
+  for (int e = 0; e < 4; ++e) g[e] = a.gate[(long long)b * a.D + ct * C + c + e];
 #pragma unroll
   for (int q = 0; q < P; ++q)
 #pragma unroll

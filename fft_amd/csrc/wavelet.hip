@@ -2,6 +2,7 @@
 // spectre_wavelet_gate_grad (spectre_hip.hip) validate nothing themselves and report this unit's `why` through spectre_last_error().
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 #include "kernel_wavelet.h"
 #include "../../include/spectre_hip.h"
 
@@ -38,7 +39,7 @@ int wavelet_refine(const SpectreWaveletArgs* p, const char** why) {
   int C = wavelet_channels(p->N);
   if (!C) { *why = "sequence too long for the LDS-resident Haar round trip (N <= 32768)"; return SPECTRE_E_UNSUPPORTED; }
   if (p->B == 0) return SPECTRE_OK;
-  if (p->B > 65535) { *why = "B > 65535"; return SPECTRE_E_UNSUPPORTED; }
+  if (p->B * ((p->D + 3) / 4) >= ((int64_t)1 << 31)) { *why = "too many tiles for one launch"; return SPECTRE_E_UNSUPPORTED; }
   if (!p->v || !p->out || !p->mask || !p->gate) { *why = "v, out, mask and gate must be non-NULL device pointers"; return SPECTRE_E_INVALID; }
   if (p->vref && (p->vref == p->v || p->vref == p->out)) { *why = "vref must not alias v or out"; return SPECTRE_E_INVALID; }
   DeviceScope g(p->device);
@@ -68,7 +69,9 @@ int wavelet_refine(const SpectreWaveletArgs* p, const char** why) {
   if (aligned && p->N >= 256 && (p->N / 2) * Cr <= kWaveletMaxFloats && p->D % Cr == 0 && P >= 1 && P <= 16) {
     a.C = Cr;
     lds = (size_t)(p->N / 2) * Cr * sizeof(float);
-    grid = dim3((unsigned)(p->D / Cr), (unsigned)p->B);
+    a.tiles = (int)(p->D / Cr);
+    a.gang = (int)std::max<int64_t>(1, 128 / (Cr * esz));
+    grid = dim3((unsigned)(a.tiles * p->B));
     const bool bf = p->dtype == SPECTRE_BF16;
     switch ((int)P) {
       case 1: if (bf) go(spectre_wavelet_refine_regs_kernel<true, 1>); else go(spectre_wavelet_refine_regs_kernel<false, 1>); break;
@@ -80,7 +83,9 @@ int wavelet_refine(const SpectreWaveletArgs* p, const char** why) {
   } else {
     a.C = C;
     lds = (size_t)p->N * C * sizeof(float);
-    grid = dim3((unsigned)((p->D + C - 1) / C), (unsigned)p->B);
+    a.tiles = (int)((p->D + C - 1) / C);
+    a.gang = (int)std::max<int64_t>(1, 128 / (C * esz));
+    grid = dim3((unsigned)(a.tiles * p->B));
     const bool vec = C >= 4 && p->D % C == 0 && aligned;
     if (p->dtype == SPECTRE_BF16) { if (vec) go(spectre_wavelet_refine_kernel<true, 4>); else go(spectre_wavelet_refine_kernel<true, 1>); }
     else { if (vec) go(spectre_wavelet_refine_kernel<false, 4>); else go(spectre_wavelet_refine_kernel<false, 1>); }
