@@ -60,6 +60,11 @@ def resample_complex(anchors: torch.Tensor, size: int, mode: str = "cubic") -> t
     return torch.complex(re.squeeze(1), im.squeeze(1)).view(B, G, size)
 
 
+def interp_complex_1d(x: torch.Tensor, size: int, mode: str = "linear") -> torch.Tensor:
+    """The reference's name and defaults for `resample_complex` (spectre.py:26-30; its layers call it with mode="cubic", :526-528)."""
+    return resample_complex(x, size, mode)
+
+
 class ComplexModReLU(nn.Module):
     """z -> z * relu(|z| + b) / sqrt(|z|^2 + eps^2), one real bias per element (spectre.py:95-121)."""
 

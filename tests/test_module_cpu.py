@@ -88,3 +88,19 @@ def test_batch_shard_partitions():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         batch_shard(4, 2, 2)
+
+
+def test_reference_names_of_the_host_helpers():
+    """`interp_complex_1d(x, size, mode="linear")` (spectre.py:26-30) is importable under the reference's name with its default mode; endpoints
+    are aligned in the cubic mode (align_corners=True), so with one group the first and last anchors come back unchanged."""
+    import inspect
+    from fft_amd import interp_complex_1d, resample_complex
+    assert list(inspect.signature(interp_complex_1d).parameters) == ["x", "size", "mode"]
+    assert inspect.signature(interp_complex_1d).parameters["mode"].default == "linear"
+    x = torch.randn(2, 3, 9, dtype=torch.complex64, generator=torch.Generator().manual_seed(0))
+    for mode in ("cubic", "linear", "nearest"):
+        assert torch.equal(interp_complex_1d(x, 33, mode), resample_complex(x, 33, mode))
+    x1 = x[:, :1]                                                    # one group: with G > 1 the reference's stack(dim=1).reshape(B*G, 2, 1, K) deals the
+    y = interp_complex_1d(x1, 33, "cubic")                           # real / imaginary planes across the groups (spectre.py:42) — reproduced, not corrected
+    assert torch.allclose(y[..., 0], x1[..., 0], atol=1e-6) and torch.allclose(y[..., -1], x1[..., -1], atol=1e-6)
+    assert torch.equal(interp_complex_1d(x, 33), resample_complex(x, 33, "linear"))
