@@ -41,11 +41,11 @@ def test_binding_matches_header(built_library):
 
 
 def test_every_abi_struct_has_the_layout_the_c_compiler_gives_the_header(tmp_path):
-    """sizeof and every field offset of the eight argument structs: ctypes mirror (fft_amd/_native.py) vs gcc on include/spectre_hip.h."""
+    """sizeof and every field offset of the ten argument structs: ctypes mirror (fft_amd/_native.py) vs gcc on include/spectre_hip.h."""
     import subprocess
     from fft_amd import _native
     structs = ["SpectreMixArgs", "SpectreMixBwdArgs", "SpectreGateArgs", "SpectreGateBwdArgs", "SpectreRfftArgs", "SpectreDecodeArgs", "SpectreDecodeHeadArgs",
-               "SpectreProbeArgs"]
+               "SpectreProbeArgs", "SpectreWaveletArgs", "SpectreWaveletGradArgs"]
     lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "spectre_hip.h"', "int main(void) {"]
     for sname in structs:
         ct = getattr(_native, sname)
@@ -74,6 +74,13 @@ def test_invalid_arguments_fail_loudly_without_a_gpu(built_library):
     a = _native.SpectreMixArgs()                                 # all-zero args: never reaches a kernel
     assert lib.spectre_mix_fwd(ctypes.byref(a)) != 0
     assert len(lib.spectre_last_error()) > 0
+    assert lib.spectre_wavelet_refine(None) == 1 and b"spectre_wavelet_refine" in lib.spectre_last_error()
+    w = _native.SpectreWaveletArgs()
+    w.B, w.N, w.D = 1, 48, 8                                     # not a power of two: refused before anything touches a device
+    assert lib.spectre_wavelet_refine(ctypes.byref(w)) == 2 and b"power-of-two" in lib.spectre_last_error()
+    w.N = 65536
+    assert lib.spectre_wavelet_refine(ctypes.byref(w)) == 2 and b"too long" in lib.spectre_last_error()
+    assert lib.spectre_wavelet_gate_grad(None) == 1
 
 
 def test_no_cpu_fallback_in_product_path():
