@@ -318,7 +318,8 @@ struct WaveletGradArgs {
 template <bool BF16>
 __global__ __launch_bounds__(512) void spectre_wavelet_gate_grad_kernel(WaveletGradArgs a) {
   __shared__ float part[8][64];
-  const int b = blockIdx.y, lane = threadIdx.x & 63, ph = threadIdx.x >> 6, c = blockIdx.x * 64 + lane;
+  const int cblocks = (a.D + 63) >> 6;                       // (one-dimensional launch: cblocks * B workgroups)
+  const int b = blockIdx.x / cblocks, lane = threadIdx.x & 63, ph = threadIdx.x >> 6, c = (blockIdx.x - b * cblocks) * 64 + lane;
   const bool live = c < a.D;
   if (!a.mask[b]) {
     if (ph == 0 && live) a.dgate[(long long)b * a.D + c] = 0.f;

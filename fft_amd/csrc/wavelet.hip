@@ -100,7 +100,7 @@ int wavelet_gate_grad(const SpectreWaveletGradArgs* p, const char** why) {
   if (p->B < 0 || p->N < 1 || p->D < 1) { *why = "bad sizes"; return SPECTRE_E_INVALID; }
   if (p->dtype != SPECTRE_F32 && p->dtype != SPECTRE_BF16) { *why = "dtype must be SPECTRE_F32 or SPECTRE_BF16"; return SPECTRE_E_UNSUPPORTED; }
   if (p->B == 0) return SPECTRE_OK;
-  if (p->B > 65535) { *why = "B > 65535"; return SPECTRE_E_UNSUPPORTED; }
+  if (p->B * ((p->D + 63) / 64) >= ((int64_t)1 << 31)) { *why = "too many tiles for one launch"; return SPECTRE_E_UNSUPPORTED; }
   if (!p->dout || !p->vref || !p->mask || !p->dgate) { *why = "dout, vref, mask and dgate must be non-NULL device pointers"; return SPECTRE_E_INVALID; }
   DeviceScope g(p->device);
   if (!g.ok) { *why = "cannot select the device"; return SPECTRE_E_HIP; }
@@ -108,7 +108,7 @@ int wavelet_gate_grad(const SpectreWaveletGradArgs* p, const char** why) {
   a.dout = p->dout; a.vref = p->vref; a.mask = static_cast<const unsigned char*>(p->mask); a.dgate = static_cast<float*>(p->dgate);
   a.B = (int)p->B; a.N = (int)p->N; a.D = (int)p->D;
   a.d_sb = p->d_sb; a.d_sn = p->d_sn; a.ref_sb = p->ref_sb; a.ref_sn = p->ref_sn;
-  const dim3 grid((unsigned)((p->D + 63) / 64), (unsigned)p->B), block(512);
+  const dim3 grid((unsigned)(((p->D + 63) / 64) * p->B)), block(512);
   hipStream_t stream = reinterpret_cast<hipStream_t>(p->stream);
   if (p->dtype == SPECTRE_BF16) hipLaunchKernelGGL(spectre_wavelet_gate_grad_kernel<true>, grid, block, 0, stream, a);
   else hipLaunchKernelGGL(spectre_wavelet_gate_grad_kernel<false>, grid, block, 0, stream, a);
