@@ -10,8 +10,8 @@ from .functional import (copy_probe, describe, empty_on_fast_allocation, get_til
 from .decode import PrefixFFTCache, rfft_prefill
 from .shard import batch_shard
 from .spectre import (AttentionPooling, ComplexModReLU, DCTPooling, MeanPool, SpectreBlock, SpectreHead, SpectreMultiHead,
-                      WaveletRefinement, interp_complex_1d, resample_complex)
+                      WaveletRefinement, complex_conv1d, interp_complex_1d, resample_complex)
 
 __all__ = ["spectral_mix", "spectral_mix_backward", "spectral_gate_fused", "describe", "time_kernel", "set_tile_order", "get_tile_order", "copy_probe", "empty_on_fast_allocation", "SpectreHead", "SpectreMultiHead", "SpectreBlock", "WaveletRefinement", "wavelet_refine", "ComplexModReLU", "DCTPooling",
-           "AttentionPooling", "MeanPool", "resample_complex", "interp_complex_1d", "batch_shard", "PrefixFFTCache", "rfft_prefill"]
+           "AttentionPooling", "MeanPool", "resample_complex", "interp_complex_1d", "complex_conv1d", "batch_shard", "PrefixFFTCache", "rfft_prefill"]
 __version__ = "0.1.0"

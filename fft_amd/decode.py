@@ -145,10 +145,8 @@ def head_decode_step(head, q_t: torch.Tensor, v_t: torch.Tensor, cache: PrefixFF
 
     One C-ABI call (`spectre_decode_head_step`, four launches): running query sum -> LayerNorm -> gate MLP; cubic resample ->
     modReLU -> decode phase; spectrum update + filter + one-row inverse; partial sums + ring-buffer writes."""
-    if head.use_toeplitz:
-        raise NotImplementedError("use_toeplitz=True is not supported (the reference itself fails to construct it)")
     cache._require_hip()
-    if not _fused_head_ok(head):
+    if head.use_toeplitz or not _fused_head_ok(head):            # (the single-call path has no Toeplitz step: anchors through PyTorch ops then)
         return _head_decode_step_ops(head, q_t, v_t, cache)
     # The C entry point takes raw pointers and reads every operand as d (or n_fft-derived) float32 values: refuse anything
     # whose size, dtype or device does not match, where the reference would raise a shape error (ADVICE r01).
@@ -200,6 +198,9 @@ def _head_decode_step_ops(head, q_t: torch.Tensor, v_t: torch.Tensor, cache: Pre
     def gate_fn(sum_q, t, j):
         descr = head.q_norm((sum_q / cache.N).unsqueeze(0)).squeeze(0)                       # :578
         anchors = torch.view_as_complex(head.gate_mlp(descr).view(1, head.G, head.B, 2))     # :579-580
+        if head.use_toeplitz:                                                                 # :582-584
+            from .spectre import complex_conv1d
+            anchors = anchors + complex_conv1d(anchors, head.toeplitz_kernel, head.toeplitz_bw)
         phase = None
         if t != j:   # exp(1j*2*pi*k*(t-j)/N) is exactly 1 while t < N; afterwards the reference's float32 value is used
             k = torch.arange(head.F_half, device=anchors.device)

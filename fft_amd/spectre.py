@@ -65,6 +65,22 @@ def interp_complex_1d(x: torch.Tensor, size: int, mode: str = "linear") -> torch
     return resample_complex(x, size, mode)
 
 
+def complex_conv1d(x: torch.Tensor, kernel: torch.Tensor, padding: int) -> torch.Tensor:
+    """Complex circular cross-correlation along the last axis — same name, arguments and result as spectre.py:334-395:
+    `out[..., l] = sum_t kernel[t] * x[..., (l + t - padding) mod L]`, kernel (2 * padding + 1,) complex.
+
+    The reference runs four real `conv1d`s on circularly padded planes (its `padding_mode='circular'` branch cannot be taken: `F.conv1d` has
+    no such argument, so the padded fallback :384-391 is what executes); here the four are ONE real conv1d with two input and two output
+    channels (weight [[k_r, -k_i], [k_i, k_r]]) on the padded (re, im) planes — O(B * G * K) work on the anchors, differentiable by autograd."""
+    *batch_shape, L = x.shape
+    planes = torch.stack((x.real, x.imag), dim=-2).reshape(-1, 2, L)
+    planes = F.pad(planes, (padding, padding), mode="circular")
+    kr, ki = kernel.real, kernel.imag
+    weight = torch.stack((torch.stack((kr, -ki)), torch.stack((ki, kr))))          # (out = 2, in = 2, K)
+    y = F.conv1d(planes, weight.to(planes.dtype))
+    return torch.complex(y[:, 0], y[:, 1]).reshape(*batch_shape, L)
+
+
 class ComplexModReLU(nn.Module):
     """z -> z * relu(|z| + b) / sqrt(|z|^2 + eps^2), one real bias per element (spectre.py:95-121)."""
 
@@ -199,12 +215,16 @@ class SpectreHead(nn.Module):
         else:
             self.pooling = MeanPool()
 
+        # Toeplitz option (spectre.py:451-474, :519-521): a learnt complex kernel of 2 * bw + 1 taps, circularly correlated with the anchors along the
+        # bucket axis and added to them.  The reference's constructor cannot build it on current PyTorch (`self.toeplitz_kernel = None` followed by
+        # `register_parameter('toeplitz_kernel', None)` raises KeyError, :453-457); this one builds what `_reset_parameters` (:464-474) intends —
+        # same parameter name, shape, dtype and initial scale — and the forward is the reference's own statement (pinned by running the reference's
+        # forward with the parameter attached by hand: tests/golden/make_golden.py `case_toeplitz`).
         self.use_toeplitz = use_toeplitz
-        self.toeplitz_kernel = None
         if use_toeplitz:
-            # the reference cannot construct this option on current PyTorch (register_parameter on an
-            # existing attribute, spectre.py:453-457), so there is nothing to be compatible with
-            raise NotImplementedError("use_toeplitz=True is not supported (the reference itself fails to construct it)")
+            self.toeplitz_kernel = nn.Parameter(torch.randn(2 * toeplitz_bw + 1, dtype=torch.cfloat) / math.sqrt(2 * toeplitz_bw + 1))
+        else:
+            self.toeplitz_kernel = None
         self.toeplitz_bw = toeplitz_bw
         self.dropout = nn.Dropout(dropout_p) if dropout_p > 0 else nn.Identity()
 
@@ -234,6 +254,8 @@ class SpectreHead(nn.Module):
         # .float(): under autocast the MLP returns bf16 / fp16, which view_as_complex refuses (the reference raises there: it is fp32-only);
         # the filter is complex64 either way, the mix then runs on the autocast dtype's rows (bf16 storage, fp32 arithmetic)
         anchors = torch.view_as_complex(self.gate_mlp(q_pool).float().view(Bsz, self.G, self.B, 2))
+        if self.use_toeplitz:                                                   # spectre.py:519-521
+            anchors = anchors + complex_conv1d(anchors, self.toeplitz_kernel, self.toeplitz_bw)
         wants_graph = torch.is_grad_enabled() and (anchors.requires_grad or self.modrelu.bias.requires_grad or
                                                    (pos_phase is not None and pos_phase.requires_grad))
         if x.is_cuda and anchors.dtype == torch.complex64 and not wants_graph:

