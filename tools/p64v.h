@@ -154,7 +154,7 @@ template <int SPLIT> constexpr int p64v_younger_first() { return 4 * (8 - SPLIT)
 //         right behind E2 of the previous one, none behind its stores (round 3: the fp32 kernel's late groups cost a memory latency
 //         per tile — same-box ablation: loads only 1.11 ms, stores only 0.90, neither 0.84).
 // OUT_BF16 = bf16 rows out (round to nearest even, like every other kernel here): a lane stores its 4 channels as 8 bytes.
-template <int SPLIT, int PF, bool WITH_MEM = false, bool IN_BF16 = false, bool OUT_BF16 = false, int GANGX = 0, int AUXD = 0, int AUXL = 0, int AUXS = 0, int PRIO = 0, int MAPX = 0, int DSPREAD = 0, int SYNCP = 0, int TSTAMP = 0, int PFL2 = 0, int STAG = 0, int PFSP = 0, int LATE = 0, int RLF = 0, int PARK = 0, int ESPREAD = 1, int EARLY1 = 0, int SKEW = 0, int MEET = 0>
+template <int SPLIT, int PF, bool WITH_MEM = false, bool IN_BF16 = false, bool OUT_BF16 = false, int GANGX = 0, int AUXD = 0, int AUXL = 0, int AUXS = 0, int PRIO = 0, int MAPX = 0, int DSPREAD = 0, int SYNCP = 0, int TSTAMP = 0, int PFL2 = 0, int STAG = 0, int PFSP = 0, int LATE = 0, int RLF = 0, int PARK = 0, int ESPREAD = 1, int EARLY1 = 0, int SKEW = 0, int MEET = 0, int LAG = 0>
 __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) {
   constexpr int ESI = IN_BF16 ? 2 : 4, ESO = OUT_BF16 ? 2 : 4;   // bytes per input / output element
   constexpr float inv_n = 1.0f / 4096.0f;
@@ -274,6 +274,10 @@ __global__ void __launch_bounds__(512, 2) spectre_mix_p64v(const RegtileArgs a) 
     cur_t = __builtin_amdgcn_readfirstlane((int)tick_lds[0]); nxt_t = __builtin_amdgcn_readfirstlane((int)tick_lds[1]);
     __syncthreads();
   }
+  // LAG (round 6, third session): the pair's FOLLOWER (odd workgroup) starts LAG x 64 clocks late and stays that far behind for the whole launch — its
+  // load requests then find their lines fetched by the leader's (one request per line in the L2's miss path instead of two, tools/fold_lab.hip), at the
+  // price of its half-line stores arriving that much later than the leader's
+  if constexpr (LAG > 0) { if (wg_lin & 1) __builtin_amdgcn_s_sleep(LAG); }
   const int pair_base = (MAPX == 4 || MAPX == 5) ? base4 + 2 * remap4(cur_t) + member4 : MAPX == 3 ? xcd_base + cur_t : MAPX == 2 ? ((bx / 16) * 8 + bx % 8) * 2 + (bx / 8) % 2 : MAPX ? wg_lin : (wg_lin / GANG) * a.tpw * GANG + (wg_lin % GANG);
   const int TS = MAPX ? a.n_wg : GANG;
   if ((MAPX == 4 || MAPX == 5) ? cur_t >= per_xcd4 : MAPX == 3 ? cur_t >= per_xcd : pair_base >= a.n_tiles) return;
